@@ -1,0 +1,112 @@
+/*
+ * megastep_hip.h -- C-ABI of the MI355X (gfx950) simulation core.
+ *
+ * This is the drop-in boundary for the reference's native extension `megastepcuda`
+ * (surfaced in Python as `megastep.cuda`, /root/reference/megastep/__init__.py:7-20,
+ * bound in /root/reference/megastep/src/wrappers.cpp:30-173).  Every entry point below
+ * names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes, no torch / ATen types.
+ *   - the library never allocates, frees or synchronises: the caller owns every buffer
+ *     and all work is enqueued asynchronously on the hipStream_t it passes
+ *     (the reference enqueues on at::cuda::getCurrentCUDAStream(), kernels.cu:30-32).
+ *   - configuration travels by value with each call (the reference keeps it in
+ *     process-global __constant__ memory, kernels.cu:12-27), so one process can drive
+ *     several devices / configurations.
+ *   - every function returns MS_OK (0) or a negative MS_E* code; ms_strerror() explains it.
+ *     (The reference raises c10::Error through pybind, common.h:12-14,33-37.)
+ *   - all float data is IEEE binary32, all index data int32, as in the reference
+ *     (rebar/arrdict.py:79-88, common.h:122).
+ */
+#ifndef MEGASTEP_HIP_H
+#define MEGASTEP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_ABI_VERSION 1
+
+#define MS_OK            0
+#define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
+#define MS_EHIP         -2   /* a HIP runtime call failed; see ms_last_hip_error()  */
+#define MS_EUNSUPPORTED -3   /* shape outside what the kernels support              */
+#define MS_ENODEVICE    -4   /* no usable gfx950 device                             */
+
+/* Replaces `initialize(agent_radius, res, fov, fps)` (wrappers.cpp:53, kernels.cu:18-27). */
+typedef struct MsConfig {
+    float agent_radius;   /* collision radius and near plane, metres (core.py:14)  */
+    int   res;            /* rays per agent, R                                      */
+    float fov;            /* field of view, degrees (< 180)                         */
+    float fps;            /* simulation steps per second                            */
+} MsConfig;
+
+/* Replaces `Scenery` + its three `Ragged`s (common.h:102-155,179-214). Device pointers. */
+typedef struct MsScenery {
+    int n_envs, n_agents, n_model;   /* N, A, M = model.size(0)                                */
+    const float* lights_vals;        /* (sum I, 3)  x, y, intensity                            */
+    const int*   lights_widths;      /* (N,)                                                   */
+    const int*   lights_starts;      /* (N,)                                                   */
+    float*       lines_vals;         /* (sum L, 2, 2) [endpoint][xy]; rows [0, A*M) of each env
+                                        are the agents' models and are REWRITTEN by ms_render
+                                        (kernels.cu:316-317). Must be 16-byte aligned.         */
+    const int*   lines_widths;       /* (N,)                                                   */
+    const int*   lines_starts;       /* (N,)                                                   */
+    const int*   lines_inverse;      /* (sum L,) global line -> env                            */
+    const float* textures_vals;      /* (sum T, 3) linear RGB, ragged per GLOBAL line          */
+    const int*   textures_widths;    /* (sum L,) texels per line                               */
+    const int*   textures_starts;    /* (sum L,)                                               */
+    const int*   textures_inverse;   /* (sum T,) texel -> global line                          */
+    const float* model;              /* (M, 2, 2) agent outline in the agent frame             */
+    float*       baked_vals;         /* (sum T,) written by ms_bake, read by ms_render         */
+    int n_lines_total, n_lights_total, n_texels_total;
+} MsScenery;
+
+/* Replaces `Agents` (common.h:157-177). Updated IN PLACE by ms_physics. */
+typedef struct MsAgents {
+    float* angles;        /* (N, A)    degrees           */
+    float* positions;     /* (N, A, 2) metres            */
+    float* angvelocity;   /* (N, A)    degrees / second  */
+    float* velocity;      /* (N, A, 2) metres / second   */
+} MsAgents;
+
+/* Replaces `Render` (common.h:216-222). Caller-allocated outputs. */
+typedef struct MsRender {
+    int*   indices;       /* (N, A, R)    line index within the env, -1 on a miss */
+    float* locations;     /* (N, A, R)    position along the line, NaN on a miss  */
+    float* dots;          /* (N, A, R)    ray . line direction,    NaN on a miss  */
+    float* distances;     /* (N, A, R)    metres, +inf on a miss                  */
+    float* screen;        /* (N, A, R, 3) linear RGB, 0 on a miss                 */
+} MsRender;
+
+int         ms_abi_version(void);
+const char* ms_strerror(int code);
+/* hipError_t of the most recent failing HIP call made by this library on this thread (0 if none). */
+int         ms_last_hip_error(void);
+/* Number of visible HIP devices, or MS_ENODEVICE. Lets the host side fail loudly up front. */
+int         ms_device_count(void);
+
+/* Replaces `bake(scenery)` (wrappers.cpp:61, kernels.cu:270-293): static lighting of every texel
+ * into scenery->baked_vals. `config` is unused by this stage and may be NULL (the reference's bake reads none of the
+ * initialize() constants and runs before any Core exists, scene.py:98). */
+int ms_bake(const MsScenery* scenery, const MsConfig* config, void* hip_stream);
+
+/* Replaces `physics(scenery, agents) -> Physics` (wrappers.cpp:69, kernels.cu:179-230):
+ * collision-limited integration of the agents, in place; `progress` is the (N, A) output that
+ * the reference returns as Physics.progress. */
+int ms_physics(const MsScenery* scenery, const MsAgents* agents, float* progress,
+               const MsConfig* config, void* hip_stream);
+
+/* Replaces `render(scenery, agents) -> Render` (wrappers.cpp:82, kernels.cu:297-475):
+ * draw (rewrites the agent rows of lines_vals) -> raycast -> shade, one fused launch. */
+int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* out,
+              const MsConfig* config, void* hip_stream);
+
+/* Scalar helper exported for tests: sin(pi x), cos(pi x) exactly as the kernels evaluate them. */
+void ms_host_sincospi(float x, float* s, float* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGASTEP_HIP_H */

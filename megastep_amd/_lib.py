@@ -1,0 +1,97 @@
+"""Loader for ``libmegastep_hip.so`` - the hipcc-built gfx950 library behind ``include/megastep_hip.h``.
+
+Counterpart of the reference's JIT build-and-load at import (reference: megastep/__init__.py:7-20): the library is
+built in-tree with hipcc (``csrc/Makefile``) and bound with ctypes. There is NO fallback: if the library cannot be
+built or loaded, or no HIP device is visible when a kernel is requested, this raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libmegastep_hip.so')
+ABI_VERSION = 1
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int)
+
+
+class MsConfig(C.Structure):
+    _fields_ = [('agent_radius', C.c_float), ('res', C.c_int), ('fov', C.c_float), ('fps', C.c_float)]
+
+
+class MsScenery(C.Structure):
+    _fields_ = [
+        ('n_envs', C.c_int), ('n_agents', C.c_int), ('n_model', C.c_int),
+        ('lights_vals', C.c_void_p), ('lights_widths', C.c_void_p), ('lights_starts', C.c_void_p),
+        ('lines_vals', C.c_void_p), ('lines_widths', C.c_void_p), ('lines_starts', C.c_void_p),
+        ('lines_inverse', C.c_void_p),
+        ('textures_vals', C.c_void_p), ('textures_widths', C.c_void_p), ('textures_starts', C.c_void_p),
+        ('textures_inverse', C.c_void_p),
+        ('model', C.c_void_p), ('baked_vals', C.c_void_p),
+        ('n_lines_total', C.c_int), ('n_lights_total', C.c_int), ('n_texels_total', C.c_int)]
+
+
+class MsAgents(C.Structure):
+    _fields_ = [('angles', C.c_void_p), ('positions', C.c_void_p), ('angvelocity', C.c_void_p), ('velocity', C.c_void_p)]
+
+
+class MsRender(C.Structure):
+    _fields_ = [('indices', C.c_void_p), ('locations', C.c_void_p), ('dots', C.c_void_p), ('distances', C.c_void_p),
+                ('screen', C.c_void_p)]
+
+
+#: every symbol include/megastep_hip.h declares
+SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics',
+           'ms_render', 'ms_host_sincospi')
+
+
+def build(force=False):
+    """Compiles csrc/megastep_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, 'megastep_hip.hip')
+    hdr = os.path.join(_HERE, '..', 'include', 'megastep_hip.h')
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        proc = subprocess.run(['make', '-C', CSRC, '-B', 'libmegastep_hip.so'], capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f'hipcc build of libmegastep_hip.so failed:\n{proc.stdout}\n{proc.stderr}')
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library. Builds it first if it is missing; raises if that is impossible."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        handle = C.CDLL(LIB_PATH)
+        missing = [s for s in SYMBOLS if not hasattr(handle, s)]
+        if missing:
+            raise ImportError(f'{LIB_PATH} does not export {missing}')
+        handle.ms_abi_version.restype = C.c_int
+        handle.ms_strerror.restype = C.c_char_p
+        handle.ms_strerror.argtypes = [C.c_int]
+        handle.ms_last_hip_error.restype = C.c_int
+        handle.ms_device_count.restype = C.c_int
+        handle.ms_bake.argtypes = [C.POINTER(MsScenery), C.POINTER(MsConfig), C.c_void_p]
+        handle.ms_physics.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.c_void_p, C.POINTER(MsConfig), C.c_void_p]
+        handle.ms_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]
+        handle.ms_host_sincospi.argtypes = [C.c_float, _f32p, _f32p]
+        for name in ('ms_bake', 'ms_physics', 'ms_render'):
+            getattr(handle, name).restype = C.c_int
+        if handle.ms_abi_version() != ABI_VERSION:
+            raise ImportError(f'{LIB_PATH} has ABI {handle.ms_abi_version()}, this package needs {ABI_VERSION}; rebuild it')
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    """Turns a negative MS_E* return into a RuntimeError, the way the reference's AT_ASSERTs surface in Python."""
+    if code != 0:
+        h = lib()
+        raise RuntimeError(f'megastep_hip: {h.ms_strerror(code).decode()} (code {code}, hipError {h.ms_last_hip_error()})')

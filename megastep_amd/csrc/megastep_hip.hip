@@ -1,0 +1,651 @@
+// megastep_hip.hip -- gfx950 (MI355X / CDNA4) simulation core behind include/megastep_hip.h.
+//
+// Three kernels, all written wave64-first:
+//
+//   physics_kernel  one wavefront per (env, agent): lanes stride over the env's wall segments
+//                   (16 B / lane, coalesced), each lane folds its own fminf, a 6-step DPP/shuffle
+//                   min-reduce finishes it, then the integration epilogue runs in the same launch
+//                   behind one workgroup barrier.           (reference: kernels.cu:179-230)
+//   render_kernel   one wavefront per (env, agent, 64-ray group), lane = ray.  Pass 1 (lane = line)
+//                   frustum-culls the env's segments against the wave's ray wedge, precomputes the
+//                   ray-independent half of the intersection and compacts the survivors IN ORDER
+//                   into a per-wave LDS list.  Pass 2 (lane = ray) folds over the list with
+//                   broadcast LDS reads and a division-free hit test.  Pass 3 shades.  draw, raycast
+//                   and shader (three launches + five allocations in the reference) are one launch.
+//                                                            (reference: kernels.cu:297-475)
+//   bake_kernel     one workgroup per env, lane = texel, the env's occluders staged once in LDS.
+//                                                            (reference: kernels.cu:238-293)
+//
+// Numerics contract: IEEE binary32 evaluated as the reference source is written -- compiled with
+// -ffp-contract=off, correctly rounded divide/sqrt, no fast-math -- so that collision masks and hit
+// indices are bit-identical to the CPU oracle and floats agree far inside the 1e-5 tolerance.
+// Every shortcut below (division-free tests, culling, hoisting) is exact, not approximate.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../../include/megastep_hip.h"
+
+namespace {
+
+constexpr float AMBIENT = .1f;      // kernels.cu:9
+constexpr float LUMINANCE = 2.f;    // kernels.cu:240
+constexpr int WAVE = 64;
+constexpr int WG = 256;             // 4 waves per workgroup
+constexpr int WAVES = WG/WAVE;
+
+thread_local int g_last_hip_error = 0;
+
+// ------------------------------------------------------------------------------------------------
+// Scalar math shared by the kernels (device) and ms_host_sincospi (host).
+// ------------------------------------------------------------------------------------------------
+
+struct P2 { float x, y; };
+
+__host__ __device__ inline P2 p2(float x, float y) { return P2{x, y}; }
+__host__ __device__ inline P2 operator-(P2 a, P2 b) { return p2(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline P2 operator+(P2 a, P2 b) { return p2(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline P2 operator*(P2 a, float v) { return p2(a.x*v, a.y*v); }
+__host__ __device__ inline P2 operator/(P2 a, float v) { return p2(a.x/v, a.y/v); }
+__host__ __device__ inline float len2(P2 a) { return a.x*a.x + a.y*a.y; }
+__host__ __device__ inline float len(P2 a) { return sqrtf(len2(a)); }
+__host__ __device__ inline float cross(P2 v, P2 w) { return v.x*w.y - v.y*w.x; }
+__host__ __device__ inline float dot(P2 v, P2 w) { return v.x*w.x + v.y*w.y; }
+
+// fminf/fmaxf with NaN and signed-zero behaviour spelled out (first operand wins ties).
+__host__ __device__ inline float ms_min(float a, float b) { if (a != a) return b; return (b < a) ? b : a; }
+__host__ __device__ inline float ms_max(float a, float b) { if (a != a) return b; return (b > a) ? b : a; }
+
+// sin(pi x), cos(pi x); stands in for sinpif/cospif (kernels.cu:305-306,336-337).  The range
+// reduction is exact in binary32, the kernel is a Taylor series in binary64 rounded once.
+__host__ __device__ inline void sincospi_f(float x, float& s, float& c) {
+    float t = x*0.5f;
+    t = t - floorf(t);
+    const float y = 2.f*t;
+    const float nq = rintf(2.f*y);
+    const float z = y - 0.5f*nq;
+    const int q = ((int)nq) & 3;
+    const double zd = (double)z;
+    const double w = zd*zd;
+    double ps = -2.1915353447830217e-05;
+    ps = ps*w + 0.00046630280576761255; ps = ps*w + -0.0073704309457143504;
+    ps = ps*w + 0.08214588661112823;    ps = ps*w + -0.5992645293207921;
+    ps = ps*w + 2.5501640398773455;     ps = ps*w + -5.16771278004997;
+    ps = ps*w + 3.141592653589793;
+    ps = ps*zd;
+    double pc = 4.303069587032947e-06;
+    pc = pc*w + -0.0001046381049248457; pc = pc*w + 0.0019295743094039231;
+    pc = pc*w + -0.02580689139001406;   pc = pc*w + 0.2353306303588932;
+    pc = pc*w + -1.3352627688545895;    pc = pc*w + 4.0587121264167685;
+    pc = pc*w + -4.934802200544679;
+    pc = pc*w + 1.0;
+    const float S = (float)ps, C = (float)pc;
+    switch (q) {
+        case 0:  s =  S; c =  C; break;
+        case 1:  s =  C; c = -S; break;
+        case 2:  s = -S; c = -C; break;
+        default: s = -C; c =  S; break;
+    }
+}
+
+// ATen `%` on floats (remainder): fmod then sign fix-up.            kernels.cu:173-175
+__device__ inline float remainder_f(float a, float b) {
+    float m = fmodf(a, b);
+    if ((m != 0.f) && ((b < 0.f) != (m < 0.f))) m += b;
+    return m;
+}
+__device__ inline float normalize_degrees(float a) {
+    return remainder_f(remainder_f(a, 360.f) + 180.f, 360.f) - 180.f;
+}
+
+struct Isect { float s, t; };
+// kernels.cu:67-89
+__device__ inline Isect intersect(P2 P, P2 U, P2 Q, P2 V) {
+    const float UxV = cross(U, V);
+    if (fabsf(UxV) < 1.e-3f) return Isect{INFINITY, INFINITY};
+    const P2 PQ = Q - P;
+    return Isect{cross(PQ, V)/UxV, cross(PQ, U)/UxV};
+}
+
+struct Proj { float s, d; };
+// kernels.cu:91-107
+__device__ inline Proj project(P2 P, P2 U, P2 Q) {
+    const float u = len(U) + 1e-6f;
+    const P2 PQ = Q - P;
+    return Proj{dot(PQ, U)/(u*u), fabsf(cross(PQ, U))/u};
+}
+
+// kernels.cu:109-118; never returns NaN or -0, so the folds over it are order-independent.
+__device__ inline float sensibilize(float p) {
+    const float q = p*.99f;
+    if (!(q > 0.f)) return 0.f;
+    return (q < 1.f) ? q : 1.f;
+}
+
+// kernels.cu:119-133
+__device__ inline float collision_cc(P2 p0, P2 v0, P2 p1, P2 v1, float agent_radius) {
+    const float r = 1.001f*2.f*agent_radius;
+    float x = 1.f;
+    const P2 dv = v0 - v1;
+    const Proj a = project(p0, dv, p1);
+    if ((0 < a.s) & (a.d < r)) {
+        const float backoff = sqrtf(r*r - a.d*a.d)/len(dv);
+        x = ms_min(x, sensibilize(a.s - backoff));
+    }
+    return x;
+}
+
+// kernels.cu:135-171
+__device__ inline float collision_cs(P2 p, P2 v, P2 la, P2 lb, float agent_radius) {
+    const float r = 1.001f*agent_radius;
+    float x = 1.f;
+    const P2 lv = lb - la;
+    const float vlen = len(v);
+    const float dp = project(la, lv, p).d;   // used by both the crossing and the side test
+
+    const Isect mid = intersect(p, v, la, lv);
+    if ((0 < mid.s) & (mid.s < 1) & (0 < mid.t) & (mid.t < 1)) {
+        x = ms_min(x, sensibilize((1 - r/dp)*mid.s));
+    }
+    const Proj a = project(p, v, la);
+    if ((0 < a.s) & (a.d < r)) {
+        const float backoff = sqrtf(r*r - a.d*a.d)/vlen;
+        x = ms_min(x, sensibilize(a.s - backoff));
+    }
+    const Proj b = project(p, v, lb);
+    if ((0 < b.s) & (b.d < r)) {
+        const float backoff = sqrtf(r*r - b.d*b.d)/vlen;
+        x = ms_min(x, sensibilize(b.s - backoff));
+    }
+    const Proj side = project(la, lv, p + v);
+    if ((0 < side.s) & (side.s < 1) & (side.d < r)) {
+        const float dq = side.d;
+        x = ms_min(x, sensibilize((dp - r)/(dp - dq)));
+    }
+    return x;
+}
+
+__device__ inline float wave_min(float x) {
+    // inputs are in [+0, 1] and never NaN, so fminf is exact and order-independent here
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fminf(x, __shfl_xor(x, o, WAVE));
+    return x;
+}
+
+__device__ inline float bits_f(uint32_t u) { return __uint_as_float(u); }
+__device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
+
+// ------------------------------------------------------------------------------------------------
+// physics                                                                    kernels.cu:179-230
+// ------------------------------------------------------------------------------------------------
+// A workgroup owns `envs_per_wg` whole envs so that every read of the start-of-step agent state
+// happens before the barrier and every write after it (agents of one env read each other).
+__global__ __launch_bounds__(WG) void physics_kernel(
+        const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
+        const float agent_radius, const float fps, const int envs_per_wg) {
+    extern __shared__ float s_progress[];   // [envs_per_wg*A]
+    const int N = sc.n_envs, A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tasks = envs_per_wg*A;
+    const int env0 = blockIdx.x*envs_per_wg;
+    const float4* __restrict__ lines4 = reinterpret_cast<const float4*>(sc.lines_vals);
+    const float2* __restrict__ pos2 = reinterpret_cast<const float2*>(ag.positions);
+    const float2* __restrict__ vel2 = reinterpret_cast<const float2*>(ag.velocity);
+
+    for (int t = wave; t < tasks; t += WAVES) {
+        const int n = env0 + t/A, a = t % A;
+        if (n >= N) continue;
+        const float2 pp = pos2[n*A + a], mm = vel2[n*A + a];
+        const P2 p0 = p2(pp.x, pp.y);
+        const P2 v0 = p2(mm.x, mm.y)/fps;
+        float x = 1.f;
+        for (int d1 = lane; d1 < A; d1 += WAVE) {
+            if (d1 != a) {
+                const float2 q = pos2[n*A + d1], m1 = vel2[n*A + d1];
+                x = ms_min(x, collision_cc(p0, v0, p2(q.x, q.y), p2(m1.x, m1.y)/fps, agent_radius));
+            }
+        }
+        const int L = sc.lines_widths[n];
+        const float4* __restrict__ ln = lines4 + sc.lines_starts[n];
+        for (int l = AF + lane; l < L; l += WAVE) {
+            const float4 w = ln[l];
+            x = ms_min(x, collision_cs(p0, v0, p2(w.x, w.y), p2(w.z, w.w), agent_radius));
+        }
+        x = wave_min(x);
+        if (lane == 0) s_progress[t] = x;
+    }
+    __syncthreads();
+    // epilogue, kernels.cu:224-227
+    float2* __restrict__ pos2w = reinterpret_cast<float2*>(ag.positions);
+    float2* __restrict__ vel2w = reinterpret_cast<float2*>(ag.velocity);
+    for (int t = tid; t < tasks; t += WG) {
+        const int n = env0 + t/A, a = t % A;
+        if (n >= N) continue;
+        const int i = n*A + a;
+        const float x = s_progress[t];
+        float2 p = pos2w[i], v = vel2w[i];
+        p.x = p.x + x*v.x/fps;
+        p.y = p.y + x*v.y/fps;
+        pos2w[i] = p;
+        float w = ag.angvelocity[i];
+        ag.angles[i] = normalize_degrees(ag.angles[i] + x*w/fps);
+        if (x < 1) {
+            vel2w[i] = make_float2(0.f, 0.f);
+            ag.angvelocity[i] = 0.f;
+        }
+        progress[i] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lighting                                                                    kernels.cu:238-268
+// ------------------------------------------------------------------------------------------------
+// `obstructed` for one (light, wall) pair without the two divides: with d' = |UxV| and the
+// numerators sign-flipped by sign(UxV), 0 < n/d < 1  <=>  0 < n' < d' exactly in round-to-nearest
+// (a quotient of two binary32 values can only round to 1 when it is 1), and 0 < s <=> 0 < c'.
+// Only s < .999f needs the quotient itself.
+__device__ inline bool light_blocked(P2 I, P2 U, float ax, float ay, float vx, float vy) {
+    const P2 V = p2(vx, vy);
+    const float UxV = cross(U, V);
+    const float ad = fabsf(UxV);
+    if (ad < 1.e-3f) return false;                       // (inf, inf): never obstructs
+    const P2 PQ = p2(ax, ay) - I;
+    const uint32_t sg = f_bits(UxV) & 0x80000000u;
+    const float nt = bits_f(f_bits(cross(PQ, U)) ^ sg);
+    const float cs = cross(PQ, V);
+    const float ns = bits_f(f_bits(cs) ^ sg);
+    if (!((nt > 0.f) & (nt < ad) & (ns > 0.f))) return false;
+    return (cs/UxV) < .999f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// render = draw + raycast + shader                                            kernels.cu:297-475
+// ------------------------------------------------------------------------------------------------
+constexpr int CH = 256;   // lines culled per chunk = capacity of a wave's candidate list
+
+struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
+
+// The drawn (world-frame) model line `l` of env n: draw_kernel, kernels.cu:297-318.
+__device__ inline float4 drawn_line(const MsScenery& sc, const MsAgents& ag, int n, int l) {
+    const int M = sc.n_model, a = l / M, m = l - a*M;
+    float s, c;
+    sincospi_f(ag.angles[n*sc.n_agents + a]/180.f, s, c);
+    const float2 p = reinterpret_cast<const float2*>(ag.positions)[n*sc.n_agents + a];
+    const float4 mdl = reinterpret_cast<const float4*>(sc.model)[m];
+    float4 w;
+    w.x = c*mdl.x - s*mdl.y + p.x;
+    w.y = s*mdl.x + c*mdl.y + p.y;
+    w.z = c*mdl.z - s*mdl.w + p.x;
+    w.w = s*mdl.z + c*mdl.w + p.y;
+    return w;
+}
+
+// kernels.cu:394-405
+struct Filt { int l, r; float lw, rw; };
+__device__ inline Filt tex_filter(float x, int w) {
+    Filt f;
+    const float y = ms_min(x*(w + 1), (float)(w - 1));
+    f.l = (int)ms_max(y - 1, 0.f);
+    f.r = (int)ms_min(y, (float)(w - 1));
+    const float ld = fabsf(y - (f.l + 1)) + 1.e-3f;
+    const float rd = fabsf(y - (f.r + 1)) + 1.e-3f;
+    f.lw = rd/(ld + rd);
+    f.rw = ld/(ld + rd);
+    return f;
+}
+
+__global__ __launch_bounds__(WG) void render_kernel(
+        const MsScenery sc, const MsAgents ag, const MsRender out,
+        const float agent_radius, const float half_screen, const int R, const int n_fans) {
+    __shared__ Cand  s_cand[WAVES][CH];
+    __shared__ float2 s_cand2[WAVES][CH];       // (cross(PQ, V), line index bits)
+    __shared__ float s_screen[WAVES][3*WAVE];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
+    // logical blocks so the fans of one env (and its lines) stay behind one L2.
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
+    const int lb = (xcd < r8 ? xcd*(q8 + 1) : r8*(q8 + 1) + (xcd - r8)*q8) + ix;
+
+    const int fan = lb*WAVES + wave;
+    if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
+    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int G = (R + WAVE - 1)/WAVE, F = A*G;
+    const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
+    const int r = g*WAVE + lane;
+    const int r_last = min(g*WAVE + WAVE - 1, R - 1);
+
+    const int L = sc.lines_widths[n];
+    const int base = sc.lines_starts[n];
+    float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
+
+    // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
+    // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
+    // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
+    if (g == 0) {
+        for (int m = lane; m < sc.n_model; m += WAVE) ln[a*sc.n_model + m] = drawn_line(sc, ag, n, a*sc.n_model + m);
+    }
+
+    // --- ray setup (kernels.cu:334-344)
+    float sn, cs;
+    sincospi_f(ag.angles[n*A + a]/180.f, sn, cs);
+    const float2 pp = reinterpret_cast<const float2*>(ag.positions)[n*A + a];
+    const float Rf = (float)R;
+    const float uy = (Rf - 2*(float)r - 1)*half_screen/Rf;            // ray_y, kernels.cu:234-236
+    const float rx = cs*1.f - sn*uy, ry = sn*1.f + cs*uy;
+    const float rlen = sqrtf(rx*rx + ry*ry);
+    const float near = agent_radius/rlen;
+
+    // wedge of this wave's rays in the agent frame: y_lo*x' <= y' <= y_hi*x', x' > 0
+    const float y_hi = (Rf - 2*(float)(g*WAVE) - 1)*half_screen/Rf;
+    const float y_lo = (Rf - 2*(float)r_last - 1)*half_screen/Rf;
+    const float k_hi = sqrtf(1.f + y_hi*y_hi), k_lo = sqrtf(1.f + y_lo*y_lo);
+
+    float nearest_s = INFINITY;
+    int nearest_idx = -1;
+
+    for (int c0 = 0; c0 < L; c0 += CH) {
+        // ---- pass 1: lane = line. Cull + precompute + ordered compaction into LDS.
+        int cnt = 0;
+        const int c1 = min(c0 + CH, L);
+        for (int l0 = c0; l0 < c1; l0 += WAVE) {
+            const int l = l0 + lane;
+            bool keep = false;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l < c1) {
+                w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                const float dax = w.x - pp.x, day = w.y - pp.y;       // PQ = Q - P
+                const float dbx = w.z - pp.x, dby = w.w - pp.y;
+                // agent-frame coordinates of both endpoints
+                const float xa = cs*dax + sn*day, ya = cs*day - sn*dax;
+                const float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
+                // Conservative: drop a segment only if it lies wholly, by a margin ~1e3 rounding
+                // errors wide, in a half-plane that no forward ray of this wave can enter.
+                const float dl = 1e-3f + 1e-4f*(fabsf(dax) + fabsf(day) + fabsf(dbx) + fabsf(dby));
+                const bool behind = (xa < -dl) & (xb < -dl);
+                const bool above = (ya - y_hi*xa > dl*k_hi) & (yb - y_hi*xb > dl*k_hi);
+                const bool below = (y_lo*xa - ya > dl*k_lo) & (y_lo*xb - yb > dl*k_lo);
+                keep = !(behind | above | below);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                const float vx = w.z - w.x, vy = w.w - w.y;           // v = b - a
+                const float pqx = w.x - pp.x, pqy = w.y - pp.y;
+                s_cand[wave][pos] = Cand{pqx, pqy, vx, vy};
+                s_cand2[wave][pos] = make_float2(pqx*vy - pqy*vx, __int_as_float(l));   // cross(PQ, V)
+            }
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- pass 2: lane = ray. Ordered fold over the candidates (kernels.cu:352-377).
+        // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked).
+        #pragma unroll 4
+        for (int i = 0; i < cnt; i++) {
+            const Cand cd = s_cand[wave][i];
+            const float d = rx*cd.vy - ry*cd.vx;                       // cross(ru, v)
+            const float nt = cd.pqx*ry - cd.pqy*rx;                    // cross(PQ, ru)
+            const float ad = fabsf(d);
+            const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+            const bool hit = (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+            if (hit) {
+                const float2 c2 = s_cand2[wave][i];
+                const float sv = c2.x/d;                               // q.s
+                if ((near < sv) & (sv < nearest_s - 1.e-4f)) {
+                    nearest_s = sv;
+                    nearest_idx = __float_as_int(c2.y);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
+    float loc = NAN, dt = NAN;
+    float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nearest_idx >= 0) {
+        hw = (nearest_idx < AF) ? drawn_line(sc, ag, n, nearest_idx) : ln[nearest_idx];
+        const float vx = hw.z - hw.x, vy = hw.w - hw.y;
+        const float d = rx*vy - ry*vx;
+        const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
+        loc = (pqx*ry - pqy*rx)/d;
+        const float dtop = rx*vx + ry*vy;
+        const float dbot = rlen*sqrtf(vx*vx + vy*vy);
+        dt = dtop/(dbot + 1.e-6f);
+    }
+    const size_t o = ((size_t)n*A + a)*R + r;
+    if (r < R) {
+        out.indices[o] = nearest_idx;
+        out.locations[o] = loc;
+        out.dots[o] = dt;
+        out.distances[o] = nearest_s*rlen;
+    }
+
+    // ---- pass 3: shade (kernels.cu:407-450)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    Filt f = Filt{0, 0, 0.f, 0.f};
+    int tstart = 0;
+    const bool is_hit = (nearest_idx >= 0) & (r < R);
+    if (is_hit) {
+        const int start = base + nearest_idx;
+        f = tex_filter(loc, sc.textures_widths[start]);
+        tstart = sc.textures_starts[start];
+    }
+    float intensity = 0.f;
+    const bool dynamic = is_hit & (nearest_idx < AF);
+    if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
+
+    // Rays that landed on an agent need light_intensity() at the hit point: lights x walls
+    // occlusion tests.  Done wave-cooperatively (lane = wall) one such ray at a time, so one
+    // unlucky lane does not serialise 6k tests while 63 lanes idle.
+    unsigned long long dyn = __ballot(dynamic);
+    if (dyn) {
+        const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;
+        const int num_i = sc.lights_widths[n];
+        const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+        while (dyn) {
+            const int j = __ffsll((long long)dyn) - 1;
+            dyn &= dyn - 1;
+            const P2 Cp = p2(__shfl(cx_l, j, WAVE), __shfl(cy_l, j, WAVE));
+            float acc = AMBIENT;
+            for (int i = 0; i < num_i; i++) {
+                const P2 I = p2(lights[3*i], lights[3*i + 1]);
+                const float Ii = lights[3*i + 2];
+                const P2 U = Cp - I;
+                bool blocked = false;
+                for (int l0 = AF; l0 < L; l0 += WAVE) {
+                    const int l1 = l0 + lane;
+                    bool bl = false;
+                    if (l1 < L) {
+                        const float4 w = ln[l1];
+                        bl = light_blocked(I, U, w.x, w.y, w.z - w.x, w.w - w.y);
+                    }
+                    if (__ballot(bl)) { blocked = true; break; }
+                }
+                const float d2 = len2(I - Cp);
+                if (!blocked) acc += LUMINANCE*Ii/ms_max(d2, 1.f);
+            }
+            if (lane == j) intensity = ms_min(acc, 1.f);
+        }
+    }
+
+    if (is_hit) {
+        const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
+        const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
+        const float dn = 1 - dt*dt;
+        s0 = dn*intensity*(f.lw*tl[0] + f.rw*tr[0]);
+        s1 = dn*intensity*(f.lw*tl[1] + f.rw*tr[1]);
+        s2 = dn*intensity*(f.lw*tl[2] + f.rw*tr[2]);
+    }
+    // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
+    s_screen[wave][3*lane] = s0; s_screen[wave][3*lane + 1] = s1; s_screen[wave][3*lane + 2] = s2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nfl = 3*(r_last - g*WAVE + 1);
+    float* __restrict__ scr = out.screen + 3*(((size_t)n*A + a)*R + g*WAVE);
+    #pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int j = lane + k*WAVE;
+        if (j < nfl) scr[j] = s_screen[wave][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bake                                                                        kernels.cu:270-293
+// ------------------------------------------------------------------------------------------------
+constexpr int BAKE_WALLS = 2048;   // occluders staged per pass: 32 KiB of LDS
+
+__global__ __launch_bounds__(WG) void bake_kernel(const MsScenery sc) {
+    __shared__ float4 s_wall[BAKE_WALLS];        // (ax, ay, vx, vy)
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int AF = sc.n_agents*sc.n_model;
+    const int L = sc.lines_widths[n], base = sc.lines_starts[n];
+    if (L == 0) return;
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
+    const int num_i = sc.lights_widths[n];
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const int t0 = sc.textures_starts[base];
+    const int t1 = sc.textures_starts[base + L - 1] + sc.textures_widths[base + L - 1];
+    const int n_walls = max(L - AF, 0);
+    const bool single = n_walls <= BAKE_WALLS;
+
+    auto stage = [&](int w0) {
+        const int w1 = min(w0 + BAKE_WALLS, n_walls);
+        for (int i = w0 + tid; i < w1; i += WG) {
+            const float4 w = ln[AF + i];
+            s_wall[i - w0] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
+        }
+        return w1 - w0;
+    };
+    int staged = 0;
+    if (single) { staged = stage(0); __syncthreads(); }
+
+    for (int tb = t0; tb < t1; tb += WG) {       // uniform trip count: barriers inside are safe
+        const int t = tb + tid;
+        const bool live = t < t1;
+        P2 Cp = p2(0.f, 0.f);
+        if (live) {
+            const int l0 = sc.textures_inverse[t];
+            const float loc = ((unsigned)(t - sc.textures_starts[l0]) + .5f)/sc.textures_widths[l0];
+            const float4 w = reinterpret_cast<const float4*>(sc.lines_vals)[l0];
+            Cp = p2(w.x, w.y)*(1.f - loc) + p2(w.z, w.w)*loc;
+        }
+        float acc = AMBIENT;
+        for (int i0 = 0; i0 < num_i; i0 += 64) {               // lights in groups of 64 (one mask)
+            const int i1 = min(i0 + 64, num_i);
+            unsigned long long blocked = 0ull;
+            for (int w0 = 0; w0 < n_walls; w0 += BAKE_WALLS) {
+                if (!single) { __syncthreads(); staged = stage(w0); __syncthreads(); }
+                for (int i = i0; i < i1; i++) {
+                    const unsigned long long bit = 1ull << (i - i0);
+                    bool bl = ((blocked & bit) != 0) | !live;
+                    const P2 I = p2(lights[3*i], lights[3*i + 1]);
+                    const P2 U = Cp - I;
+                    for (int k = 0; k < staged; k++) {
+                        if (__all(bl)) break;                  // every texel of the wave is in shadow already
+                        const float4 w = s_wall[k];
+                        bl = bl | light_blocked(I, U, w.x, w.y, w.z, w.w);
+                    }
+                    if (bl) blocked |= bit;
+                }
+            }
+            for (int i = i0; i < i1; i++) {                     // accumulate in light order
+                const P2 I = p2(lights[3*i], lights[3*i + 1]);
+                const float d2 = len2(I - Cp);
+                if (!((blocked >> (i - i0)) & 1ull)) acc += LUMINANCE*lights[3*i + 2]/ms_max(d2, 1.f);
+            }
+        }
+        if (live) sc.baked_vals[t] = ms_min(acc, 1.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ------------------------------------------------------------------------------------------------
+int hip_fail(hipError_t e) { g_last_hip_error = (int)e; return MS_EHIP; }
+
+bool scenery_ok(const MsScenery* s) {
+    return s && s->n_envs > 0 && s->n_agents > 0 && s->n_model > 0 && s->lines_vals && s->lines_widths &&
+           s->lines_starts && s->model && ((uintptr_t)s->lines_vals % 16 == 0) && ((uintptr_t)s->model % 16 == 0);
+}
+bool agents_ok(const MsAgents* a) { return a && a->angles && a->positions && a->angvelocity && a->velocity; }
+bool config_ok(const MsConfig* c) {
+    return c && c->res > 0 && c->fps > 0.f && c->agent_radius > 0.f && c->fov > 0.f && c->fov < 180.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ms_abi_version(void) { return MS_ABI_VERSION; }
+
+const char* ms_strerror(int code) {
+    switch (code) {
+        case MS_OK: return "ok";
+        case MS_EINVAL: return "invalid argument (null/misaligned pointer, non-positive size or bad config)";
+        case MS_EHIP: return "a HIP runtime call failed (see ms_last_hip_error)";
+        case MS_EUNSUPPORTED: return "shape not supported by the gfx950 kernels";
+        case MS_ENODEVICE: return "no HIP device visible";
+        default: return "unknown megastep_hip error";
+    }
+}
+
+int ms_last_hip_error(void) { return g_last_hip_error; }
+
+int ms_device_count(void) {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_last_hip_error = (int)e; return MS_ENODEVICE; }
+    return n;
+}
+
+void ms_host_sincospi(float x, float* s, float* c) { sincospi_f(x, *s, *c); }
+
+int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
+    if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
+    const int A = sc->n_agents;
+    const int envs_per_wg = A >= WAVES ? 1 : WAVES/A;
+    const int blocks = (sc->n_envs + envs_per_wg - 1)/envs_per_wg;
+    const size_t shmem = sizeof(float)*(size_t)envs_per_wg*A;
+    if (shmem > 64*1024) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(physics_kernel, dim3(blocks), dim3(WG), shmem, (hipStream_t)stream,
+                       *sc, *ag, progress, cfg->agent_radius, cfg->fps, envs_per_wg);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {
+    if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !out->indices || !out->locations ||
+        !out->dots || !out->distances || !out->screen || !sc->textures_vals || !sc->textures_widths ||
+        !sc->textures_starts || !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
+    if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
+    const int R = cfg->res;
+    const int G = (R + WAVE - 1)/WAVE;
+    const long long n_fans = (long long)sc->n_envs*sc->n_agents*G;
+    if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
+    const int blocks = (int)((n_fans + WAVES - 1)/WAVES);
+    // kernels.cu:22
+    const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
+    hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
+                       *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
+    (void)cfg;
+    if (!scenery_ok(sc) || !sc->textures_widths || !sc->textures_starts || !sc->textures_inverse ||
+        !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
+    if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
+    if (sc->n_texels_total == 0) return MS_OK;
+    hipLaunchKernelGGL(bake_kernel, dim3(sc->n_envs), dim3(WG), 0, (hipStream_t)stream, *sc);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+}  // extern "C"

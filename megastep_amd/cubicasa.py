@@ -1,0 +1,149 @@
+"""Seeded synthetic stand-in for the Cubicasa5k floorplan sample (reference: megastep/cubicasa.py:177-224).
+
+The reference downloads ~5k real floorplans (network + non-commercial licence); neither is available to this build, and
+the benchmark configs call for *synthetic* cubicasa floorplans. :func:`sample` keeps the reference's signature and
+return type - a list of geometry dicts ``{id, walls, lights, masks, res}`` - and draws from a deterministic pool of
+procedurally generated apartments whose statistics follow the one in-repo datapoint (reference: core.py:103-107:
+275 walls + 21 lights in a typical plan):
+
+* axis-aligned apartment, 8-20 m x 6-15 m, recursively split into 10-25 rooms;
+* walls are 0.15 m thick and appear as the *outlines* of wall pieces (as the reference's walls are polygon
+  exteriors, geometry.py:43-57), broken by 0.9 m door gaps; small pillars pad the count to the target;
+* 150-400 wall segments per plan (800-1200 with ``large=True``), all coordinates > MARGIN;
+* one light per room at its centroid; masks at 0.2 m with -1 wall / 0 outside / k room.
+"""
+import numpy as np
+from . import geometry, arrdict
+
+N_UNIQUE = 4992          # the reference dataset's size
+THICK = .15
+DOOR = .9
+
+
+def _rect_walls(x0, y0, x1, y1):
+    """Outline of an axis-aligned rectangle as 4 oriented segments (counter-clockwise)."""
+    c = np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]])
+    return np.stack([c, np.roll(c, -1, 0)], 1)
+
+
+def _split_rooms(rng, w, h, n_rooms, min_side):
+    rooms = [(0., 0., w, h)]
+    for _ in range(10*n_rooms):
+        if len(rooms) >= n_rooms:
+            break
+        areas = np.array([(r[2] - r[0])*(r[3] - r[1]) for r in rooms])
+        i = int(rng.choice(len(rooms), p=areas/areas.sum()))
+        x0, y0, x1, y1 = rooms[i]
+        horizontal = (x1 - x0) < (y1 - y0)          # cut across the long side
+        lo, hi = (y0, y1) if horizontal else (x0, x1)
+        if hi - lo < 2*min_side:
+            continue
+        cut = rng.uniform(lo + min_side, hi - min_side)
+        rooms.pop(i)
+        if horizontal:
+            rooms += [(x0, y0, x1, cut), (x0, cut, x1, y1)]
+        else:
+            rooms += [(x0, y0, cut, y1), (cut, y0, x1, y1)]
+    return rooms
+
+
+def _shared_edges(rooms):
+    """(i, j, axis, coord, lo, hi) for every pair of rooms sharing a boundary stretch."""
+    out = []
+    for i, a in enumerate(rooms):
+        for j in range(i + 1, len(rooms)):
+            b = rooms[j]
+            for axis in (0, 1):                      # axis 0: vertical wall at x = coord
+                o = 1 - axis
+                for coord_a, coord_b in ((a[2 + axis], b[axis]), (a[axis], b[2 + axis])):
+                    if abs(coord_a - coord_b) < 1e-9:
+                        lo, hi = max(a[o], b[o]), min(a[2 + o], b[2 + o])
+                        if hi - lo > 1e-6:
+                            out.append((i, j, axis, coord_a, lo, hi))
+    return out
+
+
+def _find(parent, i):
+    while parent[i] != i:
+        parent[i] = parent[parent[i]]
+        i = parent[i]
+    return i
+
+
+def floorplan(seed, large=False):
+    """One synthetic apartment as a geometry dict (without ``id``)."""
+    rng = np.random.RandomState(seed)
+    scale = 2.2 if large else 1.
+    w, h = scale*rng.uniform(8, 20), scale*rng.uniform(6, 15)
+    n_rooms = int(rng.randint(40, 70)) if large else int(rng.randint(10, 26))
+    target = int(rng.randint(800, 1201)) if large else int(rng.randint(150, 401))
+    rooms = _split_rooms(rng, w, h, n_rooms, 1.7)
+    off = geometry.MARGIN + THICK                   # keep every coordinate > MARGIN
+
+    # interior walls: one thick piece per shared edge, split around a door where the rooms need connecting
+    pieces = []
+    edges = _shared_edges(rooms)
+    parent = list(range(len(rooms)))
+    for k in rng.permutation(len(edges)):
+        i, j, axis, coord, lo, hi = edges[k]
+        ri, rj = _find(parent, i), _find(parent, j)
+        door = (hi - lo > DOOR + .6) and (ri != rj or rng.uniform() < .25)
+        spans = [(lo, hi)]
+        if door:
+            parent[ri] = rj
+            d0 = rng.uniform(lo + .3, hi - DOOR - .3)
+            spans = [(lo, d0), (d0 + DOOR, hi)]
+        for s0, s1 in spans:
+            if s1 - s0 < 1e-3:
+                continue
+            if axis == 0:
+                pieces.append((coord - THICK/2, s0, coord + THICK/2, s1))
+            else:
+                pieces.append((s0, coord - THICK/2, s1, coord + THICK/2))
+    # exterior shell: four thick slabs
+    pieces += [(-THICK, -THICK, w + THICK, 0.), (-THICK, h, w + THICK, h + THICK),
+               (-THICK, 0., 0., h), (w, 0., w + THICK, h)]
+
+    walls = [_rect_walls(*p) for p in pieces]
+    # pillars / ducts against room corners pad the segment count up to the target
+    n_pillars = max((target - 4*len(walls)) // 4, 0)
+    for _ in range(n_pillars):
+        x0, y0, x1, y1 = rooms[int(rng.randint(len(rooms)))]
+        s = rng.uniform(.15, .45)
+        px = rng.choice([x0 + THICK/2, x1 - THICK/2 - s])
+        py = rng.uniform(y0 + THICK/2, max(y1 - THICK/2 - s, y0 + THICK/2 + 1e-3))
+        walls.append(_rect_walls(px, py, px + s, py + s))
+    walls = np.concatenate(walls) + off
+
+    spaces = [np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]]) + off for x0, y0, x1, y1 in rooms]
+    return arrdict.arrdict(
+        walls=walls,
+        lights=geometry.centroids(spaces),
+        masks=geometry.masks(walls, spaces),
+        res=geometry.RES)
+
+
+_cache = {}
+
+
+def _plan(i, large):
+    key = (int(i), bool(large))
+    if key not in _cache:
+        _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if large else "S"}{int(i):04d}', **floorplan(1000003*int(large) + int(i), large))
+    return _cache[key]
+
+
+def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE):
+    """A deterministic sample of ``n_geometries`` floorplans; same arguments, same sample (reference:
+    cubicasa.py:177-224). ``split`` is 90/10 ``training``/``test`` or ``all`` over ``n_unique`` plans; plans are
+    generated lazily and repeat cyclically when more are asked for than the split holds. ``large`` and ``n_unique`` are
+    extensions for the big-map benchmark point and for cheap tests."""
+    cutoff = int(.9*n_unique)
+    order = np.random.RandomState(seed).permutation(n_unique)
+    if split == 'training':
+        order = order[:cutoff]
+    elif split == 'test':
+        order = order[cutoff:]
+    elif split != 'all':
+        raise ValueError('Split must be train/test/all')
+    return [_plan(order[i % len(order)], large) for i in range(n_geometries)]

@@ -1,0 +1,307 @@
+"""The ``megastep.cuda`` operator surface on MI355X.
+
+Mirrors the reference's pybind module ``megastepcuda`` (reference: megastep/src/wrappers.cpp:30-173) name for name -
+``initialize, bake, physics, render, Ragged1D/2D/3D, Agents, Scenery, Render, Physics`` - but every compute entry
+point is a hand-written gfx950 kernel reached through the C-ABI in ``include/megastep_hip.h``. Tensors stay torch-owned
+(PyTorch-ROCm is the allocator/stream plumbing); the kernels run on ``torch.cuda.current_stream()``.
+
+There is no CPU implementation here, exactly as in the reference ("If you haven't got CUDA, megastep will not work",
+reference: docs/faq.rst:23-26): calling bake/physics/render on non-GPU tensors raises.
+"""
+import ctypes as C
+import numbers
+import torch
+from . import _lib
+
+# ---------------------------------------------------------------------------------------------------------------------
+# initialize                                                                   reference: kernels.cu:18-27
+# ---------------------------------------------------------------------------------------------------------------------
+_config = None
+
+
+def initialize(agent_radius, res, fov, fps):
+    """Sets the constants used by :func:`bake`, :func:`physics` and :func:`render` (reference: wrappers.cpp:53).
+
+    As in the reference this is process-global; unlike it, the values travel by value with every launch, so nothing
+    device-side is mutated here and several devices can be driven from one process."""
+    global _config
+    if not (0 < fov < 180):
+        raise RuntimeError('fov must be in (0, 180) degrees')
+    if res <= 0 or fps <= 0 or agent_radius <= 0:
+        raise RuntimeError('agent_radius, res and fps must be positive')
+    _config = _lib.MsConfig(float(agent_radius), int(res), float(fov), float(fps))
+
+
+def _cfg():
+    if _config is None:
+        raise RuntimeError('megastep_amd.cuda.initialize(agent_radius, res, fov, fps) has not been called')
+    return _config
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# checks                                                                       reference: common.h:12-14,33-37
+# ---------------------------------------------------------------------------------------------------------------------
+def _check(t, name, dtype, ndim):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f'{name} must be a tensor')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+    if t.dtype != dtype:
+        raise RuntimeError(f'{name} must have dtype {dtype}, not {t.dtype}')
+    if t.ndim != ndim:
+        raise RuntimeError(f'{name} must be {ndim}-dimensional, not {t.ndim}')
+    return t
+
+
+def _require_gpu(*tensors):
+    dev = tensors[0].device
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError('megastep_amd kernels need GPU (HIP) tensors; got a tensor on ' + str(t.device))
+        if t.device != dev:
+            raise RuntimeError(f'all tensors must live on one device; got {t.device} and {dev}')
+    return dev
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ragged                                                                       reference: common.h:91-155
+# ---------------------------------------------------------------------------------------------------------------------
+class _Ragged:
+    """Arrays-of-arrays over one contiguous backing tensor (reference: common.h:102-155, wrappers.cpp:14-28).
+
+    ``starts/ends/inverse`` are int32 like ``widths``. Zero-width rows are legal here (the reference's scatter-based
+    ``inverses`` mis-handles them, common.h:91-98): ``inverse`` simply never mentions them."""
+    _ndim = None
+
+    def __init__(self, vals, widths):
+        _check(vals, 'vals', torch.float32, self._ndim)
+        _check(widths, 'widths', torch.int32, 1)
+        if vals.device != widths.device:
+            raise RuntimeError('vals and widths must be on the same device')
+        ends = widths.cumsum(0).to(torch.int32)
+        total = int(ends[-1]) if len(widths) else 0
+        if total != vals.shape[0]:
+            raise RuntimeError(f'widths sum to {total} but vals has {vals.shape[0]} rows')
+        self._vals, self._widths = vals, widths
+        self._starts, self._ends = ends - widths, ends
+        self._inverse = torch.repeat_interleave(
+            torch.arange(len(widths), dtype=torch.int32, device=widths.device), widths.long())
+
+    vals = property(lambda self: self._vals)
+    widths = property(lambda self: self._widths)
+    starts = property(lambda self: self._starts)
+    ends = property(lambda self: self._ends)
+    inverse = property(lambda self: self._inverse)
+
+    def __len__(self):
+        return len(self._widths)
+
+    def __getitem__(self, x):
+        if isinstance(x, numbers.Integral):
+            return self._vals[int(self._starts[x]):int(self._ends[x])]
+        if isinstance(x, slice):
+            start, stop, step = x.indices(len(self._widths))
+            if step != 1:
+                raise IndexError('Ragged slices must have step 1')
+            if stop <= start:
+                return type(self)(self._vals[:0], self._widths[:0])
+            return type(self)(self._vals[int(self._starts[start]):int(self._ends[stop - 1])], self._widths[start:stop])
+        raise TypeError(f"Can't index a Ragged with a {type(x).__name__}")
+
+    def size(self, i):
+        return self._vals.shape[i]
+
+    def clone(self):
+        return type(self)(self._vals.clone(), self._widths.clone())
+
+    def numpyify(self):
+        from .ragged import RaggedNumpy
+        return RaggedNumpy(self._vals.detach().cpu().numpy().copy(), self._widths.detach().cpu().numpy().copy())
+
+    def to(self, device):
+        return type(self)(self._vals.to(device), self._widths.to(device))
+
+    def __repr__(self):
+        return f'{type(self).__name__}(vals={tuple(self._vals.shape)}, widths=({len(self._widths)},))'
+
+
+class Ragged1D(_Ragged):
+    _ndim = 1
+
+
+class Ragged2D(_Ragged):
+    _ndim = 2
+
+
+class Ragged3D(_Ragged):
+    _ndim = 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Agents / Scenery / Render / Physics                                          reference: common.h:157-226
+# ---------------------------------------------------------------------------------------------------------------------
+class Agents:
+    """Holds the (N, A[, 2]) state tensors of the agents (reference: common.h:157-177, wrappers.cpp:103-120).
+    :func:`physics` updates them in place."""
+
+    def __init__(self, angles, positions, angvelocity, velocity):
+        self._angles = _check(angles, 'angles', torch.float32, 2)
+        self._positions = _check(positions, 'positions', torch.float32, 3)
+        self._angvelocity = _check(angvelocity, 'angvelocity', torch.float32, 2)
+        self._velocity = _check(velocity, 'velocity', torch.float32, 3)
+        n, a = angles.shape
+        if positions.shape != (n, a, 2) or velocity.shape != (n, a, 2) or angvelocity.shape != (n, a):
+            raise RuntimeError('agent tensors must be (N, A), (N, A, 2), (N, A), (N, A, 2)')
+        self._struct = _lib.MsAgents(angles.data_ptr(), positions.data_ptr(), angvelocity.data_ptr(), velocity.data_ptr())
+
+    angles = property(lambda self: self._angles)
+    positions = property(lambda self: self._positions)
+    angvelocity = property(lambda self: self._angvelocity)
+    velocity = property(lambda self: self._velocity)
+
+    def state(self, e):
+        from . import arrdict
+        return arrdict.arrdict(angles=self._angles[e], positions=self._positions[e],
+                               angvelocity=self._angvelocity[e], velocity=self._velocity[e])
+
+
+class Scenery:
+    """Holds the geometry, lights and textures of every env (reference: common.h:179-214, wrappers.cpp:122-145).
+
+    ``lines`` is ragged per env with the ``n_agents*len(model)`` agent lines first; ``textures`` and ``baked`` are
+    ragged per *line*. ``baked`` starts as ones and is filled in by :func:`bake`."""
+
+    def __init__(self, n_agents, lights, lines, textures, model):
+        if not isinstance(lights, Ragged2D) or not isinstance(lines, Ragged3D) or not isinstance(textures, Ragged2D):
+            raise RuntimeError('lights, lines, textures must be Ragged2D, Ragged3D, Ragged2D')
+        _check(model, 'model', torch.float32, 3)
+        if lights.vals.shape[1:] != (3,) or lines.vals.shape[1:] != (2, 2) or textures.vals.shape[1:] != (3,) \
+                or model.shape[1:] != (2, 2):
+            raise RuntimeError('lights/lines/textures/model rows must be (3,), (2, 2), (3,), (2, 2)')
+        if len(lights) != len(lines):
+            raise RuntimeError('lights and lines must have one row per env')
+        if len(textures) != lines.vals.shape[0]:
+            raise RuntimeError('textures must have one row per line')
+        self._n_agents = int(n_agents)
+        self._lights, self._lines, self._textures, self._model = lights, lines, textures, model
+        self._baked = Ragged1D(torch.ones_like(textures.vals[:, 0]).contiguous(), textures.widths)
+        self._struct = None
+
+    n_agents = property(lambda self: self._n_agents)
+    lights = property(lambda self: self._lights)
+    lines = property(lambda self: self._lines)
+    textures = property(lambda self: self._textures)
+    model = property(lambda self: self._model)
+    baked = property(lambda self: self._baked)
+
+    def state(self, e):
+        from . import dotdict
+        s, t = int(self._lines.starts[e]), int(self._lines.ends[e])
+        return dotdict.dotdict(n_agents=self._n_agents, lights=self._lights[e], lines=self._lines[e],
+                               textures=self._textures[s:t], model=self._model, baked=self._baked[s:t])
+
+    def _as_struct(self):
+        if self._struct is None:
+            li, ln, tx = self._lights, self._lines, self._textures
+            self._struct = _lib.MsScenery(
+                len(ln), self._n_agents, self._model.shape[0],
+                li.vals.data_ptr(), li.widths.data_ptr(), li.starts.data_ptr(),
+                ln.vals.data_ptr(), ln.widths.data_ptr(), ln.starts.data_ptr(), ln.inverse.data_ptr(),
+                tx.vals.data_ptr(), tx.widths.data_ptr(), tx.starts.data_ptr(), tx.inverse.data_ptr(),
+                self._model.data_ptr(), self._baked.vals.data_ptr(),
+                ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0])
+        return self._struct
+
+    def _tensors(self):
+        li, ln, tx = self._lights, self._lines, self._textures
+        return (ln.vals, ln.widths, li.vals, li.widths, tx.vals, tx.widths, self._model, self._baked.vals)
+
+
+class Render:
+    """Result of :func:`render` (reference: common.h:216-222, wrappers.cpp:147-164)."""
+
+    def __init__(self, indices, locations, dots, distances, screen):
+        self._t = (indices, locations, dots, distances, screen)
+
+    indices = property(lambda self: self._t[0])
+    locations = property(lambda self: self._t[1])
+    dots = property(lambda self: self._t[2])
+    distances = property(lambda self: self._t[3])
+    screen = property(lambda self: self._t[4])
+
+
+class Physics:
+    """Result of :func:`physics` (reference: common.h:224-226, wrappers.cpp:166-172)."""
+
+    def __init__(self, progress):
+        self._progress = progress
+
+    progress = property(lambda self: self._progress)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# kernels
+# ---------------------------------------------------------------------------------------------------------------------
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _on:
+    """Makes ``dev`` the current HIP device for the launch if it is not already."""
+
+    def __init__(self, dev):
+        self._guard = None if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self._guard is not None:
+            self._guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self._guard is not None:
+            self._guard.__exit__(*exc)
+
+
+def bake(scenery):
+    """Pre-computes the static lighting of every texel into ``scenery.baked`` (reference: wrappers.cpp:61,
+    kernels.cu:270-293)."""
+    dev = _require_gpu(*scenery._tensors())
+    # bake uses none of the initialize() constants (kernels.cu:238-293), and scene.scenery() calls it before any Core
+    # exists, so the config is optional here
+    cfg = C.byref(_config) if _config is not None else None
+    with _on(dev):
+        _lib.check(_lib.lib().ms_bake(C.byref(scenery._as_struct()), cfg, _stream(dev)))
+
+
+def physics(scenery, agents):
+    """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
+    returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230)."""
+    dev = _require_gpu(scenery.lines.vals, agents.angles, agents.positions, agents.angvelocity, agents.velocity)
+    if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
+        raise RuntimeError('agents do not match the scenery: expected (n_envs, n_agents) = '
+                           f'{(len(scenery.lines), scenery.n_agents)}, got {tuple(agents.angles.shape)}')
+    progress = torch.empty_like(agents.angles)
+    with _on(dev):
+        _lib.check(_lib.lib().ms_physics(C.byref(scenery._as_struct()), C.byref(agents._struct),
+                                         C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
+    return Physics(progress)
+
+
+def render(scenery, agents):
+    """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
+    (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`."""
+    dev = _require_gpu(*scenery._tensors(), agents.angles, agents.positions)
+    n, a = agents.angles.shape
+    if (n, a) != (len(scenery.lines), scenery.n_agents):
+        raise RuntimeError('agents do not match the scenery')
+    cfg = _cfg()
+    r = cfg.res
+    indices = torch.empty((n, a, r), dtype=torch.int32, device=dev)
+    locations = torch.empty((n, a, r), dtype=torch.float32, device=dev)
+    dots = torch.empty((n, a, r), dtype=torch.float32, device=dev)
+    distances = torch.empty((n, a, r), dtype=torch.float32, device=dev)
+    screen = torch.empty((n, a, r, 3), dtype=torch.float32, device=dev)
+    out = _lib.MsRender(indices.data_ptr(), locations.data_ptr(), dots.data_ptr(), distances.data_ptr(), screen.data_ptr())
+    with _on(dev):
+        _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct), C.byref(out),
+                                        C.byref(cfg), _stream(dev)))
+    return Render(indices, locations, dots, distances, screen)

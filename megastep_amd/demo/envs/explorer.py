@@ -1,0 +1,79 @@
+"""Single-agent exploration: reward for every texel seen for the first time
+(reference: megastep/demo/envs/explorer.py:8-115)."""
+import torch
+from ... import modules, core, scene, cubicasa, arrdict, dotdict
+
+
+class Explorer:
+
+    def __init__(self, n_envs, *args, device='cuda', geometries=None, **kwargs):
+        geometries = cubicasa.sample(n_envs) if geometries is None else geometries
+        scenery = scene.scenery(geometries, 1, device=device)
+        self.core = core.Core(scenery, *args, res=4*64, fov=130, **kwargs)
+        self._rgb = modules.RGB(self.core, n_agents=1, subsample=4)
+        self._depth = modules.Depth(self.core, n_agents=1, subsample=4)
+        self._mover = modules.MomentumMovement(self.core)
+        self._imu = modules.IMU(self.core)
+        self._respawner = modules.RandomSpawns(geometries, self.core)
+
+        self.action_space = self._mover.space
+        self.obs_space = dotdict.dotdict(rgb=self._rgb.space, d=self._depth.space, imu=self._imu.space)
+
+        sc = self.core.scenery
+        self._tex_to_env = sc.lines.inverse[sc.textures.inverse.long()].long()
+        self._seen = torch.full_like(self._tex_to_env, False)
+        self._potential = self.core.env_full(0.)
+        self._lengths = torch.zeros(self.core.n_envs, device=self.core.device, dtype=torch.int)
+        self.device = self.core.device
+
+    def _tex_indices(self, aux):
+        sc = self.core.scenery
+        mask = aux.indices >= 0
+        result = torch.full_like(aux.indices, -1, dtype=torch.long)
+        tex_n = (sc.lines.starts[:, None, None, None] + aux.indices)[mask].long()
+        tex_w = sc.textures.widths[tex_n].float()
+        tex_i = torch.min(torch.floor(tex_w*aux.locations[mask]), tex_w - 1)
+        result[mask] = sc.textures.starts[tex_n].long() + tex_i.long()
+        return result.unsqueeze(2)
+
+    def _reward(self, r, reset):
+        self._seen[self._tex_indices(r)] = True
+        potential = torch.zeros_like(self._potential)
+        potential.scatter_add_(0, self._tex_to_env, self._seen.float())
+        reward = (potential - self._potential)/(self.core.res//self._rgb.subsample)
+        self._potential = potential
+        reward[reset] = 0.
+        return reward
+
+    def _observe(self, reset):
+        r = modules.render(self.core)
+        obs = arrdict.arrdict(rgb=self._rgb(r), d=self._depth(r), imu=self._imu())
+        return obs, self._reward(r, reset)
+
+    def _reset(self, reset=None):
+        self._respawner(reset.unsqueeze(-1))
+        self._seen[reset[self._tex_to_env]] = False
+        self._potential[reset] = 0
+        self._lengths[reset] = 0
+
+    @torch.no_grad()
+    def reset(self):
+        reset = self.core.env_full(True)
+        self._reset(reset)
+        obs, reward = self._observe(reset)
+        return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
+
+    @torch.no_grad()
+    def step(self, decision):
+        self._mover(decision)
+        self._lengths += 1
+        reset = (self._lengths >= self._potential + 200)
+        self._reset(reset)
+        obs, reward = self._observe(reset)
+        return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
+
+    def state(self, e=0):
+        return arrdict.arrdict(
+            core=self.core.state(e), rgb=self._rgb.state(e), d=self._depth.state(e),
+            potential=self._potential[e].clone(), seen=self._seen[self._tex_to_env == e].clone(),
+            length=self._lengths[e].clone(), max_length=self._potential[e].add(200).clone())

@@ -1,0 +1,205 @@
+"""Chunks of functionality that turn up in most environments (reference: megastep/modules.py:10-381).
+
+These are the direct callers of the hot path: the movement modules end in :func:`cuda.physics`, :func:`render` wraps
+:func:`cuda.render`. Everything here is thin torch glue over the tensors the kernels own."""
+import numpy as np
+import torch
+from . import spaces, geometry, cuda, arrdict
+
+
+def _sincos_deg(angles):
+    a = np.pi/180*angles
+    return torch.sin(a), torch.cos(a)
+
+
+def to_local_frame(angles, p):
+    """Global-frame vectors -> the agents' local frames."""
+    s, c = _sincos_deg(angles)
+    x, y = p[..., 0], p[..., 1]
+    return torch.stack([c*x + s*y, -s*x + c*y], -1)
+
+
+def to_global_frame(angles, p):
+    """Agent-local vectors -> the global frame."""
+    s, c = _sincos_deg(angles)
+    x, y = p[..., 0], p[..., 1]
+    return torch.stack([c*x - s*y, s*x + c*y], -1)
+
+
+def _actionset(core, linear, angular):
+    # noop, forward/backward, strafe left/right, turn left/right
+    velocity = torch.tensor([[0., 0.], [0., 1.], [0., -1.], [1., 0.], [-1., 0.], [0., 0.], [0., 0.]])
+    angvelocity = torch.tensor([0., 0., 0., 0., 0., +1., -1.])
+    return arrdict.arrdict(velocity=linear/core.fps*velocity, angvelocity=angular/core.fps*angvelocity).to(core.device)
+
+
+class SimpleMovement:
+
+    def __init__(self, core, speed=10, ang_speed=180, n_agents=None):
+        """Movement without momentum: seven actions - nothing, forward/backward, strafe left/right, turn left/right
+        (reference: modules.py:24-66)."""
+        self.core = core
+        self._actionset = _actionset(core, speed, ang_speed)
+        self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
+
+    def __call__(self, decision):
+        """Sets the agents' velocities from ``decision.actions`` ((n_env, n_agent) ints in 0..6), then steps physics."""
+        core = self.core
+        delta = self._actionset[decision.actions.long()]
+        core.agents.angvelocity[:] = delta.angvelocity
+        core.agents.velocity[:] = to_global_frame(core.agents.angles, delta.velocity)
+        return cuda.physics(core.scenery, core.agents)
+
+
+class MomentumMovement:
+
+    def __init__(self, core, accel=5, ang_accel=180, decay=.125, n_agents=None):
+        """Movement with momentum: the seven actions accelerate rather than move, and velocity decays by ``decay``
+        each step (reference: modules.py:68-118)."""
+        self.core = core
+        self._actionset = _actionset(core, accel, ang_accel)
+        self.decay = decay
+        self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
+
+    def __call__(self, decision):
+        core = self.core
+        delta = self._actionset[decision.actions.long()]
+        core.agents.angvelocity[:] = (1 - self.decay)*core.agents.angvelocity + delta.angvelocity
+        core.agents.velocity[:] = (1 - self.decay)*core.agents.velocity + to_global_frame(core.agents.angles, delta.velocity)
+        return cuda.physics(core.scenery, core.agents)
+
+
+def unpack(d):
+    """``cuda`` result objects -> arrdicts with the same attributes (reference: modules.py:120-124)."""
+    if isinstance(d, torch.Tensor):
+        return d
+    return arrdict.arrdict({k: unpack(getattr(d, k)) for k in dir(d) if not k.startswith('_')})
+
+
+def render(core):
+    """Calls :func:`cuda.render` and reshapes for torch convs: every field gets a height-1 axis, ``screen`` becomes
+    (n_env, n_agent, 3, 1, res) (reference: modules.py:126-136)."""
+    r = unpack(cuda.render(core.scenery, core.agents))
+    r = arrdict.arrdict({k: v.unsqueeze(2) for k, v in r.items()})
+    r['screen'] = r.screen.permute(0, 1, 4, 2, 3)
+    return r
+
+
+def downsample(screen, subsample):
+    """(..., W) -> (..., W/subsample, subsample); chase it with a mean/min/max over the last axis
+    (reference: modules.py:138-145)."""
+    return screen.view(*screen.shape[:-1], screen.shape[-1]//subsample, subsample)
+
+
+class Depth:
+
+    def __init__(self, core, n_agents=None, subsample=1, max_depth=10):
+        """Depth observations in [0, 1]: one at the near plane, zero at ``max_depth`` metres
+        (reference: modules.py:147-189)."""
+        self.core = core
+        self.space = spaces.MultiImage(n_agents or core.n_agents, 1, 1, core.res//subsample)
+        self.max_depth = max_depth
+        self.subsample = subsample
+
+    def __call__(self, r=None):
+        r = render(self.core) if r is None else r
+        depth = 1 - ((r.distances - self.core.agent_radius)/self.max_depth).clamp(0, 1)
+        self._last_obs = downsample(depth, self.subsample).mean(-1).unsqueeze(3)
+        return self._last_obs
+
+    def state(self, e=0):
+        return self._last_obs[e].clone()
+
+
+class RGB:
+
+    def __init__(self, core, n_agents=None, subsample=1):
+        """Linear-RGB observations, (n_env, n_agent, 3, 1, res/subsample) (reference: modules.py:191-238)."""
+        self.core = core
+        self.space = spaces.MultiImage(n_agents or core.n_agents, 3, 1, core.res//subsample)
+        self.subsample = subsample
+
+    def __call__(self, r=None):
+        r = render(self.core) if r is None else r
+        self._last_obs = downsample(r.screen, self.subsample).mean(-1)
+        return self._last_obs
+
+    def state(self, e=0):
+        return self._last_obs[e].clone()
+
+
+class IMU:
+
+    def __init__(self, core, speed_scale=10., ang_scale=360., n_agents=None):
+        """(angular, medial, lateral) velocity observations, (n_env, n_agent, 3) (reference: modules.py:240-270)."""
+        self.core = core
+        self.space = spaces.MultiVector(n_agents or core.n_agents, 3)
+        self.speed_scale = speed_scale
+        self.ang_scale = ang_scale
+
+    def __call__(self):
+        agents = self.core.agents
+        return torch.cat([
+            agents.angvelocity[..., None]/self.ang_scale,
+            to_local_frame(agents.angles, agents.velocity)/self.speed_scale], -1)
+
+
+def random_empty_positions(geometries, n_agents, n_points):
+    """(n_geometries, n_agents, n_points, 2) randomly chosen free-cell centres, precomputed so respawns are cheap
+    (reference: modules.py:272-296; consumes the global ``np.random`` in the same order)."""
+    points = []
+    for g in geometries:
+        free = np.stack((g['masks'] > 0).nonzero(), -1)
+        n_possible = min(len(free)//n_agents, n_points)
+        sample = free[np.random.choice(np.arange(len(free)), (n_possible, n_agents), replace=True)]
+        sample = np.concatenate([sample]*int(n_points/len(sample) + 1))[-n_points:]
+        sample = np.random.permutation(sample)
+        points.append(geometry.centers(sample, g['masks'].shape, g['res']).transpose(1, 0, 2))
+    return arrdict.stack(points)
+
+
+class RandomSpawns:
+
+    def __init__(self, geometries, core, n_spawns=100):
+        """Respawns agents at random free points of their geometry (reference: modules.py:298-326)."""
+        self.core = core
+        positions = random_empty_positions(geometries, core.n_agents, n_spawns)
+        angles = core.random.uniform(-180, +180, (len(geometries), core.n_agents, n_spawns))
+        self._spawns = arrdict.torchify(arrdict.arrdict(positions=positions, angles=angles)).to(core.device)
+
+    def __call__(self, reset):
+        """``reset`` is an (n_env, n_agent) bool mask; the marked agents get a new pose and zero velocity."""
+        core = self.core
+        required = reset.nonzero(as_tuple=True)
+        choices = torch.randint_like(required[0], 0, self._spawns.angles.shape[1])
+        core.agents.angles[required] = self._spawns.angles[(*required, choices)]
+        core.agents.positions[required] = self._spawns.positions[(*required, choices)]
+        core.agents.velocity[required] = 0.
+        core.agents.angvelocity[required] = 0.
+
+
+class RandomLifespans:
+
+    def __init__(self, core, max_lifespan, min_lifespan=None):
+        """Flags agents that outlive a randomly drawn lifespan, so synchronous envs drift apart
+        (reference: modules.py:328-381)."""
+        self.min_lifespan = max_lifespan//2 if min_lifespan is None else min_lifespan
+        self.max_lifespan = max_lifespan
+        self._max_lifespans = torch.zeros((core.n_envs, core.n_agents), dtype=torch.int, device=core.device)
+        self._lifespans = torch.zeros_like(self._max_lifespans)
+        self._reset(core.agent_full(True))
+
+    def _reset(self, reset):
+        self._lifespans[reset] = 0
+        fresh = torch.randint_like(self._max_lifespans, self.min_lifespan, self.max_lifespan)
+        self._max_lifespans[reset] = fresh[reset]
+
+    def __call__(self, reset=None):
+        self._lifespans += 1
+        reset = torch.zeros_like(self._lifespans, dtype=torch.bool) if reset is None else reset
+        reset = (self._lifespans >= self._max_lifespans) | reset
+        self._reset(reset)
+        return reset
+
+    def state(self, e):
+        return arrdict.arrdict(lifespan=self._lifespans[e], max_lifespans=self._max_lifespans[e]).clone()

@@ -1,0 +1,102 @@
+"""Shared helpers for the parity tests: moving a product-side Core into the oracle's numpy world and comparing."""
+import numpy as np
+import torch
+from oracle import oracle as O
+
+
+def scene_dict(scenery):
+    """cuda.Scenery -> the oracle's scene dict (numpy copies)."""
+    n = lambda t: t.detach().cpu().numpy().copy()
+    return dict(
+        n_agents=scenery.n_agents, model=n(scenery.model),
+        lights_vals=n(scenery.lights.vals), lights_widths=n(scenery.lights.widths),
+        lines_vals=n(scenery.lines.vals), lines_widths=n(scenery.lines.widths),
+        textures_vals=n(scenery.textures.vals), textures_widths=n(scenery.textures.widths),
+        baked_vals=n(scenery.baked.vals))
+
+
+def agents_dict(agents):
+    n = lambda t: t.detach().cpu().numpy().copy()
+    return dict(angles=n(agents.angles), positions=n(agents.positions),
+                angvelocity=n(agents.angvelocity), velocity=n(agents.velocity))
+
+
+class OracleWorld:
+    """The oracle's copy of a Core: same scene, same config, agents pulled on demand."""
+
+    def __init__(self, core):
+        self.scene = O.Scene(scene_dict(core.scenery))
+        self.cfg = O.config(core.agent_radius, core.res, core.fov, core.fps)
+        self.agents = agents_dict(core.agents)
+
+    def pull_agents(self, core):
+        self.agents = agents_dict(core.agents)
+
+    def pull_baked(self, core):
+        self.scene.baked_vals[:] = core.scenery.baked.vals.cpu().numpy()
+
+    def bake(self):
+        return O.bake(self.scene, self.cfg).copy()
+
+    def physics(self):
+        progress, self.agents = O.physics(self.scene, self.agents, self.cfg)
+        return progress, self.agents
+
+    def render(self):
+        return O.render(self.scene, self.agents, self.cfg)
+
+
+def spawn(core, geometries, seed=0):
+    """Puts every agent on a random free cell of its geometry with a random heading."""
+    rng = np.random.RandomState(seed)
+    from megastep_amd import geometry
+    pos = np.zeros((core.n_envs, core.n_agents, 2), np.float32)
+    for e, g in enumerate(geometries):
+        free = np.stack((g['masks'] > 0).nonzero(), -1)
+        pick = free[rng.choice(len(free), core.n_agents)]
+        pos[e] = geometry.centers(pick, g['masks'].shape, g['res'])
+    core.agents.positions[:] = torch.as_tensor(pos, device=core.device)
+    core.agents.angles[:] = torch.as_tensor(rng.uniform(-180, 180, (core.n_envs, core.n_agents)).astype(np.float32), device=core.device)
+
+
+def random_velocities(core, rng, speed=3., spin=180.):
+    shape = (core.n_envs, core.n_agents)
+    core.agents.velocity[:] = torch.as_tensor(rng.uniform(-speed, speed, shape + (2,)).astype(np.float32), device=core.device)
+    core.agents.angvelocity[:] = torch.as_tensor(rng.uniform(-spin, spin, shape).astype(np.float32), device=core.device)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_physics_matches(core, p, progress_ref, agents_ref, atol=1e-5):
+    """Bit-exact collision masks; float state within the north-star tolerance (1e-5)."""
+    progress = _np(p.progress)
+    np.testing.assert_array_equal(progress < 1, progress_ref < 1, err_msg='collision masks differ')
+    np.testing.assert_allclose(progress, progress_ref, rtol=0, atol=atol)
+    for k in ('positions', 'velocity', 'angvelocity'):
+        np.testing.assert_allclose(_np(getattr(core.agents, k)), agents_ref[k], rtol=0, atol=atol, err_msg=k)
+    # angles live in [-180, 180): one binary32 ulp there is 1.5e-5, so compare modulo that
+    np.testing.assert_allclose(_np(core.agents.angles), agents_ref['angles'], rtol=0, atol=2e-5, err_msg='angles')
+
+
+def assert_render_matches(core, r, ref, atol=1e-5):
+    """Bit-exact hit indices (and miss sentinels); floats within 1e-5."""
+    idx = _np(r.indices)
+    np.testing.assert_array_equal(idx, ref['indices'], err_msg='hit indices differ')
+    hit = idx >= 0
+    for k in ('locations', 'dots', 'distances'):
+        got, want = _np(getattr(r, k)), ref[k]
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want), err_msg=k)
+        np.testing.assert_array_equal(np.isinf(got), np.isinf(want), err_msg=k)
+        np.testing.assert_allclose(got[hit], want[hit], rtol=0, atol=atol, err_msg=k)
+    np.testing.assert_allclose(_np(r.screen), ref['screen'], rtol=0, atol=atol, err_msg='screen')
+    # render rewrites the agents' model lines (kernels.cu:316-317)
+    lines = _np(core.scenery.lines.vals)
+    want_lines = None
+    return lines, want_lines
+
+
+def exact_fraction(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(((a == b) | (np.isnan(a) & np.isnan(b))).mean())
