@@ -171,6 +171,8 @@ __device__ inline float wave_min(float x) {
     return x;
 }
 
+// v_readlane_b32 of a float: broadcast lane `l` (wave-uniform) of v through an SGPR, no LDS round trip
+__device__ inline float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ inline float bits_f(uint32_t u) { return __uint_as_float(u); }
 __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 
@@ -439,38 +441,121 @@ __global__ __launch_bounds__(WG) void render_kernel(
     const bool dynamic = is_hit & (nearest_idx < AF);
     if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
 
-    // Rays that landed on an agent need light_intensity() at the hit point: lights x walls
-    // occlusion tests.  Done wave-cooperatively (lane = wall) one such ray at a time, so one
-    // unlucky lane does not serialise 6k tests while 63 lanes idle.
+    // Rays that landed on an agent need light_intensity() at the hit point: lights x walls occlusion
+    // tests per ray (kernels.cu:434-436).  Done wave-cooperatively and exactly, in two levels:
+    //   lane = wall : each wall is loaded once and tested against the CORRIDOR light -> target agent
+    //                 (a box around the segment light..agent, grown by the agent's extent) for every
+    //                 light; only walls inside a corridor can shadow anything on that agent.  The
+    //                 survivors are compacted into the (now free) LDS candidate list as (wall, light)
+    //                 pairs.
+    //   lane = pair : every pair is tested exactly against each of the wave's rays on that agent;
+    //                 a hit ORs the light's bit into that ray's shadow mask (LDS atomic).
+    // `blocked` is an OR over walls, so the order of the tests is free; the sum over lights is not
+    // and stays in light order.
+#ifdef MS_ABLATE_DYNLIGHT
+    unsigned long long dyn = 0ull;
+#else
     unsigned long long dyn = __ballot(dynamic);
+#endif
     if (dyn) {
-        const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;
+        const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
+        const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
         const int num_i = sc.lights_widths[n];
         const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
-        while (dyn) {
-            const int j = __ffsll((long long)dyn) - 1;
-            dyn &= dyn - 1;
-            const P2 Cp = p2(__shfl(cx_l, j, WAVE), __shfl(cy_l, j, WAVE));
-            float acc = AMBIENT;
-            for (int i = 0; i < num_i; i++) {
-                const P2 I = p2(lights[3*i], lights[3*i + 1]);
-                const float Ii = lights[3*i + 2];
-                const P2 U = Cp - I;
-                bool blocked = false;
+        float4* pair_wall = reinterpret_cast<float4*>(&s_cand[wave][0]);        // (ax, ay, vx, vy)
+        int* pair_light = reinterpret_cast<int*>(&s_cand2[wave][0]);            // light slot, [0, CH)
+        unsigned* shadow = reinterpret_cast<unsigned*>(&s_cand2[wave][CH/2]);   // [64 rays][2] light bits
+        float acc = AMBIENT;
+        for (int i0 = 0; i0 < num_i; i0 += WAVE) {
+            const int ni = min(WAVE, num_i - i0);
+            // lane i holds light i0+i
+            float Ix = 0.f, Iy = 0.f, Ii = 0.f;
+            if (lane < ni) { Ix = lights[3*(i0 + lane)]; Iy = lights[3*(i0 + lane) + 1]; Ii = lights[3*(i0 + lane) + 2]; }
+            shadow[2*lane] = 0u; shadow[2*lane + 1] = 0u;
+            unsigned long long todo = dyn;
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                const int target = __builtin_amdgcn_readlane(my_target, j);
+                const bool mine = dynamic & (my_target == target);
+                const unsigned long long tmask = __ballot(mine);
+                todo &= ~tmask;
+                const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
+                // extent of this wave's hit points around the target, + float slack
+                float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
+                #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) rho = fmaxf(rho, __shfl_xor(rho, o, WAVE));
+                rho = rho + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
+                // corridor frame of light `lane`: unit vector e from the light to the target, length el
+                const float dx = T.x - Ix, dy = T.y - Iy;
+                const float el = sqrtf(dx*dx + dy*dy);
+                const float ex = dx/el, ey = dy/el;
+
+                int cnt = 0;
+                auto flush = [&]() {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (unsigned long long rays = tmask; rays; rays &= rays - 1) {
+                        const int jr = __ffsll((long long)rays) - 1;
+                        const float Cx = readlane_f(cx_l, jr), Cy = readlane_f(cy_l, jr);
+                        for (int p = lane; p < cnt; p += WAVE) {
+                            const float4 w = pair_wall[p];
+                            const int li = pair_light[p];
+                            const P2 I = p2(lights[3*(i0 + li)], lights[3*(i0 + li) + 1]);
+                            if (light_blocked(I, p2(Cx, Cy) - I, w.x, w.y, w.z, w.w))
+                                atomicOr(&shadow[2*jr + (li >> 5)], 1u << (li & 31));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    cnt = 0;
+                };
+
                 for (int l0 = AF; l0 < L; l0 += WAVE) {
                     const int l1 = l0 + lane;
-                    bool bl = false;
-                    if (l1 < L) {
-                        const float4 w = ln[l1];
-                        bl = light_blocked(I, U, w.x, w.y, w.z - w.x, w.w - w.y);
+                    const bool live = l1 < L;
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (live) w = ln[l1];
+                    // wall relative to the target, and its margin
+                    const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
+                    const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
+                    for (int i = 0; i < ni; i++) {
+                        const float cex = readlane_f(ex, i), cey = readlane_f(ey, i);
+                        const float cel = readlane_f(el, i);
+                        // coordinates along / across the corridor, origin at the target, light at -cel
+                        const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
+                        const float ub = cex*bx + cey*by, vb = cex*by - cey*bx;
+                        const bool out = ((ua > m) & (ub > m)) | ((ua < -cel - m) & (ub < -cel - m)) |
+                                         ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
+                        const bool keep = live & !out;
+                        const unsigned long long km = __ballot(keep);
+                        if (km) {
+                            const int nk = __popcll(km);
+                            if (cnt + nk > CH) flush();
+                            if (keep) {
+                                const int pos = cnt + __popcll(km & ((1ull << lane) - 1ull));
+                                pair_wall[pos] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
+                                pair_light[pos] = i;
+                            }
+                            cnt += nk;
+                        }
                     }
-                    if (__ballot(bl)) { blocked = true; break; }
                 }
-                const float d2 = len2(I - Cp);
-                if (!blocked) acc += LUMINANCE*Ii/ms_max(d2, 1.f);
+                if (cnt) flush();
             }
-            if (lane == j) intensity = ms_min(acc, 1.f);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long blocked = ((unsigned long long)shadow[2*lane + 1] << 32) | shadow[2*lane];
+            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < ni; i++) {                               // kernels.cu:261-264, in light order
+                const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
+                const float d2 = len2(I - p2(cx_l, cy_l));
+                if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+            }
         }
+        if (dynamic) intensity = ms_min(acc, 1.f);
+#ifdef MS_DEBUG_SHADOW
+        if (dynamic) out.dots[o] = acc;
+#endif
+        __builtin_amdgcn_wave_barrier();
     }
 
     if (is_hit) {
