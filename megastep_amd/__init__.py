@@ -7,4 +7,4 @@ it; ``cubicasa`` is a seeded synthetic stand-in for the (network-fetched) datase
 """
 DEBUG = False
 
-from . import dotdict, arrdict, cuda, ragged, spaces, geometry, core, scene, toys, modules, cubicasa  # noqa: E402,F401
+from . import dotdict, arrdict, cuda, ragged, spaces, geometry, core, scene, toys, modules, cubicasa, sharding  # noqa: E402,F401

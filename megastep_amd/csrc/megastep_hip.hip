@@ -58,9 +58,8 @@ __host__ __device__ inline float ms_max(float a, float b) { if (a != a) return b
 // sin(pi x), cos(pi x); stands in for sinpif/cospif (kernels.cu:305-306,336-337).  The range
 // reduction is exact in binary32, the kernel is a Taylor series in binary64 rounded once.
 __host__ __device__ inline void sincospi_f(float x, float& s, float& c) {
-    float t = x*0.5f;
-    t = t - floorf(t);
-    const float y = 2.f*t;
+    // exact in binary32: y = x - 2 rint(x/2) in [-1, 1], then z = y - rint(2y)/2 in [-1/4, 1/4]
+    const float y = x - 2.f*rintf(x*0.5f);
     const float nq = rintf(2.f*y);
     const float z = y - 0.5f*nq;
     const int q = ((int)nq) & 3;

@@ -193,11 +193,10 @@ static inline float normalize_degrees(float a) {
  * Range reduction is exact in binary32; the kernel is a double Taylor series
  * (no FMA), rounded to binary32 once. */
 void oracle_sincospi(float x, float* sp, float* cp) {
-    float t = x*0.5f;
-    t = t - floorf(t);                 /* [0, 1]            */
-    const float y = 2.f*t;             /* x mod 2 in [0, 2] */
+    /* exact in binary32: y = x - 2 rint(x/2) in [-1, 1], then z = y - rint(2y)/2 in [-1/4, 1/4] */
+    const float y = x - 2.f*rintf(x*0.5f);
     const float nq = rintf(2.f*y);     /* nearest quarter-turn, ties to even */
-    const float z = y - 0.5f*nq;       /* [-1/4, 1/4], exact */
+    const float z = y - 0.5f*nq;
     const int q = ((int)nq) & 3;
     const double zd = (double)z;
     const double w = zd*zd;

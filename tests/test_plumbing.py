@@ -1,0 +1,136 @@
+"""BASELINE config 1: 1 env x 1 agent, single-room geometry - scene/geometry build + Ragged pack on CPU (no GPU)."""
+import numpy as np
+import pytest
+import torch
+from megastep_amd import core, cuda, cubicasa, geometry, ragged, scene, sharding, spaces, toys
+
+
+def test_box_room_scenery_on_cpu():
+    g = toys.box()
+    assert g.walls.shape == (4, 2, 2) and g.masks.shape == (36, 36) and g.masks.dtype == np.int16 and g.res == .2
+    np.testing.assert_allclose(g.walls, [[[6, 6], [1, 6]], [[1, 6], [1, 1]], [[1, 1], [6, 1]], [[6, 1], [6, 6]]], atol=1e-12)
+    assert set(np.unique(g.masks)) == {-1, 0, 1}
+    inside = geometry.centers(np.stack((g.masks == 1).nonzero(), -1), g.masks.shape, g.res)
+    assert (inside > 1).all() and (inside < 6).all()
+    s = scene.scenery([g], n_agents=1, device='cpu', bake=False)
+    assert isinstance(s.lines, cuda.Ragged3D) and isinstance(s.lights, cuda.Ragged2D) and isinstance(s.baked, cuda.Ragged1D)
+    assert s.lines.vals.shape == (12, 2, 2) and s.lines.widths.tolist() == [12]
+    assert s.textures.vals.shape == (416, 3) and s.textures.widths.tolist() == [2]*8 + [100]*4
+    assert s.baked.vals.shape == (416,) and (s.baked.vals == 1).all()
+    assert s.lights.vals.shape == (1, 3) and .5 <= s.lights.vals[0, 2] <= 2
+    assert s.model.shape == (8, 2, 2) and s.n_agents == 1
+    for r in (s.lines, s.lights, s.textures):
+        assert r.widths.dtype == r.starts.dtype == r.ends.dtype == r.inverse.dtype == torch.int32
+    st = s.state(0)
+    assert st.lines.shape == (12, 2, 2) and len(st.textures) == 12 and st.baked.vals.shape == (416,)
+
+
+def test_core_on_cpu_holds_state_but_cannot_step():
+    s = scene.scenery(3*[toys.box()], n_agents=2, device='cpu', bake=False)
+    c = core.Core(s, res=32, fov=100, fps=20)
+    assert (c.n_envs, c.n_agents, c.res, c.fov, c.fps) == (3, 2, 32, 100, 20)
+    assert c.agents.positions.shape == (3, 2, 2) and c.progress.shape == (3, 2) and (c.progress == 1).all()
+    assert c.env_full(True).dtype == torch.bool and c.agent_full(1.).shape == (3, 2) and c.env_full(3).dtype == torch.int32
+    c.agents.positions[:] = torch.tensor([3., 3.])
+    assert (c.agents.state(1).positions == 3).all()
+    st = c.state(0)
+    assert st.n_agents == 2 and st.agents.angles.shape == (2,) and st.scenery.lines.shape == (20, 2, 2)
+    with pytest.raises(AssertionError):
+        core.Core(s, fov=180)
+
+
+def test_ragged_validation_and_edges():
+    vals, widths = torch.arange(6.), torch.tensor([3, 1, 2], dtype=torch.int32)
+    r = ragged.Ragged(vals, widths)
+    assert isinstance(r, cuda.Ragged1D) and r[1].tolist() == [3.] and r[-1].tolist() == [4., 5.]
+    assert r[:2].vals.tolist() == [0., 1., 2., 3.] and r[1:].widths.tolist() == [1, 2]
+    assert r.clone().vals.data_ptr() != r.vals.data_ptr()
+    assert isinstance(r.numpyify(), ragged.RaggedNumpy)
+    z = ragged.Ragged(torch.arange(5.), torch.tensor([2, 0, 3, 0], dtype=torch.int32))      # zero-width rows
+    assert z.starts.tolist() == [0, 2, 2, 5] and z.inverse.tolist() == [0, 0, 2, 2, 2] and z[1].numel() == 0
+    with pytest.raises(RuntimeError):
+        ragged.Ragged(vals, torch.tensor([3, 1, 1], dtype=torch.int32))
+    with pytest.raises(RuntimeError):
+        ragged.Ragged(vals, widths.long())
+    with pytest.raises(RuntimeError):
+        ragged.Ragged(vals.double(), widths)
+    with pytest.raises(RuntimeError):
+        ragged.Ragged(torch.zeros(6, 2).t()[0:1].t(), torch.tensor([6], dtype=torch.int32)[:0])
+    with pytest.raises(RuntimeError):
+        ragged.Ragged(torch.zeros(2, 2, 2, 2), torch.tensor([2], dtype=torch.int32))
+    assert isinstance(ragged.Ragged(np.arange(6), np.array([3, 1, 2])), ragged.RaggedNumpy)
+    assert isinstance(ragged.RaggedNumpy(np.arange(6.), np.array([3, 1, 2])).torchify(), cuda.Ragged1D)
+
+
+def test_scenery_and_agents_validation():
+    s = scene.scenery([toys.box()], 1, device='cpu', bake=False)
+    with pytest.raises(RuntimeError):
+        cuda.Scenery(1, s.lights, s.lines, s.lights, s.model)                      # textures not per line
+    with pytest.raises(RuntimeError):
+        cuda.Agents(torch.zeros(2, 1), torch.zeros(2, 1, 3), torch.zeros(2, 1), torch.zeros(2, 1, 2))
+    with pytest.raises(RuntimeError):
+        cuda.Agents(torch.zeros(2, 1).double(), torch.zeros(2, 1, 2), torch.zeros(2, 1), torch.zeros(2, 1, 2))
+    with pytest.raises(RuntimeError):
+        cuda.initialize(.1, 64, 190, 10)
+
+
+def test_column_and_spaces():
+    g = toys.column()
+    np.testing.assert_allclose(sorted(g.lights.tolist()), [[2.5, 2.5], [2.5, 4.5], [4.5, 2.5], [4.5, 4.5]], atol=1e-12)
+    assert np.abs(g.walls - 3.5).max() == pytest.approx(.05)
+    assert spaces.MultiImage(2, 3, 1, 64).shape == (2, 3, 1, 64) and spaces.MultiDiscrete(1, 7).shape == (1, 7)
+    assert spaces.MultiVector(4, 3).shape == (4, 3) and spaces.MultiConstant(2).shape == (2,)
+
+
+def test_masks_rasteriser():
+    walls = np.array([[[1.1, 1.1], [3.1, 1.1]], [[3.1, 1.1], [3.1, 2.3]]])
+    room = np.array([[1.1, 1.1], [3.1, 1.1], [3.1, 2.3], [1.1, 2.3]])
+    m = geometry.masks(walls, [room])
+    H, W = m.shape
+    assert (H, W) == (int(3.3/.2) + 1, int(4.1/.2) + 1)
+    cells = lambda x, y: m[geometry.indices(np.array([x, y]), m.shape, .2)[0], geometry.indices(np.array([x, y]), m.shape, .2)[1]]
+    assert cells(2., 1.1) == -1 and cells(3.1, 2.) == -1          # on the walls
+    assert cells(2., 1.7) == 1 and cells(.5, .5) == 0             # inside the room / outside
+
+
+def test_synthetic_cubicasa_sample_is_deterministic_and_in_range():
+    a, b = cubicasa.sample(6, n_unique=32), cubicasa.sample(6, n_unique=32)
+    for ga, gb in zip(a, b):
+        assert ga.id == gb.id and (ga.walls == gb.walls).all() and (ga.masks == gb.masks).all()
+    for g in a:
+        assert set(g.keys()) == {'id', 'walls', 'lights', 'masks', 'res'}
+        assert 150 <= len(g.walls) <= 404 and 10 <= len(g.lights) <= 25 and g.walls.min() > geometry.MARGIN - 1e-9
+        assert scene.lengths(g.walls).min() > 1e-3
+        assert (g.masks > 0).sum() > 100 and g.masks.min() == -1
+        room_cells = geometry.indices(g.lights, g.masks.shape, g.res)
+        assert (g.masks[room_cells[:, 0], room_cells[:, 1]] > 0).all()       # every light sits inside a room
+    assert len({g.id for g in cubicasa.sample(40, n_unique=32)}) <= 29        # repeats cyclically over the split
+    assert cubicasa.sample(3, split='test', n_unique=32)[0].id != a[0].id
+    with pytest.raises(ValueError):
+        cubicasa.sample(1, split='validation')
+    big = cubicasa.sample(1, large=True, n_unique=16)[0]
+    assert 800 <= len(big.walls) <= 1204
+
+
+def test_env_slices_partition_the_envs():
+    for n, w in [(4096, 8), (10, 3), (7, 7), (5, 8)]:
+        slices = [sharding.env_slice(n, r, w) for r in range(w)]
+        assert slices[0][0] == 0 and slices[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(slices, slices[1:]))
+        sizes = [b - a for a, b in slices]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.env_slice(8, 8, 8)
+
+
+def test_shard_scenery_reassembles():
+    gs = cubicasa.sample(5, n_unique=16)
+    full = scene.scenery(gs, 2, device='cpu', random=np.random.RandomState(0), bake=False)
+    full.baked.vals.copy_(torch.rand_like(full.baked.vals))
+    shards = [sharding.shard_scenery(full, r, 2) for r in range(2)]
+    assert [len(s.lines) for s in shards] == [3, 2]
+    for name in ('lights', 'lines', 'textures', 'baked'):
+        vals = torch.cat([getattr(s, name).vals for s in shards])
+        widths = torch.cat([getattr(s, name).widths for s in shards])
+        assert torch.equal(vals, getattr(full, name).vals) and torch.equal(widths, getattr(full, name).widths)
+    assert shards[1].lines.starts[0] == 0 and shards[1].textures.starts[0] == 0
