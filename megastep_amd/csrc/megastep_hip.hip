@@ -184,6 +184,7 @@ __global__ __launch_bounds__(WG) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
         const float agent_radius, const float fps, const int envs_per_wg) {
     extern __shared__ float s_progress[];   // [envs_per_wg*A]
+    __shared__ float4 s_near[WAVES][WAVE];  // per wave: the walls within reach of its agent
     const int N = sc.n_envs, A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tasks = envs_per_wg*A;
@@ -207,10 +208,52 @@ __global__ __launch_bounds__(WG) void physics_kernel(
         }
         const int L = sc.lines_widths[n];
         const float4* __restrict__ ln = lines4 + sc.lines_starts[n];
-        for (int l = AF + lane; l < L; l += WAVE) {
-            const float4 w = ln[l];
-            x = ms_min(x, collision_cs(p0, v0, p2(w.x, w.y), p2(w.z, w.w), agent_radius));
+        // Reach cull (exact): all four sub-tests of collision_cs leave x = 1 for a wall farther from the
+        // agent than 1.02|v| + 2r - the crossing and side tests need the wall within |v| + r of p, and an
+        // endpoint that far ahead clamps to 1 (0.99 (a.s - backoff) >= 1).  The margin dwarfs rounding.
+        // Lanes test one wall each with cheap arithmetic; the few walls in reach are compacted into LDS
+        // and only those pay for the ten divides and five square roots of the real test.
+        const float r1 = 1.001f*agent_radius;
+        const float reach = 1.02f*len(v0) + 2.f*r1 + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+        const float reach2 = reach*reach;
+        int cnt = 0;
+        for (int l0 = AF; l0 < L; l0 += WAVE) {
+            const int l = l0 + lane;
+            bool in = false;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (l < L) {
+                w = ln[l];
+                const float pqx = w.x - p0.x, pqy = w.y - p0.y, vx = w.z - w.x, vy = w.w - w.y;
+                float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+                tc = fminf(fmaxf(tc, 0.f), 1.f);
+                tc = (tc == tc) ? tc : 0.f;
+                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+                in = !(0.9998f*(qx*qx + qy*qy) > reach2);              // NaNs stay in
+            }
+            const unsigned long long m = __ballot(in);
+            const int nk = __popcll(m);
+            if (cnt + nk > WAVE) {                                      // flush a full list first
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (lane < cnt) {
+                    const float4 u = s_near[wave][lane];
+                    x = ms_min(x, collision_cs(p0, v0, p2(u.x, u.y), p2(u.z, u.w), agent_radius));
+                }
+                __builtin_amdgcn_wave_barrier();
+                cnt = 0;
+            }
+            if (in) s_near[wave][cnt + __popcll(m & ((1ull << lane) - 1ull))] = w;
+            cnt += nk;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < cnt) {
+            const float4 u = s_near[wave][lane];
+            x = ms_min(x, collision_cs(p0, v0, p2(u.x, u.y), p2(u.z, u.w), agent_radius));
+        }
+        __builtin_amdgcn_wave_barrier();
         x = wave_min(x);
         if (lane == 0) s_progress[t] = x;
     }
@@ -261,7 +304,12 @@ __device__ inline bool light_blocked(P2 I, P2 U, float ax, float ay, float vx, f
 // ------------------------------------------------------------------------------------------------
 // render = draw + raycast + shader                                            kernels.cu:297-475
 // ------------------------------------------------------------------------------------------------
-constexpr int CH = 256;   // lines culled per chunk = capacity of a wave's candidate list
+#ifndef MS_GROUPS
+#define MS_GROUPS 8
+#endif
+constexpr int GROUPS = MS_GROUPS;     // ray groups (sub-wedges) per wave
+constexpr int GSIZE = WAVE/GROUPS;    // rays per group
+constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair list in the dynamic-light pass
 
 struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
 
@@ -297,8 +345,8 @@ __device__ inline Filt tex_filter(float x, int w) {
 __global__ __launch_bounds__(WG) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans) {
-    __shared__ Cand  s_cand[WAVES][CH];
-    __shared__ float2 s_cand2[WAVES][CH];       // (cross(PQ, V), line index bits)
+    __shared__ Cand  s_cand[WAVES][PAIRS];      // raycast: the chunk's 64 lines; lighting: pair walls
+    __shared__ int   s_aux[WAVES][PAIRS + 2*WAVE];   // lighting: pair light slots, then 64 x 2 shadow words
     __shared__ float s_screen[WAVES][3*WAVE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -338,67 +386,101 @@ __global__ __launch_bounds__(WG) void render_kernel(
     const float rlen = sqrtf(rx*rx + ry*ry);
     const float near = agent_radius/rlen;
 
-    // wedge of this wave's rays in the agent frame: y_lo*x' <= y' <= y_hi*x', x' > 0
-    const float y_hi = (Rf - 2*(float)(g*WAVE) - 1)*half_screen/Rf;
-    const float y_lo = (Rf - 2*(float)r_last - 1)*half_screen/Rf;
-    const float k_hi = sqrtf(1.f + y_hi*y_hi), k_lo = sqrtf(1.f + y_lo*y_lo);
+    // Screen-space bookkeeping for the culling below.  In the agent frame (x' forward, y' left) a point
+    // is seen at screen coordinate ys = y'/x', i.e. at the continuous ray index c_a - ys*c_b (ray_y inverted).
+    // Nothing with x' below x_clip can be hit: a hit has x' = s > agent_radius/|ru| > 2 x_clip.
+    const float c_a = 0.5f*(Rf - 1.f), c_b = 0.5f*Rf/half_screen;
+    const float x_clip = 0.5f*agent_radius/sqrtf(1.f + half_screen*half_screen);
+    const float g0 = (float)(g*WAVE);
+    const int my_group = lane/GSIZE;
 
     float nearest_s = INFINITY;
     int nearest_idx = -1;
+#ifdef MS_DEBUG_COUNT
+    int dbg_iters = 0, dbg_mine = 0, dbg_hits = 0, dbg_inc = 0;
+#endif
 
-    for (int c0 = 0; c0 < L; c0 += CH) {
-        // ---- pass 1: lane = line. Cull + precompute + ordered compaction into LDS.
-        int cnt = 0;
-        const int c1 = min(c0 + CH, L);
-        for (int l0 = c0; l0 < c1; l0 += WAVE) {
-            const int l = l0 + lane;
-            bool keep = false;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l < c1) {
-                w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
-                const float dax = w.x - pp.x, day = w.y - pp.y;       // PQ = Q - P
-                const float dbx = w.z - pp.x, dby = w.w - pp.y;
-                // agent-frame coordinates of both endpoints
-                const float xa = cs*dax + sn*day, ya = cs*day - sn*dax;
-                const float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
-                // Conservative: drop a segment only if it lies wholly, by a margin ~1e3 rounding
-                // errors wide, in a half-plane that no forward ray of this wave can enter.
-                const float dl = 1e-3f + 1e-4f*(fabsf(dax) + fabsf(day) + fabsf(dbx) + fabsf(dby));
-                const bool behind = (xa < -dl) & (xb < -dl);
-                const bool above = (ya - y_hi*xa > dl*k_hi) & (yb - y_hi*xb > dl*k_hi);
-                const bool below = (y_lo*xa - ya > dl*k_lo) & (y_lo*xb - yb > dl*k_lo);
-                keep = !(behind | above | below);
+    for (int c0 = 0; c0 < L; c0 += WAVE) {
+        // ---- pass 1: lane = line.  Each line of the chunk gets a CONSERVATIVE interval [r_lo, r_hi] of
+        // continuous ray indices it can be hit from; a ballot per ray group turns those into one 64-bit
+        // line mask per group.  Margins are ~1e3 rounding errors wide; anything doubtful is kept.
+        const int l = c0 + lane;
+        bool inc = false;
+        float r_lo = 0.f, r_hi = 0.f, dmin2 = 0.f;
+        // Depth bound per ray group: the largest squared hit distance any of its rays still holds.  The
+        // fold state only ever decreases, so a line whose nearest point is beyond that bound can never
+        // pass `s < nearest_s - 1e-4` for any ray of the group - now or later (exact, with 1e-4 slack).
+        float bound2 = (nearest_idx >= 0) ? nearest_s*nearest_s*(rx*rx + ry*ry) : INFINITY;
+        #pragma unroll
+        for (int o = 1; o < GSIZE; o <<= 1) bound2 = fmaxf(bound2, __shfl_xor(bound2, o, WAVE));
+        if (l < L) {
+            const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+            const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
+            const float dbx = w.z - pp.x, dby = w.w - pp.y;
+            s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
+            // agent-frame coordinates of both endpoints
+            float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
+            float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
+            const bool fa = xa >= x_clip, fb = xb >= x_clip;
+            inc = fa | fb | !(xa == xa) | !(xb == xb);                  // wholly behind the clip plane: never hit
+            if (fa != fb) {                                             // clip the hidden end to x' = x_clip
+                const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
+                const float yc = ya + t*(yb - ya);
+                if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                const float vx = w.z - w.x, vy = w.w - w.y;           // v = b - a
-                const float pqx = w.x - pp.x, pqy = w.y - pp.y;
-                s_cand[wave][pos] = Cand{pqx, pqy, vx, vy};
-                s_cand2[wave][pos] = make_float2(pqx*vy - pqy*vx, __int_as_float(l));   // cross(PQ, V)
-            }
-            cnt += __popcll(m);
+            const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
+            const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
+            const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
+            r_lo = fminf(ra, rb) - marg - g0;
+            r_hi = fmaxf(ra, rb) + marg - g0;
+            // squared distance from the agent to the segment, shaved by 2e-4 so it is a lower bound
+            const float vx = w.z - w.x, vy = w.w - w.y;
+            float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+            tc = fminf(fmaxf(tc, 0.f), 1.f);
+            tc = (tc == tc) ? tc : 0.f;
+            const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+            dmin2 = 0.9998f*(qx*qx + qy*qy);
+        }
+        unsigned long long my_mask = 0ull;
+        #pragma unroll
+        for (int k = 0; k < GROUPS; k++) {
+            // excluded only if provably outside the group's rays [k*GSIZE, k*GSIZE + GSIZE - 1]; NaNs keep
+            const float b2 = readlane_f(bound2, k*GSIZE);
+            const bool ov = inc & !((r_lo > (float)(k*GSIZE + GSIZE - 1)) | (r_hi < (float)(k*GSIZE)) | (dmin2 > b2));
+            const unsigned long long mk = __ballot(ov);
+            if (my_group == k) my_mask = mk;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- pass 2: lane = ray. Ordered fold over the candidates (kernels.cu:352-377).
+        // ---- pass 2: lane = ray.  Every lane walks ITS group's lines in index order, so the fold is
+        // the reference's sequential one (kernels.cu:352-377) minus lines that provably cannot hit.
         // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked).
-        #pragma unroll 4
-        for (int i = 0; i < cnt; i++) {
-            const Cand cd = s_cand[wave][i];
+#ifdef MS_DEBUG_COUNT
+        dbg_mine += __popcll(my_mask); dbg_inc += __popcll(__ballot(inc));
+#endif
+        while (__ballot(my_mask != 0ull)) {
+#ifdef MS_DEBUG_COUNT
+            dbg_iters++;
+#endif
+            const bool active = my_mask != 0ull;
+            const int j = active ? __ffsll((long long)my_mask) - 1 : 0;
+            my_mask &= my_mask - 1ull;
+            const Cand cd = s_cand[wave][j];
             const float d = rx*cd.vy - ry*cd.vx;                       // cross(ru, v)
             const float nt = cd.pqx*ry - cd.pqy*rx;                    // cross(PQ, ru)
             const float ad = fabsf(d);
             const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
-            const bool hit = (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+            const bool hit = active & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+#ifdef MS_DEBUG_COUNT
+            dbg_hits += hit;
+#endif
             if (hit) {
-                const float2 c2 = s_cand2[wave][i];
-                const float sv = c2.x/d;                               // q.s
+                const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;      // q.s = cross(PQ, V)/UxV
                 if ((near < sv) & (sv < nearest_s - 1.e-4f)) {
                     nearest_s = sv;
-                    nearest_idx = __float_as_int(c2.y);
+                    nearest_idx = c0 + j;
                 }
             }
         }
@@ -424,6 +506,10 @@ __global__ __launch_bounds__(WG) void render_kernel(
         out.locations[o] = loc;
         out.dots[o] = dt;
         out.distances[o] = nearest_s*rlen;
+#ifdef MS_DEBUG_COUNT
+        out.locations[o] = (float)dbg_iters; out.dots[o] = (float)dbg_mine; out.distances[o] = (float)dbg_hits;
+        out.screen[3*o] = (float)dbg_inc;
+#endif
     }
 
     // ---- pass 3: shade (kernels.cu:407-450)
@@ -462,8 +548,8 @@ __global__ __launch_bounds__(WG) void render_kernel(
         const int num_i = sc.lights_widths[n];
         const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
         float4* pair_wall = reinterpret_cast<float4*>(&s_cand[wave][0]);        // (ax, ay, vx, vy)
-        int* pair_light = reinterpret_cast<int*>(&s_cand2[wave][0]);            // light slot, [0, CH)
-        unsigned* shadow = reinterpret_cast<unsigned*>(&s_cand2[wave][CH/2]);   // [64 rays][2] light bits
+        int* pair_light = &s_aux[wave][0];                                      // light slot, [0, PAIRS)
+        unsigned* shadow = reinterpret_cast<unsigned*>(&s_aux[wave][PAIRS]);    // [64 rays][2] light bits
         float acc = AMBIENT;
         for (int i0 = 0; i0 < num_i; i0 += WAVE) {
             const int ni = min(WAVE, num_i - i0);
@@ -529,7 +615,7 @@ __global__ __launch_bounds__(WG) void render_kernel(
                         const unsigned long long km = __ballot(keep);
                         if (km) {
                             const int nk = __popcll(km);
-                            if (cnt + nk > CH) flush();
+                            if (cnt + nk > PAIRS) flush();
                             if (keep) {
                                 const int pos = cnt + __popcll(km & ((1ull << lane) - 1ull));
                                 pair_wall[pos] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
