@@ -342,11 +342,13 @@ __device__ inline Filt tex_filter(float x, int w) {
     return f;
 }
 
-__global__ __launch_bounds__(WG) void render_kernel(
+#ifndef MS_RENDER_WAVES
+#define MS_RENDER_WAVES 1
+#endif
+__global__ __launch_bounds__(WG, MS_RENDER_WAVES) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans) {
-    __shared__ Cand  s_cand[WAVES][PAIRS];      // raycast: the chunk's 64 lines; lighting: pair walls
-    __shared__ int   s_aux[WAVES][PAIRS + 2*WAVE];   // lighting: pair light slots, then 64 x 2 shadow words
+    __shared__ Cand  s_cand[WAVES][WAVE];       // the chunk's 64 lines
     __shared__ float s_screen[WAVES][3*WAVE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -526,122 +528,8 @@ __global__ __launch_bounds__(WG) void render_kernel(
     const bool dynamic = is_hit & (nearest_idx < AF);
     if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
 
-    // Rays that landed on an agent need light_intensity() at the hit point: lights x walls occlusion
-    // tests per ray (kernels.cu:434-436).  Done wave-cooperatively and exactly, in two levels:
-    //   lane = wall : each wall is loaded once and tested against the CORRIDOR light -> target agent
-    //                 (a box around the segment light..agent, grown by the agent's extent) for every
-    //                 light; only walls inside a corridor can shadow anything on that agent.  The
-    //                 survivors are compacted into the (now free) LDS candidate list as (wall, light)
-    //                 pairs.
-    //   lane = pair : every pair is tested exactly against each of the wave's rays on that agent;
-    //                 a hit ORs the light's bit into that ray's shadow mask (LDS atomic).
-    // `blocked` is an OR over walls, so the order of the tests is free; the sum over lights is not
-    // and stays in light order.
-#ifdef MS_ABLATE_DYNLIGHT
-    unsigned long long dyn = 0ull;
-#else
-    unsigned long long dyn = __ballot(dynamic);
-#endif
-    if (dyn) {
-        const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
-        const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
-        const int num_i = sc.lights_widths[n];
-        const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
-        float4* pair_wall = reinterpret_cast<float4*>(&s_cand[wave][0]);        // (ax, ay, vx, vy)
-        int* pair_light = &s_aux[wave][0];                                      // light slot, [0, PAIRS)
-        unsigned* shadow = reinterpret_cast<unsigned*>(&s_aux[wave][PAIRS]);    // [64 rays][2] light bits
-        float acc = AMBIENT;
-        for (int i0 = 0; i0 < num_i; i0 += WAVE) {
-            const int ni = min(WAVE, num_i - i0);
-            // lane i holds light i0+i
-            float Ix = 0.f, Iy = 0.f, Ii = 0.f;
-            if (lane < ni) { Ix = lights[3*(i0 + lane)]; Iy = lights[3*(i0 + lane) + 1]; Ii = lights[3*(i0 + lane) + 2]; }
-            shadow[2*lane] = 0u; shadow[2*lane + 1] = 0u;
-            unsigned long long todo = dyn;
-            while (todo) {
-                const int j = __ffsll((long long)todo) - 1;
-                const int target = __builtin_amdgcn_readlane(my_target, j);
-                const bool mine = dynamic & (my_target == target);
-                const unsigned long long tmask = __ballot(mine);
-                todo &= ~tmask;
-                const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
-                // extent of this wave's hit points around the target, + float slack
-                float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
-                #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) rho = fmaxf(rho, __shfl_xor(rho, o, WAVE));
-                rho = rho + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
-                // corridor frame of light `lane`: unit vector e from the light to the target, length el
-                const float dx = T.x - Ix, dy = T.y - Iy;
-                const float el = sqrtf(dx*dx + dy*dy);
-                const float ex = dx/el, ey = dy/el;
-
-                int cnt = 0;
-                auto flush = [&]() {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (unsigned long long rays = tmask; rays; rays &= rays - 1) {
-                        const int jr = __ffsll((long long)rays) - 1;
-                        const float Cx = readlane_f(cx_l, jr), Cy = readlane_f(cy_l, jr);
-                        for (int p = lane; p < cnt; p += WAVE) {
-                            const float4 w = pair_wall[p];
-                            const int li = pair_light[p];
-                            const P2 I = p2(lights[3*(i0 + li)], lights[3*(i0 + li) + 1]);
-                            if (light_blocked(I, p2(Cx, Cy) - I, w.x, w.y, w.z, w.w))
-                                atomicOr(&shadow[2*jr + (li >> 5)], 1u << (li & 31));
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    cnt = 0;
-                };
-
-                for (int l0 = AF; l0 < L; l0 += WAVE) {
-                    const int l1 = l0 + lane;
-                    const bool live = l1 < L;
-                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (live) w = ln[l1];
-                    // wall relative to the target, and its margin
-                    const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
-                    const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
-                    for (int i = 0; i < ni; i++) {
-                        const float cex = readlane_f(ex, i), cey = readlane_f(ey, i);
-                        const float cel = readlane_f(el, i);
-                        // coordinates along / across the corridor, origin at the target, light at -cel
-                        const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
-                        const float ub = cex*bx + cey*by, vb = cex*by - cey*bx;
-                        const bool out = ((ua > m) & (ub > m)) | ((ua < -cel - m) & (ub < -cel - m)) |
-                                         ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
-                        const bool keep = live & !out;
-                        const unsigned long long km = __ballot(keep);
-                        if (km) {
-                            const int nk = __popcll(km);
-                            if (cnt + nk > PAIRS) flush();
-                            if (keep) {
-                                const int pos = cnt + __popcll(km & ((1ull << lane) - 1ull));
-                                pair_wall[pos] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
-                                pair_light[pos] = i;
-                            }
-                            cnt += nk;
-                        }
-                    }
-                }
-                if (cnt) flush();
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const unsigned long long blocked = ((unsigned long long)shadow[2*lane + 1] << 32) | shadow[2*lane];
-            __builtin_amdgcn_wave_barrier();
-            for (int i = 0; i < ni; i++) {                               // kernels.cu:261-264, in light order
-                const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
-                const float d2 = len2(I - p2(cx_l, cy_l));
-                if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
-            }
-        }
-        if (dynamic) intensity = ms_min(acc, 1.f);
-#ifdef MS_DEBUG_SHADOW
-        if (dynamic) out.dots[o] = acc;
-#endif
-        __builtin_amdgcn_wave_barrier();
-    }
+    // Rays that landed on an agent (dynamic) are lit by dynlight_kernel, launched right behind this one;
+    // they leave here black.
 
     if (is_hit) {
         const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
@@ -662,6 +550,213 @@ __global__ __launch_bounds__(WG) void render_kernel(
     for (int k = 0; k < 3; k++) {
         const int j = lane + k*WAVE;
         if (j < nfl) scr[j] = s_screen[wave][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dynamic lighting of rays that hit an agent                               kernels.cu:432-436
+// ------------------------------------------------------------------------------------------------
+// Second launch of ms_render: ONE WORKGROUP PER (env, agent, 64-ray group), kept out of render_kernel
+// so that kernel stays at 64 VGPRs.  Every wave of the workgroup reads the group's 64 hit indices and
+// the workgroup leaves at once unless one of them is an agent line (~1 group in 7 on the benchmark
+// workload).  Such rays need light_intensity() at the hit point: lights x walls occlusion tests per
+// ray.  That is done cooperatively and exactly:
+//   * all four waves hold the same per-ray state (lane = ray) and split the LIGHTS between them.
+//   * per target agent, lights are ranked NEAREST FIRST.  With every intensity >= 0 the sum
+//     0.1 + sum_i 2 I_i / max(d_i^2, 1) over unblocked lights only grows, so once the lights proven
+//     unblocked so far add up to >= 1.001 the reference's min(sum, 1) is exactly 1 whatever the
+//     remaining lights do (the 1e-3 dwarfs the reordering error of a <= 64-term float sum), and that
+//     ray is done.  Phase 1 evaluates the four nearest lights, one per wave (usually the target's own
+//     room light settles it); phase 2 deals the remaining lights round-robin to the waves.  A ray that
+//     never saturates has every light evaluated and is summed in the reference's light order.
+//   * within a wave, lane = wall: a wall can only shadow the target from a light if it reaches into
+//     the CORRIDOR light -> target (a box around that segment grown by the extent of the hit points);
+//     surviving (wall, light) pairs are compacted into the wave's LDS pair list.
+//   * lane = pair, loop over the open rays: the reference's obstructed() test; a hit ORs the light's
+//     bit into that ray's shadow words (LDS atomic, shared by the four waves).
+struct LightPair { float ax, ay, vx, vy, ix, iy; int light; int pad; };
+
+__global__ __launch_bounds__(WG) void dynlight_kernel(
+        const MsScenery sc, const MsAgents ag, const MsRender out, const int R) {
+    __shared__ LightPair s_pair[WAVES][PAIRS];
+    __shared__ unsigned s_shadow[2*WAVE];        // per ray: 64 light bits, OR-ed by all waves
+    __shared__ float s_part[WAVE];               // per ray: order-free sum of the lights proven unblocked
+    __shared__ int s_order[WAVE];                // light slots, nearest first
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fan = blockIdx.x;
+    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int G = (R + WAVE - 1)/WAVE, F = A*G;
+    const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
+    const int r = g*WAVE + lane;
+    const size_t o = ((size_t)n*A + a)*R + r;
+    // everything that does not depend on the indices is requested before they are looked at
+    const int L = sc.lines_widths[n];
+    const int base = sc.lines_starts[n];
+    const int num_i = sc.lights_widths[n];
+    const int lbase = sc.lights_starts[n];
+    int nearest_idx = -1;
+    float loc = 0.f, dt = 0.f;
+    if (r < R) { nearest_idx = out.indices[o]; loc = out.locations[o]; dt = out.dots[o]; }
+    const bool dynamic = (nearest_idx >= 0) & (nearest_idx < AF);
+    const unsigned long long dyn = __ballot(dynamic);
+    if (!dyn) return;                            // uniform across the workgroup: every wave sees the same 64 rays
+#ifdef MS_DEBUG_TIME
+    const long long t_start = __builtin_readcyclecounter();
+    long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+#define MS_STAMP(x) x = __builtin_readcyclecounter()
+#else
+#define MS_STAMP(x)
+#endif
+
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)lbase;
+    float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
+    Filt f = Filt{0, 0, 0.f, 0.f};
+    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+    if (dynamic) {
+        hw = drawn_line(sc, ag, n, nearest_idx);            // same inputs, same bits as render_kernel's
+        const int start = base + nearest_idx;
+        f = tex_filter(loc, sc.textures_widths[start]);
+        const int tstart = sc.textures_starts[start];
+        const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
+        const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
+        #pragma unroll
+        for (int k = 0; k < 3; k++) { t0[k] = tl[k]; t1[k] = tr[k]; }
+    }
+    const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
+    const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
+    MS_STAMP(t_a);
+
+    float acc = AMBIENT;                 // the reference's in-order sum, for rays that do not saturate
+    bool saturated = false;
+    for (int i0 = 0; i0 < num_i; i0 += WAVE) {
+        const int ni = min(WAVE, num_i - i0);
+        // lane i holds light i0+i
+        float Ix = 0.f, Iy = 0.f, Ii = 0.f;
+        if (lane < ni) { Ix = lights[3*(i0 + lane)]; Iy = lights[3*(i0 + lane) + 1]; Ii = lights[3*(i0 + lane) + 2]; }
+        // the shortcut needs non-negative, finite contributions and all lights in this one group
+        const bool shortcut = (num_i <= WAVE) & (__ballot((lane < ni) & !(Ii >= 0.f)) == 0ull);
+        __syncthreads();
+        if (wave == 0) { s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u; s_part[lane] = AMBIENT; }
+        unsigned long long todo = dyn;
+        while (todo) {                                       // uniform across the workgroup
+            const int j = __ffsll((long long)todo) - 1;
+            const int target = __builtin_amdgcn_readlane(my_target, j);
+            const bool mine = dynamic & (my_target == target);
+            todo &= ~__ballot(mine);
+            const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
+            // extent of the hit points around the target, + float slack
+            float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
+            #pragma unroll
+            for (int q = 32; q > 0; q >>= 1) rho = fmaxf(rho, __shfl_xor(rho, q, WAVE));
+            rho = rho + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
+            // corridor frame of light `lane`: unit vector e from the light to the target, length el
+            const float dx = T.x - Ix, dy = T.y - Iy;
+            const float key = dx*dx + dy*dy;
+            const float el = sqrtf(key);
+            const float ex = dx/el, ey = dy/el;
+            // rank the lights by distance to the target (ties by slot); every wave computes the same
+            int rank = 0;
+            for (int q = 0; q < ni; q++) {
+                const float kq = readlane_f(key, q);
+                rank += ((kq < key) | ((kq == key) & (q < lane))) ? 1 : 0;
+            }
+            __syncthreads();
+            if ((wave == 0) & (lane < ni)) s_order[rank] = lane;
+            __syncthreads();
+
+            // sweep: evaluates the lights ranked o_lo, o_lo + o_step, ... < o_hi for the open rays of this target
+            auto sweep = [&](int o_lo, int o_hi, int o_step, unsigned long long open) {
+                int cnt = 0;
+                auto flush = [&]() {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int p0 = 0; p0 < cnt; p0 += WAVE) {
+                        const LightPair pr = s_pair[wave][min(p0 + lane, cnt - 1)];
+                        const P2 I = p2(pr.ix, pr.iy);
+                        for (unsigned long long rays = open; rays; rays &= rays - 1) {
+                            const int jr = __ffsll((long long)rays) - 1;
+                            const P2 C = p2(readlane_f(cx_l, jr), readlane_f(cy_l, jr));
+                            if ((p0 + lane < cnt) && light_blocked(I, C - I, pr.ax, pr.ay, pr.vx, pr.vy))
+                                atomicOr(&s_shadow[2*jr + (pr.light >> 5)], 1u << (pr.light & 31));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    cnt = 0;
+                };
+                float4 wn = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (AF + lane < L) wn = ln[AF + lane];
+                for (int l0 = AF; l0 < L; l0 += WAVE) {
+                    const bool live = l0 + lane < L;
+                    const float4 w = wn;
+                    if (l0 + WAVE + lane < L) wn = ln[l0 + WAVE + lane];      // next chunk in flight
+                    // wall relative to the target, and its margin
+                    const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
+                    const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
+                    for (int oi = o_lo; oi < o_hi; oi += o_step) {
+                        const int i = __builtin_amdgcn_readfirstlane(s_order[oi]);
+                        const float cex = readlane_f(ex, i), cey = readlane_f(ey, i), cel = readlane_f(el, i);
+                        // coordinates along / across the corridor, origin at the target, light at -cel
+                        const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
+                        const float ub = cex*bx + cey*by, vb = cex*by - cey*bx;
+                        const bool outside = ((ua > m) & (ub > m)) | ((ua < -cel - m) & (ub < -cel - m)) |
+                                             ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
+                        const bool keep = live & !outside;
+                        const unsigned long long km = __ballot(keep);
+                        if (km) {
+                            const int nk = __popcll(km);
+                            if (cnt + nk > PAIRS) flush();
+                            if (keep) s_pair[wave][cnt + __popcll(km & ((1ull << lane) - 1ull))] =
+                                LightPair{w.x, w.y, w.z - w.x, w.w - w.y, readlane_f(Ix, i), readlane_f(Iy, i), i, 0};
+                            cnt += nk;
+                        }
+                    }
+                }
+                if (cnt) flush();
+            };
+
+            // phase 1: the four nearest lights, one per wave
+            MS_STAMP(t_b);
+            unsigned long long open = __ballot(mine);
+            if (wave < ni) sweep(wave, wave + 1, 1, open);
+            __syncthreads();
+            if (wave < ni) {
+                const int i = __builtin_amdgcn_readfirstlane(s_order[wave]);
+                const unsigned long long blocked = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
+                if (mine & !((blocked >> i) & 1ull)) {
+                    const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
+                    atomicAdd(&s_part[lane], LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f));
+                }
+            }
+            __syncthreads();
+            if (mine) saturated = shortcut & (s_part[lane] >= 1.001f);
+            MS_STAMP(t_c);
+            // phase 2: whatever is left, the remaining lights dealt round-robin to the waves
+            open = __ballot(mine & !saturated);              // identical in every wave
+            if (open && ni > WAVES) sweep(WAVES + wave, ni, WAVES, open);
+        }
+        __syncthreads();
+        if (!__ballot(dynamic & !saturated)) break;                  // every ray clamps to 1: no sum needed
+        const unsigned long long blocked = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
+        for (int i = 0; i < ni; i++) {                               // kernels.cu:261-264, in light order
+            const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
+            const float d2 = len2(I - p2(cx_l, cy_l));
+            if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+        }
+    }
+    if (dynamic & (wave == 0)) {                             // kernels.cu:441-445
+        const float intensity = saturated ? 1.f : ms_min(acc, 1.f);
+        const float dn = 1 - dt*dt;
+        out.screen[3*o]     = dn*intensity*(f.lw*t0[0] + f.rw*t1[0]);
+        out.screen[3*o + 1] = dn*intensity*(f.lw*t0[1] + f.rw*t1[1]);
+        out.screen[3*o + 2] = dn*intensity*(f.lw*t0[2] + f.rw*t1[2]);
+#ifdef MS_DEBUG_TIME
+        MS_STAMP(t_d);
+        out.distances[o] = (float)(t_d - t_start);
+        out.locations[o] = (float)(t_a - t_start); out.dots[o] = (float)(t_b - t_a); out.screen[3*o] = (float)(t_c - t_b);
+#endif
     }
 }
 
@@ -803,6 +898,8 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
     hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
                        *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+    if (sc->n_agents > 1)    // with one agent per env no ray can land on an agent line (own lines sit inside the near plane)
+        hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
