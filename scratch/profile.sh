@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collects the round's rocprofv3 evidence into gpurun_out/prof_$1/: kernel-trace stats of the default bench command,
+# then HBM traffic counters in separate PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
+tag=$1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/prof_$tag; mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $out/sq -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_sq.log 2>&1
+python - <<PY
+import pandas as pd, json
+out='$out'
+st = pd.read_csv(f'{out}/stats/bench_kernel_stats.csv')
+st = st[st.Name.str.contains('render_kernel|physics_kernel|dynlight_kernel|bake_kernel')]
+print(st[['Name','Calls','AverageNs','MinNs','MaxNs']].to_string())
+res = {}
+for c, f in [('FETCH_SIZE','fetch'),('WRITE_SIZE','write')]:
+    d = pd.read_csv(f'{out}/{f}/bench_counter_collection.csv')
+    d['k'] = d.Kernel_Name.str.extract(r'(render_kernel|physics_kernel|dynlight_kernel)')
+    g = d[d.k.notna() & (d.Counter_Name==c)].groupby('k').Counter_Value.mean()
+    res[c] = g.to_dict(); print(c, '(KB per launch, raw counter)', g.round(0).to_dict())
+json.dump(res, open(f'{out}/traffic_raw.json','w'))
+PY
+tail -1 $out/bench_stats.log | cut -c1-400
