@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/megastep_hip.h"
 
 namespace {
@@ -173,6 +174,24 @@ __device__ inline float wave_min(float x) {
 // v_readlane_b32 of a float: broadcast lane `l` (wave-uniform) of v through an SGPR, no LDS round trip
 __device__ inline float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ inline float bits_f(uint32_t u) { return __uint_as_float(u); }
+
+// Wave-wide inclusive scans on the VALU (DPP row shifts + the gfx9 row broadcasts), no LDS traffic.
+// `ident` fills lanes whose DPP source falls off the row / the masked rows.
+#define MS_DPP(ident, x, ctrl, rows) __builtin_amdgcn_update_dpp(ident, x, ctrl, rows, 0xf, false)
+__device__ inline int wave_scan_add(int x) {
+    x += MS_DPP(0, x, 0x111, 0xf); x += MS_DPP(0, x, 0x112, 0xf);      // row_shr:1, :2
+    x += MS_DPP(0, x, 0x114, 0xf); x += MS_DPP(0, x, 0x118, 0xf);      // row_shr:4, :8
+    x += MS_DPP(0, x, 0x142, 0xa);                                     // row_bcast:15 into rows 1, 3
+    x += MS_DPP(0, x, 0x143, 0xc);                                     // row_bcast:31 into rows 2, 3
+    return x;
+}
+__device__ inline int wave_scan_max(int x) {                           // for values >= -1
+    x = max(x, MS_DPP(-1, x, 0x111, 0xf)); x = max(x, MS_DPP(-1, x, 0x112, 0xf));
+    x = max(x, MS_DPP(-1, x, 0x114, 0xf)); x = max(x, MS_DPP(-1, x, 0x118, 0xf));
+    x = max(x, MS_DPP(-1, x, 0x142, 0xa));
+    x = max(x, MS_DPP(-1, x, 0x143, 0xc));
+    return x;
+}
 __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,10 +361,11 @@ __device__ inline Filt tex_filter(float x, int w) {
     return f;
 }
 
-#ifndef MS_RENDER_WAVES
-#define MS_RENDER_WAVES 1
-#endif
-__global__ __launch_bounds__(WG, MS_RENDER_WAVES) void render_kernel(
+// IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
+// IMPL 1 ("pairs", default): (line, ray) pairs flattened over all 64 lanes + LDS atomic argmin; rays whose
+//          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
+template <int IMPL>
+__global__ __launch_bounds__(WG) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans) {
     __shared__ Cand  s_cand[WAVES][WAVE];       // the chunk's 64 lines
@@ -361,6 +381,10 @@ __global__ __launch_bounds__(WG, MS_RENDER_WAVES) void render_kernel(
 
     const int fan = lb*WAVES + wave;
     if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
+#ifdef MS_DEBUG_RTIME
+    const long long rt_start = __builtin_readcyclecounter();
+    long long rt_scan = 0; int rt_amb = 0, rt_iters = 0, rt_pairs = 0;
+#endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
     const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
@@ -402,91 +426,296 @@ __global__ __launch_bounds__(WG, MS_RENDER_WAVES) void render_kernel(
     int dbg_iters = 0, dbg_mine = 0, dbg_hits = 0, dbg_inc = 0;
 #endif
 
-    for (int c0 = 0; c0 < L; c0 += WAVE) {
-        // ---- pass 1: lane = line.  Each line of the chunk gets a CONSERVATIVE interval [r_lo, r_hi] of
-        // continuous ray indices it can be hit from; a ballot per ray group turns those into one 64-bit
-        // line mask per group.  Margins are ~1e3 rounding errors wide; anything doubtful is kept.
-        const int l = c0 + lane;
-        bool inc = false;
-        float r_lo = 0.f, r_hi = 0.f, dmin2 = 0.f;
-        // Depth bound per ray group: the largest squared hit distance any of its rays still holds.  The
-        // fold state only ever decreases, so a line whose nearest point is beyond that bound can never
-        // pass `s < nearest_s - 1e-4` for any ray of the group - now or later (exact, with 1e-4 slack).
-        float bound2 = (nearest_idx >= 0) ? nearest_s*nearest_s*(rx*rx + ry*ry) : INFINITY;
-        #pragma unroll
-        for (int o = 1; o < GSIZE; o <<= 1) bound2 = fmaxf(bound2, __shfl_xor(bound2, o, WAVE));
-        if (l < L) {
-            const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
-            const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
-            const float dbx = w.z - pp.x, dby = w.w - pp.y;
-            s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
-            // agent-frame coordinates of both endpoints
-            float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
-            float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
-            const bool fa = xa >= x_clip, fb = xb >= x_clip;
-            inc = fa | fb | !(xa == xa) | !(xb == xb);                  // wholly behind the clip plane: never hit
-            if (fa != fb) {                                             // clip the hidden end to x' = x_clip
-                const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
-                const float yc = ya + t*(yb - ya);
-                if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
-            }
-            const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
-            const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
-            const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
-            r_lo = fminf(ra, rb) - marg - g0;
-            r_hi = fmaxf(ra, rb) + marg - g0;
-            // squared distance from the agent to the segment, shaved by 2e-4 so it is a lower bound
-            const float vx = w.z - w.x, vy = w.w - w.y;
-            float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
-            tc = fminf(fmaxf(tc, 0.f), 1.f);
-            tc = (tc == tc) ? tc : 0.f;
-            const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-            dmin2 = 0.9998f*(qx*qx + qy*qy);
-        }
-        unsigned long long my_mask = 0ull;
-        #pragma unroll
-        for (int k = 0; k < GROUPS; k++) {
-            // excluded only if provably outside the group's rays [k*GSIZE, k*GSIZE + GSIZE - 1]; NaNs keep
-            const float b2 = readlane_f(bound2, k*GSIZE);
-            const bool ov = inc & !((r_lo > (float)(k*GSIZE + GSIZE - 1)) | (r_hi < (float)(k*GSIZE)) | (dmin2 > b2));
-            const unsigned long long mk = __ballot(ov);
-            if (my_group == k) my_mask = mk;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (IMPL == 1) {
+        // ------------------------------------------------------------------------------------------
+        // (line, ray) pairs.  Pass 1 (lane = line) turns each line of the chunk into a conservative
+        // INTEGER interval of this wave's rays; a DPP prefix sum lays all the intervals of the chunk end
+        // to end, and pass 2 deals those (line, ray) pairs to the 64 lanes - every lane does one exact
+        // intersection per step, whichever line and ray it belongs to.  Each hit is merged into its ray's
+        // slot with a 64-bit LDS atomic min on the key (s bits << 32 | line): s > 0, so keys order by s,
+        // ties by line index.  A second atomic keeps the runner-up.
+        //
+        // Why this equals the reference's order-dependent fold (kernels.cu:369-376): let (m, j*) be the
+        // least key and m2 the runner-up's s.  If m < m2 - 1e-4f, then when the fold reaches j* its state is
+        // inf or some s_k >= m2, so j* takes over, and nothing later can pass `s < m - 1e-4`: the fold ends
+        // on (m, j*).  Otherwise the two best hits sit inside the hysteresis band (a ray through a shared
+        // wall corner, coincident walls): with the third-best clearly behind, the fold of those two in line
+        // order settles it; failing that the ray is re-done by the literal sequential fold below.
+        // ------------------------------------------------------------------------------------------
+        __shared__ int s_info[WAVES][WAVE];                   // per line: (first pair << 6) | first ray
+        __shared__ int s_mark[WAVES][WAVE];                   // pair window: which line starts here
+        __shared__ float4 s_ray[WAVES][WAVE];                 // per ray: rx, ry, near
+        __shared__ unsigned long long s_best[WAVES][WAVE], s_second[WAVES][WAVE], s_third[WAVES][WAVE];
+        s_ray[wave][lane] = make_float4(rx, ry, near, 0.f);
+        s_best[wave][lane] = ~0ull;
+        s_second[wave][lane] = ~0ull;
+        s_third[wave][lane] = ~0ull;
+        const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
 
-        // ---- pass 2: lane = ray.  Every lane walks ITS group's lines in index order, so the fold is
-        // the reference's sequential one (kernels.cu:352-377) minus lines that provably cannot hit.
-        // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked).
-#ifdef MS_DEBUG_COUNT
-        dbg_mine += __popcll(my_mask); dbg_inc += __popcll(__ballot(inc));
+        for (int c0 = 0; c0 < L; c0 += WAVE) {
+            const int l = c0 + lane;
+            int lo = 0, len = 0;
+            if (l < L) {
+                const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
+                const float dbx = w.z - pp.x, dby = w.w - pp.y;
+                s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
+                // agent-frame coordinates of both endpoints
+                float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
+                float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
+                const bool fa = xa >= x_clip, fb = xb >= x_clip;
+                const bool inc = fa | fb | !(xa == xa) | !(xb == xb);       // wholly behind the clip plane: never hit
+                if (fa != fb) {                                             // clip the hidden end to x' = x_clip
+                    const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
+                    const float yc = ya + t*(yb - ya);
+                    if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
+                }
+                const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
+                const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
+                const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
+                // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
+                const float flo = fminf(fmaxf(fminf(ra, rb) - marg - g0, 0.f), 64.f);
+                const float fhi = fmaxf(fminf(fmaxf(ra, rb) + marg - g0, last_local), -1.f);
+                lo = (int)ceilf(flo);
+                len = inc ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+            }
+            const int incl = wave_scan_add(len);
+            const int first = incl - len;                                    // this line's first pair
+            const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
+            s_info[wave][lane] = (first << 6) | (lo & 63);
+            int carry = -1;
+#ifdef MS_DEBUG_RTIME
+            rt_pairs += P;
 #endif
-        while (__ballot(my_mask != 0ull)) {
-#ifdef MS_DEBUG_COUNT
-            dbg_iters++;
+            for (int p0 = 0; p0 < P; p0 += WAVE) {
+#ifdef MS_DEBUG_RTIME
+                rt_iters++;
 #endif
-            const bool active = my_mask != 0ull;
-            const int j = active ? __ffsll((long long)my_mask) - 1 : 0;
-            my_mask &= my_mask - 1ull;
-            const Cand cd = s_cand[wave][j];
-            const float d = rx*cd.vy - ry*cd.vx;                       // cross(ru, v)
-            const float nt = cd.pqx*ry - cd.pqy*rx;                    // cross(PQ, ru)
-            const float ad = fabsf(d);
-            const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
-            const bool hit = active & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
-#ifdef MS_DEBUG_COUNT
-            dbg_hits += hit;
-#endif
-            if (hit) {
-                const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;      // q.s = cross(PQ, V)/UxV
-                if ((near < sv) & (sv < nearest_s - 1.e-4f)) {
-                    nearest_s = sv;
-                    nearest_idx = c0 + j;
+                // which line owns pair p0 + lane: lines mark their first pair, a max-scan spreads the marks
+                s_mark[wave][lane] = -1;
+                if ((len > 0) & (first >= p0) & (first < p0 + WAVE)) s_mark[wave][first - p0] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int owner = max(wave_scan_max(s_mark[wave][lane]), carry);
+                carry = __builtin_amdgcn_readlane(owner, 63);
+                const int p = p0 + lane;
+                const bool valid = p < P;
+                const int j = valid ? owner : 0;
+                const int info = s_info[wave][j];
+                const int rr = valid ? (info & 63) + (p - (info >> 6)) : 0;  // ray of this pair, wave-local
+                const Cand cd = s_cand[wave][j];
+                const float4 ray = s_ray[wave][rr];
+                const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
+                const float nt = cd.pqx*ray.y - cd.pqy*ray.x;                // cross(PQ, ru)
+                const float ad = fabsf(d);
+                const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked)
+                const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+                if (hit) {
+                    const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
+                    if (ray.z < sv) {                                        // beyond the near plane, kernels.cu:369
+                        const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)(c0 + j);
+                        // keep the three smallest keys: whatever loses at one level drops to the next
+                        const unsigned long long old1 = atomicMin(&s_best[wave][rr], key);
+                        const unsigned long long lose1 = old1 > key ? old1 : key;
+                        if (lose1 != ~0ull) {
+                            const unsigned long long old2 = atomicMin(&s_second[wave][rr], lose1);
+                            const unsigned long long lose2 = old2 > lose1 ? old2 : lose1;
+                            if (lose2 != ~0ull) atomicMin(&s_third[wave][rr], lose2);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long best = s_best[wave][lane], second = s_second[wave][lane], third = s_third[wave][lane];
+        bool ambiguous = false;
+        if (best != ~0ull) {
+            const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
+            const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
+            nearest_s = s1;
+            nearest_idx = i1;
+            if ((second != ~0ull) && !(s1 < s2 - 1.e-4f)) {
+                // The two best hits are inside the band.  If every other hit is clearly behind both
+                // (s2 < s3 - 1e-4f, s3 the third-smallest), no other line can interfere: each of the two
+                // beats any state left by the others and the others never beat them, so the fold is the
+                // fold of just these two in line order.
+                if ((third == ~0ull) || (s2 < s3 - 1.e-4f)) {
+                    const bool first_is_1 = i1 < i2;
+                    const float sa = first_is_1 ? s1 : s2, sb = first_is_1 ? s2 : s1;
+                    const int ia = first_is_1 ? i1 : i2, ib = first_is_1 ? i2 : i1;
+                    const bool b_wins = sb < sa - 1.e-4f;
+                    nearest_s = b_wins ? sb : sa;
+                    nearest_idx = b_wins ? ib : ia;
+                } else {
+                    ambiguous = true;
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        // The literal fold for the rays that need it (kernels.cu:352-377).  Chunk by chunk, lane = line;
+        // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
+        // line order into the ray's own state, which lives in the ray's lane.
+        const unsigned long long amb = __ballot(ambiguous);
+        if (__popcll(amb) > 6) {
+            // many such rays (a view full of coincident walls): cheaper to let every one of them walk all
+            // the lines itself, lines broadcast from LDS
+            float x = INFINITY;
+            int xi = -1;
+            for (int c0 = 0; c0 < L; c0 += WAVE) {
+                const int l = c0 + lane;
+                if (l < L) {
+                    const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                    s_cand[wave][lane] = Cand{w.x - pp.x, w.y - pp.y, w.z - w.x, w.w - w.y};
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int cn = min(WAVE, L - c0);
+                if (ambiguous) {
+                    for (int j = 0; j < cn; j++) {
+                        const Cand cd = s_cand[wave][j];
+                        const float d = rx*cd.vy - ry*cd.vx;
+                        const float nt = cd.pqx*ry - cd.pqy*rx;
+                        const float ad = fabsf(d);
+                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                        if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                            if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = c0 + j; }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+        } else if (amb) {
+            float x = INFINITY;
+            int xi = -1;
+            for (int c0 = 0; c0 < L; c0 += WAVE) {
+                const int l = c0 + lane;
+                float pqx = 0.f, pqy = 0.f, vx = 0.f, vy = 0.f;
+                if (l < L) {
+                    const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                    pqx = w.x - pp.x; pqy = w.y - pp.y; vx = w.z - w.x; vy = w.w - w.y;
+                }
+                for (unsigned long long todo = amb; todo; todo &= todo - 1) {
+                    const int jr = __ffsll((long long)todo) - 1;
+                    const float jrx = readlane_f(rx, jr), jry = readlane_f(ry, jr), jnear = readlane_f(near, jr);
+                    const float d = jrx*vy - jry*vx;
+                    const float nt = pqx*jry - pqy*jrx;
+                    const float ad = fabsf(d);
+                    const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                    bool valid = false;
+                    float sv = 0.f;
+                    if ((l < L) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                        sv = (pqx*vy - pqy*vx)/d;
+                        valid = jnear < sv;
+                    }
+                    unsigned long long m = __ballot(valid);
+                    if (m) {
+                        float xs = readlane_f(x, jr);
+                        int xis = __builtin_amdgcn_readlane(xi, jr);
+                        for (; m; m &= m - 1) {
+                            const int j = __ffsll((long long)m) - 1;
+                            const float sj = readlane_f(sv, j);
+                            if (sj < xs - 1.e-4f) { xs = sj; xis = c0 + j; }
+                        }
+                        if (lane == jr) { x = xs; xi = xis; }
+                    }
+                }
+            }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+        }
+    } else {
+        for (int c0 = 0; c0 < L; c0 += WAVE) {
+            // ---- pass 1: lane = line.  Each line of the chunk gets a CONSERVATIVE interval [r_lo, r_hi] of
+            // continuous ray indices it can be hit from; a ballot per ray group turns those into one 64-bit
+            // line mask per group.  Margins are ~1e3 rounding errors wide; anything doubtful is kept.
+            const int l = c0 + lane;
+            bool inc = false;
+            float r_lo = 0.f, r_hi = 0.f, dmin2 = 0.f;
+            // Depth bound per ray group: the largest squared hit distance any of its rays still holds.  The
+            // fold state only ever decreases, so a line whose nearest point is beyond that bound can never
+            // pass `s < nearest_s - 1e-4` for any ray of the group - now or later (exact, with 1e-4 slack).
+            float bound2 = (nearest_idx >= 0) ? nearest_s*nearest_s*(rx*rx + ry*ry) : INFINITY;
+            #pragma unroll
+            for (int o = 1; o < GSIZE; o <<= 1) bound2 = fmaxf(bound2, __shfl_xor(bound2, o, WAVE));
+            if (l < L) {
+                const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
+                const float dbx = w.z - pp.x, dby = w.w - pp.y;
+                s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
+                // agent-frame coordinates of both endpoints
+                float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
+                float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
+                const bool fa = xa >= x_clip, fb = xb >= x_clip;
+                inc = fa | fb | !(xa == xa) | !(xb == xb);                  // wholly behind the clip plane: never hit
+                if (fa != fb) {                                             // clip the hidden end to x' = x_clip
+                    const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
+                    const float yc = ya + t*(yb - ya);
+                    if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
+                }
+                const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
+                const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
+                const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
+                r_lo = fminf(ra, rb) - marg - g0;
+                r_hi = fmaxf(ra, rb) + marg - g0;
+                // squared distance from the agent to the segment, shaved by 2e-4 so it is a lower bound
+                const float vx = w.z - w.x, vy = w.w - w.y;
+                float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+                tc = fminf(fmaxf(tc, 0.f), 1.f);
+                tc = (tc == tc) ? tc : 0.f;
+                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+                dmin2 = 0.9998f*(qx*qx + qy*qy);
+            }
+            unsigned long long my_mask = 0ull;
+            #pragma unroll
+            for (int k = 0; k < GROUPS; k++) {
+                // excluded only if provably outside the group's rays [k*GSIZE, k*GSIZE + GSIZE - 1]; NaNs keep
+                const float b2 = readlane_f(bound2, k*GSIZE);
+                const bool ov = inc & !((r_lo > (float)(k*GSIZE + GSIZE - 1)) | (r_hi < (float)(k*GSIZE)) | (dmin2 > b2));
+                const unsigned long long mk = __ballot(ov);
+                if (my_group == k) my_mask = mk;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            // ---- pass 2: lane = ray.  Every lane walks ITS group's lines in index order, so the fold is
+            // the reference's sequential one (kernels.cu:352-377) minus lines that provably cannot hit.
+            // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked).
+    #ifdef MS_DEBUG_COUNT
+            dbg_mine += __popcll(my_mask); dbg_inc += __popcll(__ballot(inc));
+    #endif
+            while (__ballot(my_mask != 0ull)) {
+    #ifdef MS_DEBUG_COUNT
+                dbg_iters++;
+    #endif
+                const bool active = my_mask != 0ull;
+                const int j = active ? __ffsll((long long)my_mask) - 1 : 0;
+                my_mask &= my_mask - 1ull;
+                const Cand cd = s_cand[wave][j];
+                const float d = rx*cd.vy - ry*cd.vx;                       // cross(ru, v)
+                const float nt = cd.pqx*ry - cd.pqy*rx;                    // cross(PQ, ru)
+                const float ad = fabsf(d);
+                const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                const bool hit = active & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+    #ifdef MS_DEBUG_COUNT
+                dbg_hits += hit;
+    #endif
+                if (hit) {
+                    const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;      // q.s = cross(PQ, V)/UxV
+                    if ((near < sv) & (sv < nearest_s - 1.e-4f)) {
+                        nearest_s = sv;
+                        nearest_idx = c0 + j;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
     }
 
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
@@ -508,6 +737,13 @@ __global__ __launch_bounds__(WG, MS_RENDER_WAVES) void render_kernel(
         out.locations[o] = loc;
         out.dots[o] = dt;
         out.distances[o] = nearest_s*rlen;
+#ifdef MS_DEBUG_RTIME
+        if constexpr (IMPL == 1) {
+            const long long rt_end = __builtin_readcyclecounter();
+            out.locations[o] = (float)(rt_scan - rt_start); out.dots[o] = (float)(rt_end - rt_scan);
+            out.distances[o] = (float)rt_amb; out.indices[o] = rt_iters*100000 + rt_pairs;
+        }
+#endif
 #ifdef MS_DEBUG_COUNT
         out.locations[o] = (float)dbg_iters; out.dots[o] = (float)dbg_mine; out.distances[o] = (float)dbg_hits;
         out.screen[3*o] = (float)dbg_inc;
@@ -896,8 +1132,15 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const int blocks = (int)((n_fans + WAVES - 1)/WAVES);
     // kernels.cu:22
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
-    hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
-                       *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+    // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
+    // (kept for A/B verification); both produce the same bits.
+    static const bool seq = [] { const char* e = getenv("MEGASTEP_RENDER_IMPL"); return e && e[0] == 's'; }();
+    if (seq)
+        hipLaunchKernelGGL(render_kernel<0>, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
+                           *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+    else
+        hipLaunchKernelGGL(render_kernel<1>, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
+                           *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
     if (sc->n_agents > 1)    // with one agent per env no ray can land on an agent line (own lines sit inside the near plane)
         hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
     const hipError_t e = hipGetLastError();
