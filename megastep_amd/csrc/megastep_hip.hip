@@ -559,6 +559,9 @@ __global__ __launch_bounds__(WG) void render_kernel(
         // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
         // line order into the ray's own state, which lives in the ray's lane.
         const unsigned long long amb = __ballot(ambiguous);
+#ifdef MS_DEBUG_RTIME
+        rt_scan = __builtin_readcyclecounter(); rt_amb = __popcll(amb);
+#endif
         if (__popcll(amb) > 6) {
             // many such rays (a view full of coincident walls): cheaper to let every one of them walk all
             // the lines itself, lines broadcast from LDS

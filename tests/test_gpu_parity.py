@@ -95,3 +95,79 @@ def test_errors_are_loud():
     agents = core._init_agents(1, 1, 'cpu')
     with pytest.raises(RuntimeError, match='GPU'):
         cuda.physics(scenery, agents)
+
+
+def _custom_world(walls_per_env, n_agents, res, fov, positions, angles, lights=None):
+    """A Core over hand-made wall sets (one (W, 2, 2) array per env), agents placed explicitly."""
+    from megastep_amd import core, scene, arrdict
+    geoms = [arrdict.arrdict(walls=np.asarray(w, float), lights=np.array([[2., 2.]]) if lights is None else lights,
+                             masks=np.ones((4, 4), np.int16), res=.2) for w in walls_per_env]
+    np.random.seed(0)
+    scenery = scene.scenery(geoms, n_agents, device='cuda', random=np.random.RandomState(0))
+    c = core.Core(scenery, res=res, fov=fov, fps=10)
+    c.agents.positions[:] = torch.as_tensor(np.asarray(positions, np.float32), device=c.device)
+    c.agents.angles[:] = torch.as_tensor(np.asarray(angles, np.float32), device=c.device)
+    return c
+
+
+def test_hysteresis_band_adversarial():
+    """Stacks of (nearly) coincident walls in shuffled order: the 1e-4 z-fight rule (kernels.cu:369) makes the
+    winner depend on line order, which is exactly what the atomic-argmin path has to reproduce. Offsets straddle
+    the band: 0, 2e-5, 5e-5, 9e-5, 1e-4, 1.1e-4, 2e-4, 1e-3."""
+    rng = np.random.RandomState(3)
+    offsets = np.array([0., 0., 2e-5, 5e-5, 9e-5, 1e-4, 1.1e-4, 2e-4, 3e-4, 1e-3])
+    envs, pos, ang = [], [], []
+    for e in range(48):
+        k = rng.randint(2, 9)
+        xs = 4. + rng.choice(offsets, k)*rng.choice([1, 1, -1], k) + rng.choice([0., 0., .5], k)
+        walls = [[[x, 1. + rng.uniform(-.2, .2)], [x, 3. + rng.uniform(-.2, .2)]] for x in xs]
+        if e % 3 == 0:      # an enclosing corner so that rays through shared vertices occur too
+            walls += [[[4., 3.], [2., 3.]], [[2., 3.], [2., 1.]], [[2., 1.], [4., 1.]]]
+        if e % 4 == 0:      # duplicates and reversed duplicates
+            walls += [walls[0], [walls[1][1], walls[1][0]]]
+        order = rng.permutation(len(walls))
+        envs.append(np.array(walls)[order])
+        pos.append([[rng.uniform(2.2, 3.9), rng.uniform(1.5, 2.5)]])
+        ang.append([rng.uniform(-30, 30)])
+    # pad every env to its own length is fine: Ragged
+    c = _custom_world(envs, 1, 64, 100, pos, ang)
+    from megastep_amd import cuda
+    ref = util.OracleWorld(c)
+    ref.bake(); ref.pull_baked(c); ref.pull_agents(c)
+    r = cuda.render(c.scenery, c.agents)
+    util.assert_render_matches(c, r, ref.render())
+
+
+def test_agent_wedged_between_coincident_walls():
+    """An agent 0.11 m from a wall that is doubled by a flush pillar face: most of its rays tie."""
+    wall = [[[2., 1.], [2., 2.2]], [[2., 2.2], [2., 4.]]]
+    pillar = [[[2., 2.], [2.3, 2.]], [[2.3, 2.], [2.3, 2.4]], [[2.3, 2.4], [2., 2.4]], [[2., 2.4], [2., 2.]]]
+    triple = pillar + [[[2., 2.05], [2., 2.35]]]
+    box = [[[1., 1.], [4., 1.]], [[4., 1.], [4., 4.]], [[4., 4.], [1., 4.]], [[1., 4.], [1., 1.]]]
+    envs = [np.array(wall + pillar + box), np.array(pillar + wall + box), np.array(wall + triple + box),
+            np.array(triple[::-1] + wall + box)]
+    c = _custom_world(envs, 1, 64, 130, [[[2.11, 2.2]]]*4, [[180.], [170.], [-175.], [180.]])
+    from megastep_amd import cuda
+    ref = util.OracleWorld(c)
+    ref.bake(); ref.pull_baked(c); ref.pull_agents(c)
+    r = cuda.render(c.scenery, c.agents)
+    util.assert_render_matches(c, r, ref.render())
+
+
+def test_full_benchmark_size_matches_oracle():
+    """BASELINE.json's metric shape - 4096 envs x 4 agents x 64 rays on synthetic cubicasa plans - against the
+    oracle (OpenMP over envs), two steps."""
+    from megastep_amd import cuda
+    import bench
+    c, geometries = bench.build_world(4096, 4, 64, 130., torch.device('cuda'), seed=1, n_unique=128)
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c)
+    rng = np.random.RandomState(5)
+    for step in range(2):
+        util.random_velocities(c, rng, speed=6.)
+        ref.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        prog_ref, agents_ref = ref.physics()
+        util.assert_physics_matches(c, p, prog_ref, agents_ref)
+        util.assert_render_matches(c, r, ref.render())
