@@ -59,6 +59,19 @@ def algorithmic_bytes(core):
     return render, physics
 
 
+def measured_traffic(args, world):
+    """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact command (profiles/rNN_traffic.json,
+    written by scratch/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950). None when the workload differs from the profiled one."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
+        t = json.load(open(path))
+        w = t.get('workload', {})
+        if (w.get('envs'), w.get('agents'), w.get('res'), w.get('large', False)) == (args.envs, args.agents, args.res, args.large):
+            return t['render_bytes_per_launch']
+    return None
+
+
 def cpu_baseline(core, budget_s=12., max_envs=256):
     """The CPU oracle on a bounded sample: the first `max_envs` envs of this workload, all host cores (OpenMP)."""
     from oracle import oracle as O
@@ -171,10 +184,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from megastep_amd import sharding
+    elapsed = sharding.max_over_ranks(elapsed, device)      # the slowest rank sets the step rate
 
     render_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     rb, pb = algorithmic_bytes(core)
@@ -195,8 +206,8 @@ def main():
             'parallelism': f'env-sharded x{world}, no collectives'},
         'agent_steps_per_sec': value*A,
         'roofline': {
-            'kernel': 'render_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': achieved/HBM_PEAK_GBPS, 'traffic': None,
+            'kernel': 'ms_render = render_kernel<1> + dynlight_kernel', 'bound': 'hbm', 'achieved': achieved,
+            'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS, 'traffic': measured_traffic(args, world),
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
             'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9},
     }
