@@ -185,6 +185,13 @@ __device__ inline int wave_scan_add(int x) {
     x += MS_DPP(0, x, 0x143, 0xc);                                     // row_bcast:31 into rows 2, 3
     return x;
 }
+__device__ inline float wave_max_f(float x) {                          // all-lanes max of non-negative floats
+    int v = __float_as_int(x);                                         // non-negative floats order like ints
+    v = max(v, MS_DPP(0, v, 0x111, 0xf)); v = max(v, MS_DPP(0, v, 0x112, 0xf));
+    v = max(v, MS_DPP(0, v, 0x114, 0xf)); v = max(v, MS_DPP(0, v, 0x118, 0xf));
+    v = max(v, MS_DPP(0, v, 0x142, 0xa)); v = max(v, MS_DPP(0, v, 0x143, 0xc));
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
 __device__ inline int wave_scan_max(int x) {                           // for values >= -1
     x = max(x, MS_DPP(-1, x, 0x111, 0xf)); x = max(x, MS_DPP(-1, x, 0x112, 0xf));
     x = max(x, MS_DPP(-1, x, 0x114, 0xf)); x = max(x, MS_DPP(-1, x, 0x118, 0xf));
@@ -800,14 +807,14 @@ __global__ __launch_bounds__(WG) void render_kernel(
 // the workgroup leaves at once unless one of them is an agent line (~1 group in 7 on the benchmark
 // workload).  Such rays need light_intensity() at the hit point: lights x walls occlusion tests per
 // ray.  That is done cooperatively and exactly:
-//   * all four waves hold the same per-ray state (lane = ray) and split the LIGHTS between them.
+//   * all four waves hold the same per-ray state (lane = ray) and split the WALLS between them.
 //   * per target agent, lights are ranked NEAREST FIRST.  With every intensity >= 0 the sum
 //     0.1 + sum_i 2 I_i / max(d_i^2, 1) over unblocked lights only grows, so once the lights proven
 //     unblocked so far add up to >= 1.001 the reference's min(sum, 1) is exactly 1 whatever the
 //     remaining lights do (the 1e-3 dwarfs the reordering error of a <= 64-term float sum), and that
-//     ray is done.  Phase 1 evaluates the four nearest lights, one per wave (usually the target's own
-//     room light settles it); phase 2 deals the remaining lights round-robin to the waves.  A ray that
-//     never saturates has every light evaluated and is summed in the reference's light order.
+//     ray is done.  Phase 1 evaluates the four nearest lights (usually the target's own room light
+//     settles it); phase 2 the remaining ones.  A ray that never saturates has every light evaluated
+//     and is summed in the reference's light order.  In both phases the waves split the WALLS.
 //   * within a wave, lane = wall: a wall can only shadow the target from a light if it reaches into
 //     the CORRIDOR light -> target (a box around that segment grown by the extent of the hit points);
 //     surviving (wall, light) pairs are compacted into the wave's LDS pair list.
@@ -819,8 +826,6 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out, const int R) {
     __shared__ LightPair s_pair[WAVES][PAIRS];
     __shared__ unsigned s_shadow[2*WAVE];        // per ray: 64 light bits, OR-ed by all waves
-    __shared__ float s_part[WAVE];               // per ray: order-free sum of the lights proven unblocked
-    __shared__ int s_order[WAVE];                // light slots, nearest first
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fan = blockIdx.x;
@@ -838,7 +843,11 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
     float loc = 0.f, dt = 0.f;
     if (r < R) { nearest_idx = out.indices[o]; loc = out.locations[o]; dt = out.dots[o]; }
     const bool dynamic = (nearest_idx >= 0) & (nearest_idx < AF);
+#ifdef MS_ABLATE_DYNLIGHT
+    const unsigned long long dyn = 0ull;         // idle-cost experiment: every workgroup leaves after its reads
+#else
     const unsigned long long dyn = __ballot(dynamic);
+#endif
     if (!dyn) return;                            // uniform across the workgroup: every wave sees the same 64 rays
 #ifdef MS_DEBUG_TIME
     const long long t_start = __builtin_readcyclecounter();
@@ -854,7 +863,7 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
     Filt f = Filt{0, 0, 0.f, 0.f};
     float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
     if (dynamic) {
-        hw = drawn_line(sc, ag, n, nearest_idx);            // same inputs, same bits as render_kernel's
+        hw = ln[nearest_idx];                               // the agent line render_kernel drew and published (kernels.cu:316-317)
         const int start = base + nearest_idx;
         f = tex_filter(loc, sc.textures_widths[start]);
         const int tstart = sc.textures_starts[start];
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
         // the shortcut needs non-negative, finite contributions and all lights in this one group
         const bool shortcut = (num_i <= WAVE) & (__ballot((lane < ni) & !(Ii >= 0.f)) == 0ull);
         __syncthreads();
-        if (wave == 0) { s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u; s_part[lane] = AMBIENT; }
+        if (wave == 0) { s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u; }
         unsigned long long todo = dyn;
         while (todo) {                                       // uniform across the workgroup
             const int j = __ffsll((long long)todo) - 1;
@@ -887,9 +896,7 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
             const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
             // extent of the hit points around the target, + float slack
             float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
-            #pragma unroll
-            for (int q = 32; q > 0; q >>= 1) rho = fmaxf(rho, __shfl_xor(rho, q, WAVE));
-            rho = rho + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
+            rho = wave_max_f(rho) + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
             // corridor frame of light `lane`: unit vector e from the light to the target, length el
             const float dx = T.x - Ix, dy = T.y - Iy;
             const float key = dx*dx + dy*dy;
@@ -901,12 +908,13 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
                 const float kq = readlane_f(key, q);
                 rank += ((kq < key) | ((kq == key) & (q < lane))) ? 1 : 0;
             }
-            __syncthreads();
-            if ((wave == 0) & (lane < ni)) s_order[rank] = lane;
-            __syncthreads();
+            if (lane >= ni) rank = -1;
+            // the light ranked oi: the lane whose rank is oi
+            auto ranked = [&](int oi) { return __ffsll((long long)__ballot(rank == oi)) - 1; };
 
-            // sweep: evaluates the lights ranked o_lo, o_lo + o_step, ... < o_hi for the open rays of this target
-            auto sweep = [&](int o_lo, int o_hi, int o_step, unsigned long long open) {
+            // sweep: evaluates the lights ranked [o_lo, o_hi) for the open rays of this target against this
+            // wave's share of the walls (chunk `wave`, `wave + 4`, ...: few dependent loads per wave)
+            auto sweep = [&](int o_lo, int o_hi, unsigned long long open) {
                 int cnt = 0;
                 auto flush = [&]() {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -925,17 +933,18 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
                     __builtin_amdgcn_wave_barrier();
                     cnt = 0;
                 };
+                const int first = AF + wave*WAVE;
                 float4 wn = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (AF + lane < L) wn = ln[AF + lane];
-                for (int l0 = AF; l0 < L; l0 += WAVE) {
+                if (first + lane < L) wn = ln[first + lane];
+                for (int l0 = first; l0 < L; l0 += WAVES*WAVE) {
                     const bool live = l0 + lane < L;
                     const float4 w = wn;
-                    if (l0 + WAVE + lane < L) wn = ln[l0 + WAVE + lane];      // next chunk in flight
+                    if (l0 + WAVES*WAVE + lane < L) wn = ln[l0 + WAVES*WAVE + lane];      // next chunk in flight
                     // wall relative to the target, and its margin
                     const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
                     const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
-                    for (int oi = o_lo; oi < o_hi; oi += o_step) {
-                        const int i = __builtin_amdgcn_readfirstlane(s_order[oi]);
+                    for (int oi = o_lo; oi < o_hi; oi++) {
+                        const int i = ranked(oi);
                         const float cex = readlane_f(ex, i), cey = readlane_f(ey, i), cel = readlane_f(el, i);
                         // coordinates along / across the corridor, origin at the target, light at -cel
                         const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
@@ -956,25 +965,33 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
                 if (cnt) flush();
             };
 
-            // phase 1: the four nearest lights, one per wave
+            // phase 1: the NEAR_LIGHTS nearest lights
             MS_STAMP(t_b);
+            constexpr int NEAR_LIGHTS = 4;
+            const int n1 = min(NEAR_LIGHTS, ni);
             unsigned long long open = __ballot(mine);
-            if (wave < ni) sweep(wave, wave + 1, 1, open);
+            sweep(0, n1, open);
             __syncthreads();
-            if (wave < ni) {
-                const int i = __builtin_amdgcn_readfirstlane(s_order[wave]);
+            int near_i[NEAR_LIGHTS];                         // (ballots must run with every lane active)
+            #pragma unroll
+            for (int oi = 0; oi < NEAR_LIGHTS; oi++) near_i[oi] = ranked(min(oi, n1 - 1));
+            if (mine) {
                 const unsigned long long blocked = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
-                if (mine & !((blocked >> i) & 1ull)) {
-                    const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
-                    atomicAdd(&s_part[lane], LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f));
+                float part = AMBIENT;                        // order-free sum of the lights proven unblocked
+                #pragma unroll
+                for (int oi = 0; oi < NEAR_LIGHTS; oi++) {
+                    const int i = near_i[oi];
+                    if ((oi < n1) && !((blocked >> i) & 1ull)) {
+                        const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
+                        part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+                    }
                 }
+                saturated = shortcut & (part >= 1.001f);
             }
-            __syncthreads();
-            if (mine) saturated = shortcut & (s_part[lane] >= 1.001f);
             MS_STAMP(t_c);
-            // phase 2: whatever is left, the remaining lights dealt round-robin to the waves
+            // phase 2: whatever is left, all the remaining lights
             open = __ballot(mine & !saturated);              // identical in every wave
-            if (open && ni > WAVES) sweep(WAVES + wave, ni, WAVES, open);
+            if (open && ni > n1) sweep(n1, ni, open);
         }
         __syncthreads();
         if (!__ballot(dynamic & !saturated)) break;                  // every ray clamps to 1: no sum needed
