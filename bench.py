@@ -72,8 +72,9 @@ def measured_traffic(args, world):
     return None
 
 
-def cpu_baseline(core, budget_s=12., max_envs=256):
-    """The CPU oracle on a bounded sample: the first `max_envs` envs of this workload, all host cores (OpenMP)."""
+def cpu_baseline(core, budget_s=4., max_envs=4096):
+    """The CPU oracle on a bounded sample: the first `max_envs` envs of this workload, all host cores (OpenMP over
+    envs), for about `budget_s` seconds of wall time (a few tens of seconds of CPU work per 8 cores)."""
     from oracle import oracle as O
     from tests import util
     n = min(max_envs, core.n_envs)
@@ -98,7 +99,7 @@ def cpu_baseline(core, budget_s=12., max_envs=256):
         O.render(scene, agents, cfg)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or steps >= 200:
+        if dt > budget_s or steps >= 100:
             break
     return {'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': os.cpu_count(), 'kind': 'port',
             'sample': f'first {n} envs of the workload x {steps} steps (physics+render), C oracle with OpenMP over envs'}

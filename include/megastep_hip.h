@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 1
+#define MS_ABI_VERSION 2
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -78,7 +78,14 @@ typedef struct MsRender {
     float* dots;          /* (N, A, R)    ray . line direction,    NaN on a miss  */
     float* distances;     /* (N, A, R)    metres, +inf on a miss                  */
     float* screen;        /* (N, A, R, 3) linear RGB, 0 on a miss                 */
+    /* Optional scratch, not an output: lets ms_render hand the ray groups that need dynamic lighting
+     * from its first kernel to its second as a compact list.  At least MS_RENDER_WORKSPACE_INTS(N, A, R)
+     * ints, contents undefined before and after the call; NULL selects a slower hand-off. */
+    int*   workspace;
 } MsRender;
+
+/* ints of MsRender.workspace needed for N envs, A agents, R rays */
+#define MS_RENDER_WORKSPACE_INTS(N, A, R) (16 + (long long)(N)*(A)*(((R) + 63)/64))
 
 int         ms_abi_version(void);
 const char* ms_strerror(int code);

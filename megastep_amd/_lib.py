@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -40,7 +40,7 @@ class MsAgents(C.Structure):
 
 class MsRender(C.Structure):
     _fields_ = [('indices', C.c_void_p), ('locations', C.c_void_p), ('dots', C.c_void_p), ('distances', C.c_void_p),
-                ('screen', C.c_void_p)]
+                ('screen', C.c_void_p), ('workspace', C.c_void_p)]
 
 
 #: every symbol include/megastep_hip.h declares

@@ -775,7 +775,10 @@ __global__ __launch_bounds__(WG) void render_kernel(
     if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
 
     // Rays that landed on an agent (dynamic) are lit by dynlight_kernel, launched right behind this one;
-    // they leave here black.
+    // they leave here black, and their ray group is queued for it.
+    if (out.workspace && __ballot(dynamic)) {
+        if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
+    }
 
     if (is_hit) {
         const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
@@ -828,7 +831,11 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
     __shared__ unsigned s_shadow[2*WAVE];        // per ray: 64 light bits, OR-ed by all waves
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int fan = blockIdx.x;
+    int fan = blockIdx.x;
+    if (out.workspace) {                         // compact list from render_kernel: the busy groups start first
+        if (fan >= out.workspace[0]) return;
+        fan = out.workspace[16 + fan];
+    }
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
     const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
@@ -1155,6 +1162,10 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
     // (kept for A/B verification); both produce the same bits.
     static const bool seq = [] { const char* e = getenv("MEGASTEP_RENDER_IMPL"); return e && e[0] == 's'; }();
+    if (out->workspace && sc->n_agents > 1) {
+        const hipError_t em = hipMemsetAsync(out->workspace, 0, sizeof(int), (hipStream_t)stream);
+        if (em != hipSuccess) return hip_fail(em);
+    }
     if (seq)
         hipLaunchKernelGGL(render_kernel<0>, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
                            *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);

@@ -244,7 +244,7 @@ int oracle_ragged_index(const int* widths, int W, int* starts, int* ends, int* i
 int oracle_physics(const OrScenery* sc, OrAgents* ag, float* progress, const OrConfig* cfg) {
     const int N = sc->n_envs, A = sc->n_agents, DF = sc->n_agents*sc->n_model;
     const float fps = cfg->fps, R_ = cfg->agent_radius;
-    #pragma omp parallel for schedule(dynamic, 16)
+    #pragma omp parallel for schedule(dynamic, 1)
     for (int n = 0; n < N; n++) {
         const int L = sc->lines_widths[n];
         const float* lines = sc->lines_vals + 4*(size_t)sc->lines_starts[n];
@@ -343,7 +343,7 @@ int oracle_render(OrScenery* sc, const OrAgents* ag, OrRender* out, const OrConf
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
     const float R_ = cfg->agent_radius;
 
-    #pragma omp parallel for schedule(dynamic, 4)
+    #pragma omp parallel for schedule(dynamic, 1)
     for (int n = 0; n < N; n++) {
         float* lines = sc->lines_vals + 4*(size_t)sc->lines_starts[n];
         const int num_l = sc->lines_widths[n];
