@@ -177,27 +177,28 @@ __device__ inline float bits_f(uint32_t u) { return __uint_as_float(u); }
 
 // Wave-wide inclusive scans on the VALU (DPP row shifts + the gfx9 row broadcasts), no LDS traffic.
 // `ident` fills lanes whose DPP source falls off the row / the masked rows.
-#define MS_DPP(ident, x, ctrl, rows) __builtin_amdgcn_update_dpp(ident, x, ctrl, rows, 0xf, false)
-__device__ inline int wave_scan_add(int x) {
-    x += MS_DPP(0, x, 0x111, 0xf); x += MS_DPP(0, x, 0x112, 0xf);      // row_shr:1, :2
-    x += MS_DPP(0, x, 0x114, 0xf); x += MS_DPP(0, x, 0x118, 0xf);      // row_shr:4, :8
-    x += MS_DPP(0, x, 0x142, 0xa);                                     // row_bcast:15 into rows 1, 3
-    x += MS_DPP(0, x, 0x143, 0xc);                                     // row_bcast:31 into rows 2, 3
+// (hipcc does not fold update_dpp into the consuming op, so these are spelled out: one VALU op per step, the
+// two wait states a DPP read of a freshly written VGPR needs are in the string, EXEC must be full.)
+#define MS_SCAN6(op) \
+    "s_nop 1\n " op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 1\n " op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 1\n " op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 1\n " op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n" \
+    "s_nop 1\n " op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n" \
+    "s_nop 1\n " op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n" \
+    "s_nop 1\n"
+__device__ inline int wave_scan_add(int x) {                           // lanes without a DPP source keep their value
+    asm volatile(MS_SCAN6("v_add_u32_dpp") : "+v"(x));
+    return x;
+}
+__device__ inline int wave_scan_max(int x) {
+    asm volatile(MS_SCAN6("v_max_i32_dpp") : "+v"(x));
     return x;
 }
 __device__ inline float wave_max_f(float x) {                          // all-lanes max of non-negative floats
     int v = __float_as_int(x);                                         // non-negative floats order like ints
-    v = max(v, MS_DPP(0, v, 0x111, 0xf)); v = max(v, MS_DPP(0, v, 0x112, 0xf));
-    v = max(v, MS_DPP(0, v, 0x114, 0xf)); v = max(v, MS_DPP(0, v, 0x118, 0xf));
-    v = max(v, MS_DPP(0, v, 0x142, 0xa)); v = max(v, MS_DPP(0, v, 0x143, 0xc));
+    asm volatile(MS_SCAN6("v_max_i32_dpp") : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(v, 63));
-}
-__device__ inline int wave_scan_max(int x) {                           // for values >= -1
-    x = max(x, MS_DPP(-1, x, 0x111, 0xf)); x = max(x, MS_DPP(-1, x, 0x112, 0xf));
-    x = max(x, MS_DPP(-1, x, 0x114, 0xf)); x = max(x, MS_DPP(-1, x, 0x118, 0xf));
-    x = max(x, MS_DPP(-1, x, 0x142, 0xa));
-    x = max(x, MS_DPP(-1, x, 0x143, 0xc));
-    return x;
 }
 __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 
@@ -458,8 +459,12 @@ __global__ __launch_bounds__(WG) void render_kernel(
         s_second[wave][lane] = ~0ull;
         s_third[wave][lane] = ~0ull;
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
-
-        for (int c0 = 0; c0 < L; c0 += WAVE) {
+#ifdef MS_ABL_NOCHUNKS
+        const int L_ = 0;
+#else
+        const int L_ = L;
+#endif
+        for (int c0 = 0; c0 < L_; c0 += WAVE) {
             const int l = c0 + lane;
             int lo = 0, len = 0;
             if (l < L) {
@@ -488,7 +493,11 @@ __global__ __launch_bounds__(WG) void render_kernel(
             }
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
+#ifdef MS_ABL_NOPAIRS
+            const int P = 0;
+#else
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
+#endif
             s_info[wave][lane] = (first << 6) | (lo & 63);
             int carry = -1;
 #ifdef MS_DEBUG_RTIME
