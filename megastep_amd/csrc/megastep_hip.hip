@@ -410,10 +410,24 @@ __global__ __launch_bounds__(WG) void render_kernel(
         for (int m = lane; m < sc.n_model; m += WAVE) ln[a*sc.n_model + m] = drawn_line(sc, ag, n, a*sc.n_model + m);
     }
 
+    // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
+    // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
+    float ag_s = 0.f, ag_c = 0.f;
+    float2 ag_p = make_float2(0.f, 0.f);
+    if (lane < A) {
+        sincospi_f(ag.angles[n*A + lane]/180.f, ag_s, ag_c);
+        ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
+    }
     // --- ray setup (kernels.cu:334-344)
     float sn, cs;
-    sincospi_f(ag.angles[n*A + a]/180.f, sn, cs);
-    const float2 pp = reinterpret_cast<const float2*>(ag.positions)[n*A + a];
+    float2 pp;
+    if (A <= WAVE) {
+        sn = readlane_f(ag_s, a); cs = readlane_f(ag_c, a);
+        pp = make_float2(readlane_f(ag_p.x, a), readlane_f(ag_p.y, a));
+    } else {
+        sincospi_f(ag.angles[n*A + a]/180.f, sn, cs);
+        pp = reinterpret_cast<const float2*>(ag.positions)[n*A + a];
+    }
     const float Rf = (float)R;
     const float uy = (Rf - 2*(float)r - 1)*half_screen/Rf;            // ray_y, kernels.cu:234-236
     const float rx = cs*1.f - sn*uy, ry = sn*1.f + cs*uy;
@@ -468,7 +482,19 @@ __global__ __launch_bounds__(WG) void render_kernel(
             const int l = c0 + lane;
             int lo = 0, len = 0;
             if (l < L) {
-                const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                float4 w;
+                if (l >= AF) {
+                    w = ln[l];
+                } else if (A <= WAVE) {                                     // draw_kernel, kernels.cu:297-318
+                    const int la = l / sc.n_model;
+                    const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
+                    const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
+                    const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
+                    w.x = c_*mdl.x - s_*mdl.y + px_; w.y = s_*mdl.x + c_*mdl.y + py_;
+                    w.z = c_*mdl.z - s_*mdl.w + px_; w.w = s_*mdl.z + c_*mdl.w + py_;
+                } else {
+                    w = drawn_line(sc, ag, n, l);
+                }
                 const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
                 const float dbx = w.z - pp.x, dby = w.w - pp.y;
                 s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
