@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 2
+#define MS_ABI_VERSION 3
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */

@@ -372,12 +372,15 @@ __device__ inline Filt tex_filter(float x, int w) {
 // IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
 // IMPL 1 ("pairs", default): (line, ray) pairs flattened over all 64 lanes + LDS atomic argmin; rays whose
 //          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
-template <int IMPL>
-__global__ __launch_bounds__(WG) void render_kernel(
+// 8 waves per SIMD (<= 64 VGPRs): 2048 workgroups resident, so the benchmark's 4096 run in two even rounds.
+// RW = waves per workgroup.  The waves never talk to each other, so RW = 1 lets every wave give its slot and
+// LDS back the moment it is done instead of waiting for the slowest of four.
+template <int IMPL, int RW>
+__global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans) {
-    __shared__ Cand  s_cand[WAVES][WAVE];       // the chunk's 64 lines
-    __shared__ float s_screen[WAVES][3*WAVE];
+    __shared__ Cand  s_cand[RW][WAVE];       // the chunk's 64 lines
+    __shared__ float s_screen[RW][3*WAVE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 
@@ -387,10 +390,11 @@ __global__ __launch_bounds__(WG) void render_kernel(
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
     const int lb = (xcd < r8 ? xcd*(q8 + 1) : r8*(q8 + 1) + (xcd - r8)*q8) + ix;
 
-    const int fan = lb*WAVES + wave;
+    const int fan = lb*RW + wave;
     if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
 #ifdef MS_DEBUG_RTIME
     const long long rt_start = __builtin_readcyclecounter();
+    const unsigned long long rt_real0 = __builtin_amdgcn_s_memrealtime();
     long long rt_scan = 0; int rt_amb = 0, rt_iters = 0, rt_pairs = 0;
 #endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
@@ -464,10 +468,10 @@ __global__ __launch_bounds__(WG) void render_kernel(
         // wall corner, coincident walls): with the third-best clearly behind, the fold of those two in line
         // order settles it; failing that the ray is re-done by the literal sequential fold below.
         // ------------------------------------------------------------------------------------------
-        __shared__ int s_info[WAVES][WAVE];                   // per line: (first pair << 6) | first ray
-        __shared__ int s_mark[WAVES][WAVE];                   // pair window: which line starts here
-        __shared__ float4 s_ray[WAVES][WAVE];                 // per ray: rx, ry, near
-        __shared__ unsigned long long s_best[WAVES][WAVE], s_second[WAVES][WAVE], s_third[WAVES][WAVE];
+        __shared__ int s_info[RW][WAVE];                   // per line: (first pair << 6) | first ray
+        __shared__ int s_mark[RW][WAVE];                   // pair window: which line starts here
+        __shared__ float4 s_ray[RW][WAVE];                 // per ray: rx, ry, near
+        __shared__ unsigned long long s_best[RW][WAVE], s_second[RW][WAVE], s_third[RW][WAVE];
         s_ray[wave][lane] = make_float4(rx, ry, near, 0.f);
         s_best[wave][lane] = ~0ull;
         s_second[wave][lane] = ~0ull;
@@ -785,8 +789,15 @@ __global__ __launch_bounds__(WG) void render_kernel(
 #ifdef MS_DEBUG_RTIME
         if constexpr (IMPL == 1) {
             const long long rt_end = __builtin_readcyclecounter();
+#ifdef MS_DEBUG_TIMELINE
+            out.locations[o] = (float)(rt_real0 & 0xffffff); out.dots[o] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff);
+            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            out.distances[o] = (float)(((xcc & 0xf) << 12) | ((hwid >> 8) & 0xf) << 4 | ((hwid >> 4) & 0x3)); out.indices[o] = rt_iters*100000 + rt_pairs;
+#else
             out.locations[o] = (float)(rt_scan - rt_start); out.dots[o] = (float)(rt_end - rt_scan);
             out.distances[o] = (float)rt_amb; out.indices[o] = rt_iters*100000 + rt_pairs;
+#endif
         }
 #endif
 #ifdef MS_DEBUG_COUNT
@@ -1191,7 +1202,6 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const int G = (R + WAVE - 1)/WAVE;
     const long long n_fans = (long long)sc->n_envs*sc->n_agents*G;
     if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
-    const int blocks = (int)((n_fans + WAVES - 1)/WAVES);
     // kernels.cu:22
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
     // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
@@ -1201,11 +1211,13 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
         const hipError_t em = hipMemsetAsync(out->workspace, 0, sizeof(int), (hipStream_t)stream);
         if (em != hipSuccess) return hip_fail(em);
     }
+    constexpr int RW = 1;
+    const int rblocks = (int)((n_fans + RW - 1)/RW);
     if (seq)
-        hipLaunchKernelGGL(render_kernel<0>, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((render_kernel<0, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
                            *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
     else
-        hipLaunchKernelGGL(render_kernel<1>, dim3(blocks), dim3(WG), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL((render_kernel<1, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
                            *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
     if (sc->n_agents > 1)    // with one agent per env no ray can land on an agent line (own lines sit inside the near plane)
         hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
