@@ -1,0 +1,81 @@
+"""The example environments (the reference's callers of the hot path, demo/envs/*.py) stepping on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _decision(env, n):
+    from megastep_amd import arrdict
+    return arrdict.arrdict(actions=torch.randint(0, 7, (n, env.action_space.shape[0]), device='cuda'))
+
+
+def test_minimal_env_shapes_and_motion():
+    """docs/tutorials/minimal-env/index.rst:288-290: Minimal(128).reset().obs; code gives (N, 1, 3, 1, 64)."""
+    from megastep_amd.demo import Minimal
+    torch.manual_seed(0); np.random.seed(0)
+    env = Minimal(128)
+    world = env.reset()
+    assert world.obs.shape == (128, 1, 3, 1, 64) and world.obs.dtype == torch.float32
+    assert 0 <= world.obs.min() and world.obs.max() <= 1 and world.obs.max() > 0
+    p0 = env.core.agents.positions.clone()
+    for _ in range(5):
+        world = env.step(_decision(env, 128))
+    assert (env.core.agents.positions - p0).abs().max() > 0
+    pos = env.core.agents.positions
+    assert (pos > 1).all() and (pos < 6).all(), 'agents must stay inside the box'
+    state = env.state(0)
+    assert state.rgb.shape == (1, 3, 1, 64) and state.core.scenery.lines.shape == (12, 2, 2)
+
+
+def test_explorer_env():
+    from megastep_amd.demo import Explorer
+    from megastep_amd import cubicasa
+    torch.manual_seed(0); np.random.seed(0)
+    env = Explorer(16, geometries=cubicasa.sample(16, n_unique=16))
+    world = env.reset()
+    assert world.obs.rgb.shape == (16, 1, 3, 1, 64) and world.obs.d.shape == (16, 1, 1, 1, 64) and world.obs.imu.shape == (16, 1, 3)
+    assert world.reset.all() and (world.reward == 0).all()
+    total = torch.zeros(16, device='cuda')
+    for _ in range(20):
+        world = env.step(_decision(env, 16))
+        total += world.reward
+    assert (total > 0).any() and torch.isfinite(total).all()          # new texels get seen
+    assert (world.obs.d >= 0).all() and (world.obs.d <= 1).all()
+    assert env.state(0).seen.dtype == torch.bool or env.state(0).seen.dtype == torch.int64
+
+
+def test_deathmatch_env():
+    from megastep_amd.demo import Deathmatch
+    from megastep_amd import cubicasa
+    torch.manual_seed(0); np.random.seed(0)
+    env = Deathmatch(32, 4, geometries=cubicasa.sample(8, n_unique=16))
+    assert env.n_envs == 32 and env.core.n_envs == 8 and env.core.res == 512
+    world = env.reset()
+    assert world.obs.rgb.shape == (32, 1, 3, 1, 128) and world.obs.d.shape == (32, 1, 1, 1, 128)
+    assert world.obs.imu.shape == (32, 1, 3) and world.obs.health.shape == (32, 1, 1)
+    assert world.reset.shape == (32,) and world.reward.shape == (32,)
+    for _ in range(10):
+        world = env.step(_decision(env, 32))
+    assert torch.isfinite(world.obs.rgb).all() and torch.isfinite(world.obs.d).all()
+    assert (env._health <= 1).all()
+    assert env.state(0).matchings.shape == (4, 4)
+
+
+def test_observation_modules_against_a_torch_restatement():
+    """Depth/RGB on a real render equal their definition (modules.py:170-184,211-224) applied to the raw outputs."""
+    from megastep_amd import core, cubicasa, modules, scene, cuda
+    np.random.seed(0)
+    gs = cubicasa.sample(4, n_unique=16)
+    c = core.Core(scene.scenery(gs, 2, random=np.random.RandomState(0)), res=64, fov=100)
+    modules.RandomSpawns(gs, c)(c.agent_full(True))
+    r = modules.render(c)
+    assert r.screen.shape == (4, 2, 3, 1, 64) and r.indices.shape == (4, 2, 1, 64)
+    d = modules.Depth(c, subsample=4, max_depth=10)(r)
+    want = 1 - ((r.distances - c.agent_radius)/10).clamp(0, 1)
+    torch.testing.assert_close(d, want.view(4, 2, 1, 16, 4).mean(-1).unsqueeze(3))
+    rgb = modules.RGB(c, subsample=4)(r)
+    torch.testing.assert_close(rgb, r.screen.view(4, 2, 3, 1, 16, 4).mean(-1))
+    raw = cuda.render(c.scenery, c.agents)
+    torch.testing.assert_close(raw.screen.permute(0, 1, 3, 2).unsqueeze(3), r.screen)
