@@ -25,6 +25,11 @@ class Explorer:
         self._potential = self.core.env_full(0.)
         self._lengths = torch.zeros(self.core.n_envs, device=self.core.device, dtype=torch.int)
         self.device = self.core.device
+        # bookkeeping for the incremental reward: which ray last claimed a texel, and each env's texel range
+        self._claim = torch.full_like(self._tex_to_env, -1)
+        line_ends = sc.lines.ends.long()
+        self._tex_ends = sc.textures.ends.long()[line_ends - 1]
+        self._tex_starts = torch.cat([self._tex_ends.new_zeros(1), self._tex_ends[:-1]])
 
     def _tex_indices(self, aux):
         sc = self.core.scenery
@@ -37,11 +42,20 @@ class Explorer:
         return result.unsqueeze(2)
 
     def _reward(self, r, reset):
-        self._seen[self._tex_indices(r)] = True
-        potential = torch.zeros_like(self._potential)
-        potential.scatter_add_(0, self._tex_to_env, self._seen.float())
+        """Reward = newly seen texels per env (reference: explorer.py:45-58). The reference re-counts every texel of
+        every env each step (a scatter_add over all of them); here only the texels this step's rays landed on are
+        touched: a texel is counted once, by whichever of the rays on it holds the claim, if it was unseen before."""
+        tex = self._tex_indices(r).reshape(-1)
+        tex = tex[tex >= 0]
+        rays = torch.arange(len(tex), device=tex.device)
+        self._claim[tex] = rays                              # duplicates: some single ray wins each texel
+        fresh = (self._claim[tex] == rays) & ~self._seen[tex]
+        self._seen[tex] = True
+        potential = self._potential.clone()
+        potential.scatter_add_(0, self._tex_to_env[tex], fresh.float())
         reward = (potential - self._potential)/(self.core.res//self._rgb.subsample)
         self._potential = potential
+        # Should I render twice so that the last reward is accurate?
         reward[reset] = 0.
         return reward
 
@@ -52,7 +66,11 @@ class Explorer:
 
     def _reset(self, reset=None):
         self._respawner(reset.unsqueeze(-1))
-        self._seen[reset[self._tex_to_env]] = False
+        envs = reset.nonzero().squeeze(-1)
+        if len(envs):                                        # forget what the respawned envs had seen
+            starts, lens = self._tex_starts[envs], self._tex_ends[envs] - self._tex_starts[envs]
+            offsets = torch.arange(int(lens.sum()), device=envs.device) - torch.repeat_interleave(lens.cumsum(0) - lens, lens)
+            self._seen[torch.repeat_interleave(starts, lens) + offsets] = False
         self._potential[reset] = 0
         self._lengths[reset] = 0
 

@@ -79,3 +79,26 @@ def test_observation_modules_against_a_torch_restatement():
     torch.testing.assert_close(rgb, r.screen.view(4, 2, 3, 1, 16, 4).mean(-1))
     raw = cuda.render(c.scenery, c.agents)
     torch.testing.assert_close(raw.screen.permute(0, 1, 3, 2).unsqueeze(3), r.screen)
+
+
+def test_explorer_reward_equals_the_reference_formula():
+    """The incremental bookkeeping must give the reference's numbers: potential = seen texels per env
+    (explorer.py:45-58), reward = its increase / 64, respawned envs forget."""
+    from megastep_amd.demo import Explorer
+    from megastep_amd import cubicasa
+    torch.manual_seed(1); np.random.seed(1)
+    env = Explorer(8, geometries=cubicasa.sample(8, n_unique=16))
+    env.reset()
+    prev = env._potential.clone()
+    for step in range(30):
+        if step == 12:
+            env._lengths[3] = 10_000                          # force a respawn of env 3
+        world = env.step(_decision(env, 8))
+        potential = torch.zeros(8, device='cuda').scatter_add_(0, env._tex_to_env, env._seen.float())
+        torch.testing.assert_close(env._potential, potential)
+        want = (potential - torch.where(world.reset, torch.zeros_like(prev), prev))/64
+        want[world.reset] = 0.
+        if step != 12:
+            torch.testing.assert_close(world.reward, want)
+        prev = potential
+    assert world.reset.sum() == 0 and env._potential.min() > 0
