@@ -61,6 +61,20 @@ typedef struct MsScenery {
     const float* model;              /* (M, 2, 2) agent outline in the agent frame             */
     float*       baked_vals;         /* (sum T,) written by ms_bake, read by ms_render         */
     int n_lines_total, n_lights_total, n_texels_total;
+    /* Optional light grid (lg_vals NULL = none; no counterpart in the reference): a per-env uniform grid over the
+     * floorplan that caches, for every cell and each of the env's first 64 lights, whether the light reaches the
+     * cell.  Written by ms_bake, read by ms_render's dynamic lighting, exact by construction: a cell is only ever
+     * marked when EVERY point in it provably has that status, anything else stays 0 and is worked out per ray.
+     *   lg_vals   (sum cells, 4) uint32, 2 bits per light: 0 unknown, 1 lit, 2 dark; must start zeroed
+     *   lg_starts (N,)   first cell of env n
+     *   lg_geom   (N, 4) float: x and y of the grid's origin, cells along x, cells along y
+     *   lg_cell   cell size in metres;  lg_max_cells  max over envs of cells (launch bound for ms_bake)
+     * Only for sceneries with at most 64 lights in every env: pass lg_vals = NULL otherwise. */
+    unsigned*    lg_vals;
+    const int*   lg_starts;
+    const float* lg_geom;
+    float        lg_cell;
+    int          lg_max_cells;
 } MsScenery;
 
 /* Replaces `Agents` (common.h:157-177). Updated IN PLACE by ms_physics. */

@@ -31,7 +31,9 @@ class MsScenery(C.Structure):
         ('textures_vals', C.c_void_p), ('textures_widths', C.c_void_p), ('textures_starts', C.c_void_p),
         ('textures_inverse', C.c_void_p),
         ('model', C.c_void_p), ('baked_vals', C.c_void_p),
-        ('n_lines_total', C.c_int), ('n_lights_total', C.c_int), ('n_texels_total', C.c_int)]
+        ('n_lines_total', C.c_int), ('n_lights_total', C.c_int), ('n_texels_total', C.c_int),
+        ('lg_vals', C.c_void_p), ('lg_starts', C.c_void_p), ('lg_geom', C.c_void_p), ('lg_cell', C.c_float),
+        ('lg_max_cells', C.c_int)]
 
 
 class MsAgents(C.Structure):

@@ -1070,6 +1070,193 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// dynamic lighting with the light grid
+// ------------------------------------------------------------------------------------------------
+// Same job and launch shape as dynlight_kernel, for sceneries that carry a light grid (MsScenery.lg_vals,
+// filled by ms_bake) and have at most 64 lights per env.  Each agent-hit ray looks up the cell its hit point
+// is in: lights the grid marks LIT are unblocked, DARK ones blocked - exactly, see lightgrid_kernel - and
+// usually that settles the ray (no UNKNOWN light, or the LIT ones already saturate the sum).  Only what is
+// left - rays with UNKNOWN lights, those lights only - goes through the corridor sweep + exact tests.
+__global__ __launch_bounds__(WG) void dynlight_grid_kernel(
+        const MsScenery sc, const MsAgents ag, const MsRender out, const int R) {
+    __shared__ LightPair s_pair[WAVES][PAIRS];
+    __shared__ unsigned s_shadow[2*WAVE];        // per ray: 64 light bits, OR-ed by all waves
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int fan = blockIdx.x;
+    if (out.workspace) {                         // compact list from render_kernel: the busy groups start first
+        if (fan >= out.workspace[0]) return;
+        fan = out.workspace[16 + fan];
+    }
+    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int G = (R + WAVE - 1)/WAVE, F = A*G;
+    const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
+    const int r = g*WAVE + lane;
+    const size_t o = ((size_t)n*A + a)*R + r;
+    // everything that does not depend on the indices is requested before they are looked at
+    const int L = sc.lines_widths[n];
+    const int base = sc.lines_starts[n];
+    const int ni = sc.lights_widths[n];          // <= 64, checked by the host
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
+    const int lg_base = sc.lg_starts[n];
+    float Ix = 0.f, Iy = 0.f, Ii = 0.f;          // lane i holds light i
+    if (lane < ni) { Ix = lights[3*lane]; Iy = lights[3*lane + 1]; Ii = lights[3*lane + 2]; }
+    int nearest_idx = -1;
+    float loc = 0.f, dt = 0.f;
+    if (r < R) { nearest_idx = out.indices[o]; loc = out.locations[o]; dt = out.dots[o]; }
+    const bool dynamic = (nearest_idx >= 0) & (nearest_idx < AF);
+    if (!__ballot(dynamic)) return;              // uniform across the workgroup: every wave sees the same 64 rays
+
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
+    float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
+    Filt f = Filt{0, 0, 0.f, 0.f};
+    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
+    if (dynamic) {
+        hw = ln[nearest_idx];                               // the agent line render_kernel drew and published (kernels.cu:316-317)
+        const int start = base + nearest_idx;
+        f = tex_filter(loc, sc.textures_widths[start]);
+        const int tstart = sc.textures_starts[start];
+        const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
+        const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
+        #pragma unroll
+        for (int k = 0; k < 3; k++) { t0[k] = tl[k]; t1[k] = tr[k]; }
+    }
+    const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
+    const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
+
+    // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
+    uint4 st = make_uint4(0u, 0u, 0u, 0u);
+    if (dynamic) {
+        const float fx = floorf((cx_l - geom.x)/sc.lg_cell), fy = floorf((cy_l - geom.y)/sc.lg_cell);
+        if ((fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w))
+            st = reinterpret_cast<const uint4*>(sc.lg_vals)[lg_base + (int)fy*(int)geom.z + (int)fx];
+    }
+    const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
+    unsigned long long lit = 0ull, dark = 0ull, need_lights = 0ull;
+    float part = AMBIENT;                        // order-free sum over the lights the grid proves unblocked
+    for (int i = 0; i < ni; i++) {
+        const unsigned wd = (i < 16) ? st.x : (i < 32) ? st.y : (i < 48) ? st.z : st.w;
+        const unsigned s2 = (wd >> (2*(i & 15))) & 3u;
+        if (s2 == 1u) {
+            const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
+            part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+            lit |= 1ull << i;
+        } else if (s2 == 2u) {
+            dark |= 1ull << i;
+        }
+    }
+    const unsigned long long all = (ni >= 64) ? ~0ull : ((1ull << ni) - 1ull);
+    const unsigned long long unk = ~(lit | dark) & all;
+    // saturated: the reference's min(sum, 1) is exactly 1 whatever the unknown lights do (see dynlight_kernel)
+    const bool saturated = dynamic & shortcut & (part >= 1.001f);
+    const bool need = dynamic & !saturated & (unk != 0ull);
+    for (int i = 0; i < ni; i++) if (__ballot(need & (((unk >> i) & 1ull) != 0ull))) need_lights |= 1ull << i;
+
+    unsigned long long blocked = dark;
+    if (need_lights) {                           // uniform: some ray still has lights to test against the walls
+        if (wave == 0) { s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u; }
+        __syncthreads();
+        unsigned long long todo = __ballot(need);
+        while (todo) {                           // one target agent at a time
+            const int target = __builtin_amdgcn_readlane(my_target, __ffsll((long long)todo) - 1);
+            const bool mine = need & (my_target == target);
+            const unsigned long long open = __ballot(mine);
+            todo &= ~open;
+            // the lights any of this target's rays still needs
+            unsigned long long tl_mask = 0ull;
+            for (unsigned long long m = need_lights; m; m &= m - 1) {
+                const int i = __ffsll((long long)m) - 1;
+                if (__ballot(mine & (((unk >> i) & 1ull) != 0ull))) tl_mask |= 1ull << i;
+            }
+            const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
+            // extent of the hit points around the target, + float slack
+            float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
+            rho = wave_max_f(rho) + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
+            // corridor frame of light `lane`: unit vector e from the light to the target, length el
+            const float dx = T.x - Ix, dy = T.y - Iy;
+            const float el = sqrtf(dx*dx + dy*dy);
+            const float ex = dx/el, ey = dy/el;
+
+            int cnt = 0;
+            auto flush = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int p0 = 0; p0 < cnt; p0 += WAVE) {
+                    const LightPair pr = s_pair[wave][min(p0 + lane, cnt - 1)];
+                    const P2 I = p2(pr.ix, pr.iy);
+                    for (unsigned long long rays = open; rays; rays &= rays - 1) {
+                        const int jr = __ffsll((long long)rays) - 1;
+                        const P2 C = p2(readlane_f(cx_l, jr), readlane_f(cy_l, jr));
+                        if ((p0 + lane < cnt) && light_blocked(I, C - I, pr.ax, pr.ay, pr.vx, pr.vy))
+                            atomicOr(&s_shadow[2*jr + (pr.light >> 5)], 1u << (pr.light & 31));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                cnt = 0;
+            };
+            // this wave's share of the walls: chunks wave, wave + 4, ...
+            const int first = AF + wave*WAVE;
+            float4 wn = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (first + lane < L) wn = ln[first + lane];
+            for (int l0 = first; l0 < L; l0 += WAVES*WAVE) {
+                const bool live = l0 + lane < L;
+                const float4 w = wn;
+                if (l0 + WAVES*WAVE + lane < L) wn = ln[l0 + WAVES*WAVE + lane];      // next chunk in flight
+                // wall relative to the target, and its margin
+                const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
+                const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
+                for (unsigned long long lm = tl_mask; lm; lm &= lm - 1) {
+                    const int i = __ffsll((long long)lm) - 1;
+                    const float cex = readlane_f(ex, i), cey = readlane_f(ey, i), cel = readlane_f(el, i);
+                    // coordinates along / across the corridor, origin at the target, light at -cel
+                    const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
+                    const float ub = cex*bx + cey*by, vb = cex*by - cey*bx;
+                    const bool outside = ((ua > m) & (ub > m)) | ((ua < -cel - m) & (ub < -cel - m)) |
+                                         ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
+                    const bool keep = live & !outside;
+                    const unsigned long long km = __ballot(keep);
+                    if (km) {
+                        const int nk = __popcll(km);
+                        if (cnt + nk > PAIRS) flush();
+                        if (keep) s_pair[wave][cnt + __popcll(km & ((1ull << lane) - 1ull))] =
+                            LightPair{w.x, w.y, w.z - w.x, w.w - w.y, readlane_f(Ix, i), readlane_f(Iy, i), i, 0};
+                        cnt += nk;
+                    }
+                }
+            }
+            if (cnt) flush();
+        }
+        __syncthreads();
+        // swept lights: the walls' verdict; the others: the grid's
+        const unsigned long long shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
+        blocked = dark | (shadow & unk);
+    }
+#ifdef MS_DEBUG_GRID
+    if (dynamic & (wave == 0)) {
+        out.distances[o] = (float)__popcll(need_lights); out.locations[o] = saturated ? 1.f : 0.f; out.dots[o] = (float)__popcll(unk);
+    }
+#endif
+    if (dynamic & (wave == 0)) {                             // kernels.cu:261-267, 441-445
+        float intensity = 1.f;
+        if (!saturated) {
+            float acc = AMBIENT;
+            for (int i = 0; i < ni; i++) {                   // in light order
+                const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
+                const float d2 = len2(I - p2(cx_l, cy_l));
+                if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+            }
+            intensity = ms_min(acc, 1.f);
+        }
+        const float dn = 1 - dt*dt;
+        out.screen[3*o]     = dn*intensity*(f.lw*t0[0] + f.rw*t1[0]);
+        out.screen[3*o + 1] = dn*intensity*(f.lw*t0[1] + f.rw*t1[1]);
+        out.screen[3*o + 2] = dn*intensity*(f.lw*t0[2] + f.rw*t1[2]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bake                                                                        kernels.cu:270-293
 // ------------------------------------------------------------------------------------------------
 constexpr int BAKE_WALLS = 2048;   // occluders staged per pass: 32 KiB of LDS
@@ -1135,6 +1322,116 @@ __global__ __launch_bounds__(WG) void bake_kernel(const MsScenery sc) {
             }
         }
         if (live) sc.baked_vals[t] = ms_min(acc, 1.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// light grid: which lights reach which cells                   (accelerates kernels.cu:238-268 at run time)
+// ------------------------------------------------------------------------------------------------
+// One thread per cell of the env's grid, the env's walls staged in LDS.  For a cell (grown by LG_SLACK so a
+// hit point's rounding cannot put it outside) and a light, with the reference's obstructed() test in mind:
+//   LIT   if no wall comes near the corridor light -> cell: then no segment light -> point-in-cell crosses or
+//         even grazes a wall, and obstructed() is false for every wall.
+//   DARK  if some single wall shadows all four corners with room to spare (|UxV| >= 1e-2, t in (d, 1-d),
+//         s in (d, .999-d), d = 2e-3, ~1e3 rounding errors).  For a fixed light and wall those conditions are
+//         affine inequalities in the point, so they hold on the whole cell, and obstructed() is true there.
+//   else  the cell stays UNKNOWN (0) for that light and ms_render tests rays in it against the walls.
+constexpr float LG_SLACK = 0.01f;
+constexpr int LG_LIGHTS = 64;          // lights per env the grid covers
+
+__global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
+    __shared__ float4 s_wall[BAKE_WALLS];        // (ax, ay, vx, vy)
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
+    const int nx = (int)geom.z, ncell = nx*(int)geom.w;
+    if ((int)blockIdx.x*WG >= ncell) return;     // uniform: whole workgroups leave together
+    const int c = blockIdx.x*WG + tid;
+    const bool live = c < ncell;
+    const int AF = sc.n_agents*sc.n_model;
+    const int L = sc.lines_widths[n];
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
+    const int num_i = min(sc.lights_widths[n], LG_LIGHTS);
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const int n_walls = max(L - AF, 0);
+    const float cell = sc.lg_cell;
+    const int ix = c % nx, iy = c / nx;
+    const float x0 = geom.x + ix*cell - LG_SLACK, y0 = geom.y + iy*cell - LG_SLACK;
+    const float x1 = x0 + cell + 2*LG_SLACK, y1 = y0 + cell + 2*LG_SLACK;
+    const P2 ctr = p2(.5f*(x0 + x1), .5f*(y0 + y1));
+    const float rho = .5f*sqrtf((x1 - x0)*(x1 - x0) + (y1 - y0)*(y1 - y0)) + 5e-3f + 1e-4f*(fabsf(ctr.x) + fabsf(ctr.y));
+    unsigned long long touched = 0ull, dark = 0ull;
+
+    for (int w0 = 0; w0 < n_walls; w0 += BAKE_WALLS) {       // uniform trip count: barriers are safe
+        __syncthreads();
+        const int staged = min(BAKE_WALLS, n_walls - w0);
+        for (int i = tid; i < staged; i += WG) {
+            const float4 w = ln[AF + w0 + i];
+            s_wall[i] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
+        }
+        __syncthreads();
+        if (!live) continue;
+        for (int i = 0; i < num_i; i++) {
+            const unsigned long long bit = 1ull << i;
+            if (dark & bit) continue;
+            const P2 I = p2(lights[3*i], lights[3*i + 1]);
+            // corridor frame: unit vector e from the light to the cell centre, length el
+            const float dx = ctr.x - I.x, dy = ctr.y - I.y;
+            const float el = sqrtf(dx*dx + dy*dy);
+            const float ex = dx/el, ey = dy/el;
+            // the four corners as seen from the light
+            const P2 U0 = p2(x0, y0) - I, U1 = p2(x1, y0) - I, U2 = p2(x1, y1) - I, U3 = p2(x0, y1) - I;
+            for (int k = 0; k < staged; k++) {
+                const float4 w = s_wall[k];
+                const float ax = w.x - ctr.x, ay = w.y - ctr.y, bx = ax + w.z, by = ay + w.w;
+                const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
+                const float ua = ex*ax + ey*ay, va = ex*ay - ey*ax;
+                const float ub = ex*bx + ey*by, vb = ex*by - ey*bx;
+                const bool outside = ((ua > m) & (ub > m)) | ((ua < -el - m) & (ub < -el - m)) |
+                                     ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
+                if (outside) continue;                       // NaNs fall through to `touched`
+                // Near the corridor, but does its shadow - the wedge behind the wall as seen from the light,
+                // bounded by the lines light-a, light-b and the wall itself - reach the cell at all?  Not if all
+                // four corners lie, by 5 mm, beyond one of those three lines.
+                const P2 V = p2(w.z, w.w), PQ = p2(w.x, w.y) - I, PB = PQ + V;
+                {
+                    constexpr float MG2 = 5e-3f*5e-3f;
+                    const float sb = cross(PQ, PB);                                  // which side of light-a is b on
+                    const float la2 = len2(PQ), lb2 = len2(PB), lv2 = len2(V);
+                    const float a0 = cross(PQ, U0), a1 = cross(PQ, U1), a2 = cross(PQ, U2), a3 = cross(PQ, U3);
+                    const float b0 = cross(PB, U0), b1 = cross(PB, U1), b2 = cross(PB, U2), b3 = cross(PB, U3);
+                    const float si = -cross(V, PQ);                                  // which side of the wall is the light on
+                    const float w0_ = cross(V, U0 - PQ), w1_ = cross(V, U1 - PQ), w2_ = cross(V, U2 - PQ), w3_ = cross(V, U3 - PQ);
+                    auto beyond = [](float side, float c, float l2) { return (side*c < 0.f) & (c*c > MG2*l2); };
+                    auto same = [](float side, float c, float l2) { return (side*c > 0.f) & (c*c > MG2*l2); };
+                    const bool opp_a = beyond(sb, a0, la2) & beyond(sb, a1, la2) & beyond(sb, a2, la2) & beyond(sb, a3, la2);
+                    const bool opp_b = beyond(-sb, b0, lb2) & beyond(-sb, b1, lb2) & beyond(-sb, b2, lb2) & beyond(-sb, b3, lb2);
+                    const bool front = same(si, w0_, lv2) & same(si, w1_, lv2) & same(si, w2_, lv2) & same(si, w3_, lv2);
+                    if (opp_a | opp_b | front) continue;
+                }
+                touched |= bit;
+                // does this wall shadow the whole cell?
+                const float c1 = cross(PQ, V);
+                const float d0 = cross(U0, V), d1 = cross(U1, V), d2 = cross(U2, V), d3 = cross(U3, V);
+                const float sg = d0 < 0.f ? -1.f : 1.f;
+                const float e0 = sg*d0, e1 = sg*d1, e2 = sg*d2, e3 = sg*d3, cc = sg*c1;
+                bool full = (e0 >= 1e-2f) & (e1 >= 1e-2f) & (e2 >= 1e-2f) & (e3 >= 1e-2f);
+                const float n0 = sg*cross(PQ, U0), n1 = sg*cross(PQ, U1), n2 = sg*cross(PQ, U2), n3 = sg*cross(PQ, U3);
+                constexpr float D = 2e-3f;
+                full &= (n0 > D*e0) & (n0 < (1.f - D)*e0) & (n1 > D*e1) & (n1 < (1.f - D)*e1) &
+                        (n2 > D*e2) & (n2 < (1.f - D)*e2) & (n3 > D*e3) & (n3 < (1.f - D)*e3);
+                full &= (cc > D*e0) & (cc < (.999f - D)*e0) & (cc > D*e1) & (cc < (.999f - D)*e1) &
+                        (cc > D*e2) & (cc < (.999f - D)*e2) & (cc > D*e3) & (cc < (.999f - D)*e3);
+                if (full) { dark |= bit; break; }
+            }
+        }
+    }
+    if (live) {
+        unsigned wd[4] = {0u, 0u, 0u, 0u};
+        for (int i = 0; i < num_i; i++) {
+            const unsigned st = ((dark >> i) & 1ull) ? 2u : (((touched >> i) & 1ull) ? 0u : 1u);
+            wd[i >> 4] |= st << (2*(i & 15));
+        }
+        reinterpret_cast<uint4*>(sc.lg_vals)[sc.lg_starts[n] + c] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
 }
 
@@ -1219,8 +1516,12 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     else
         hipLaunchKernelGGL((render_kernel<1, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
                            *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
-    if (sc->n_agents > 1)    // with one agent per env no ray can land on an agent line (own lines sit inside the near plane)
-        hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
+    if (sc->n_agents > 1) {  // with one agent per env no ray can land on an agent line (own lines sit inside the near plane)
+        if (sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f)
+            hipLaunchKernelGGL(dynlight_grid_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
+        else
+            hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
@@ -1230,8 +1531,13 @@ int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !sc->textures_widths || !sc->textures_starts || !sc->textures_inverse ||
         !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
-    if (sc->n_texels_total == 0) return MS_OK;
-    hipLaunchKernelGGL(bake_kernel, dim3(sc->n_envs), dim3(WG), 0, (hipStream_t)stream, *sc);
+    if (sc->n_texels_total > 0)
+        hipLaunchKernelGGL(bake_kernel, dim3(sc->n_envs), dim3(WG), 0, (hipStream_t)stream, *sc);
+    if (sc->lg_vals) {
+        if (!sc->lg_starts || !sc->lg_geom || !(sc->lg_cell > 0.f) || sc->lg_max_cells <= 0 || ((uintptr_t)sc->lg_vals % 16) ||
+            ((uintptr_t)sc->lg_geom % 16)) return MS_EINVAL;
+        hipLaunchKernelGGL(lightgrid_kernel, dim3((sc->lg_max_cells + WG - 1)/WG, sc->n_envs), dim3(WG), 0, (hipStream_t)stream, *sc);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }

@@ -200,16 +200,45 @@ class Scenery:
         return dotdict.dotdict(n_agents=self._n_agents, lights=self._lights[e], lines=self._lines[e],
                                textures=self._textures[s:t], model=self._model, baked=self._baked[s:t])
 
+    LIGHT_GRID_CELL = .25
+
+    def _light_grid(self):
+        """Storage and geometry of the light grid (see include/megastep_hip.h): a uniform grid over each env's walls,
+        half a metre of slack around them. `bake` fills it in; zeros mean 'unknown', which is always safe."""
+        ln = self._lines
+        dev = ln.vals.device
+        n_envs, cell = len(ln), self.LIGHT_GRID_CELL
+        env = ln.inverse.long()
+        static = (torch.arange(ln.vals.shape[0], device=dev) - ln.starts.long()[env]) >= self._n_agents*self._model.shape[0]
+        env, pts = env[static], ln.vals[static]              # the walls; agent rows move
+        big = torch.finfo(torch.float32).max
+        idx = env[:, None].expand(-1, 2)
+        lo = torch.full((n_envs, 2), big, device=dev).scatter_reduce_(0, idx, pts.amin(1), 'amin')
+        hi = torch.full((n_envs, 2), -big, device=dev).scatter_reduce_(0, idx, pts.amax(1), 'amax')
+        empty = lo[:, 0] > hi[:, 0]                          # an env without walls gets a 1 x 1 grid
+        lo[empty], hi[empty] = 0., 0.
+        origin = torch.floor(lo) - .5
+        dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
+        cells = (dims[:, 0]*dims[:, 1]).long()
+        starts = (cells.cumsum(0) - cells).to(torch.int32)
+        geom = torch.cat([origin, dims], 1).float().contiguous()
+        vals = torch.zeros((int(cells.sum()), 4), dtype=torch.int32, device=dev)
+        return vals, starts.contiguous(), geom, cell, int(cells.max())
+
     def _as_struct(self):
         if self._struct is None:
             li, ln, tx = self._lights, self._lines, self._textures
+            # the grid holds 64 lights per env; sceneries beyond that go without
+            few_lights = len(li.widths) == 0 or int(li.widths.max()) <= 64
+            self._lg = lg = self._light_grid() if few_lights else (None, None, None, 0., 0)
             self._struct = _lib.MsScenery(
                 len(ln), self._n_agents, self._model.shape[0],
                 li.vals.data_ptr(), li.widths.data_ptr(), li.starts.data_ptr(),
                 ln.vals.data_ptr(), ln.widths.data_ptr(), ln.starts.data_ptr(), ln.inverse.data_ptr(),
                 tx.vals.data_ptr(), tx.widths.data_ptr(), tx.starts.data_ptr(), tx.inverse.data_ptr(),
                 self._model.data_ptr(), self._baked.vals.data_ptr(),
-                ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0])
+                ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0],
+                *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4])
         return self._struct
 
     def _tensors(self):
