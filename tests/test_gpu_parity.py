@@ -171,3 +171,74 @@ def test_full_benchmark_size_matches_oracle():
         prog_ref, agents_ref = ref.physics()
         util.assert_physics_matches(c, p, prog_ref, agents_ref)
         util.assert_render_matches(c, r, ref.render())
+
+
+def _obstructed(I, C, walls):
+    """obstructed() of kernels.cu:253-257 in float32 numpy: (n_points, n_walls) booleans."""
+    f = np.float32
+    a, v = walls[None, :, 0], (walls[:, 1] - walls[:, 0])[None]
+    U = (C - I)[:, None]
+    d = U[..., 0]*v[..., 1] - U[..., 1]*v[..., 0]
+    PQ = a - I
+    with np.errstate(divide='ignore', invalid='ignore'):
+        s = (PQ[..., 0]*v[..., 1] - PQ[..., 1]*v[..., 0])/d
+        t = (PQ[..., 0]*U[..., 1] - PQ[..., 1]*U[..., 0])/d
+    return (np.abs(d) >= f(1e-3)) & (t > 0) & (t < 1) & (s > 0) & (s < f(.999))
+
+
+def test_light_grid_verdicts_hold_for_every_sampled_point():
+    """The grid may say LIT / DARK only where it is true for EVERY point of the cell: sample points in cells and
+    evaluate the reference's obstructed() test against all walls."""
+    c, _ = _world(6, 2, 64, 130, seed=3)
+    sc = c.scenery
+    vals, starts, geom, cell, _ = (t.cpu().numpy() if torch.is_tensor(t) else t for t in sc._lg)
+    rng = np.random.RandomState(0)
+    n_lit = n_dark = 0
+    for e in range(6):
+        walls = sc.lines[e].cpu().numpy()[16:]
+        lights = sc.lights[e].cpu().numpy()
+        ox, oy, nx, ny = geom[e]
+        nx, ny = int(nx), int(ny)
+        cells = rng.choice(nx*ny, 150, replace=False)
+        for cidx in cells:
+            ix, iy = cidx % nx, cidx // nx
+            pts = (np.array([ox + ix*cell, oy + iy*cell]) + rng.uniform(0, cell, (24, 2))).astype(np.float32)
+            pts = np.concatenate([pts, np.array([[ox + ix*cell, oy + iy*cell], [ox + (ix + 1)*cell, oy + (iy + 1)*cell]], np.float32)])
+            words = vals[starts[e] + cidx].astype(np.uint32)
+            for i, light in enumerate(lights[:64]):
+                state = (words[i >> 4] >> np.uint32(2*(i & 15))) & 3
+                if state == 0:
+                    continue
+                blocked = _obstructed(light[:2].astype(np.float32), pts, walls).any(1)
+                if state == 1:
+                    assert not blocked.any(), (e, cidx, i, 'LIT cell has a shadowed point')
+                    n_lit += 1
+                else:
+                    assert blocked.all(), (e, cidx, i, 'DARK cell has a lit point')
+                    n_dark += 1
+    assert n_lit > 50 and n_dark > 1000, (n_lit, n_dark)
+
+
+def test_crowded_rooms_exercise_dynamic_lighting():
+    """Four agents packed into one room of each plan, looking at each other: many rays land on agents, under every
+    mix of lit / shadowed / partly shadowed lights."""
+    from megastep_amd import cuda
+    c, geometries = _world(24, 4, 64, 130, seed=5)
+    rng = np.random.RandomState(2)
+    pos = np.zeros((24, 4, 2), np.float32)
+    ang = np.zeros((24, 4), np.float32)
+    from megastep_amd import geometry
+    for e, g in enumerate(geometries):
+        room = rng.randint(1, g['masks'].max() + 1)
+        free = np.stack((g['masks'] == room).nonzero(), -1)
+        centre = geometry.centers(free[rng.randint(len(free))], g['masks'].shape, g['res'])
+        pos[e] = centre + rng.uniform(-.45, .45, (4, 2))
+        ang[e] = np.degrees(np.arctan2(*(pos[e].mean(0) - pos[e]).T[::-1])) + rng.uniform(-20, 20, 4)
+    c.agents.positions[:] = torch.as_tensor(pos, device=c.device)
+    c.agents.angles[:] = torch.as_tensor(ang, device=c.device)
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c); ref.pull_agents(c)
+    r = cuda.render(c.scenery, c.agents)
+    idx = r.indices.cpu().numpy()
+    assert ((idx >= 0) & (idx < 32)).mean() > .05, 'expected plenty of rays on agents'
+    util.assert_render_matches(c, r, ref.render())
