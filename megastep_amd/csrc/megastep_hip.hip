@@ -392,11 +392,6 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
 
     const int fan = lb*RW + wave;
     if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
-#ifdef MS_DEBUG_RTIME
-    const long long rt_start = __builtin_readcyclecounter();
-    const unsigned long long rt_real0 = __builtin_amdgcn_s_memrealtime();
-    long long rt_scan = 0; int rt_amb = 0, rt_iters = 0, rt_pairs = 0;
-#endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
     const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
@@ -448,9 +443,6 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
 
     float nearest_s = INFINITY;
     int nearest_idx = -1;
-#ifdef MS_DEBUG_COUNT
-    int dbg_iters = 0, dbg_mine = 0, dbg_hits = 0, dbg_inc = 0;
-#endif
 
     if constexpr (IMPL == 1) {
         // ------------------------------------------------------------------------------------------
@@ -477,12 +469,7 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
         s_second[wave][lane] = ~0ull;
         s_third[wave][lane] = ~0ull;
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
-#ifdef MS_ABL_NOCHUNKS
-        const int L_ = 0;
-#else
-        const int L_ = L;
-#endif
-        for (int c0 = 0; c0 < L_; c0 += WAVE) {
+        for (int c0 = 0; c0 < L; c0 += WAVE) {
             const int l = c0 + lane;
             int lo = 0, len = 0;
             if (l < L) {
@@ -523,20 +510,10 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
             }
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
-#ifdef MS_ABL_NOPAIRS
-            const int P = 0;
-#else
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
-#endif
             s_info[wave][lane] = (first << 6) | (lo & 63);
             int carry = -1;
-#ifdef MS_DEBUG_RTIME
-            rt_pairs += P;
-#endif
             for (int p0 = 0; p0 < P; p0 += WAVE) {
-#ifdef MS_DEBUG_RTIME
-                rt_iters++;
-#endif
                 // which line owns pair p0 + lane: lines mark their first pair, a max-scan spreads the marks
                 s_mark[wave][lane] = -1;
                 if ((len > 0) & (first >= p0) & (first < p0 + WAVE)) s_mark[wave][first - p0] = lane;
@@ -605,9 +582,6 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
         // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
         // line order into the ray's own state, which lives in the ray's lane.
         const unsigned long long amb = __ballot(ambiguous);
-#ifdef MS_DEBUG_RTIME
-        rt_scan = __builtin_readcyclecounter(); rt_amb = __popcll(amb);
-#endif
         if (__popcll(amb) > 6) {
             // many such rays (a view full of coincident walls): cheaper to let every one of them walk all
             // the lines itself, lines broadcast from LDS
@@ -735,13 +709,7 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
             // ---- pass 2: lane = ray.  Every lane walks ITS group's lines in index order, so the fold is
             // the reference's sequential one (kernels.cu:352-377) minus lines that provably cannot hit.
             // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked).
-    #ifdef MS_DEBUG_COUNT
-            dbg_mine += __popcll(my_mask); dbg_inc += __popcll(__ballot(inc));
-    #endif
             while (__ballot(my_mask != 0ull)) {
-    #ifdef MS_DEBUG_COUNT
-                dbg_iters++;
-    #endif
                 const bool active = my_mask != 0ull;
                 const int j = active ? __ffsll((long long)my_mask) - 1 : 0;
                 my_mask &= my_mask - 1ull;
@@ -751,9 +719,6 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
                 const float ad = fabsf(d);
                 const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
                 const bool hit = active & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
-    #ifdef MS_DEBUG_COUNT
-                dbg_hits += hit;
-    #endif
                 if (hit) {
                     const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;      // q.s = cross(PQ, V)/UxV
                     if ((near < sv) & (sv < nearest_s - 1.e-4f)) {
@@ -786,24 +751,6 @@ __global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
         out.locations[o] = loc;
         out.dots[o] = dt;
         out.distances[o] = nearest_s*rlen;
-#ifdef MS_DEBUG_RTIME
-        if constexpr (IMPL == 1) {
-            const long long rt_end = __builtin_readcyclecounter();
-#ifdef MS_DEBUG_TIMELINE
-            out.locations[o] = (float)(rt_real0 & 0xffffff); out.dots[o] = (float)(__builtin_amdgcn_s_memrealtime() & 0xffffff);
-            unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            out.distances[o] = (float)(((xcc & 0xf) << 12) | ((hwid >> 8) & 0xf) << 4 | ((hwid >> 4) & 0x3)); out.indices[o] = rt_iters*100000 + rt_pairs;
-#else
-            out.locations[o] = (float)(rt_scan - rt_start); out.dots[o] = (float)(rt_end - rt_scan);
-            out.distances[o] = (float)rt_amb; out.indices[o] = rt_iters*100000 + rt_pairs;
-#endif
-        }
-#endif
-#ifdef MS_DEBUG_COUNT
-        out.locations[o] = (float)dbg_iters; out.dots[o] = (float)dbg_mine; out.distances[o] = (float)dbg_hits;
-        out.screen[3*o] = (float)dbg_inc;
-#endif
     }
 
     // ---- pass 3: shade (kernels.cu:407-450)
@@ -896,19 +843,8 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
     float loc = 0.f, dt = 0.f;
     if (r < R) { nearest_idx = out.indices[o]; loc = out.locations[o]; dt = out.dots[o]; }
     const bool dynamic = (nearest_idx >= 0) & (nearest_idx < AF);
-#ifdef MS_ABLATE_DYNLIGHT
-    const unsigned long long dyn = 0ull;         // idle-cost experiment: every workgroup leaves after its reads
-#else
     const unsigned long long dyn = __ballot(dynamic);
-#endif
     if (!dyn) return;                            // uniform across the workgroup: every wave sees the same 64 rays
-#ifdef MS_DEBUG_TIME
-    const long long t_start = __builtin_readcyclecounter();
-    long long t_a = 0, t_b = 0, t_c = 0, t_d = 0;
-#define MS_STAMP(x) x = __builtin_readcyclecounter()
-#else
-#define MS_STAMP(x)
-#endif
 
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
     const float* __restrict__ lights = sc.lights_vals + 3*(size_t)lbase;
@@ -927,7 +863,6 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
     }
     const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
     const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
-    MS_STAMP(t_a);
 
     float acc = AMBIENT;                 // the reference's in-order sum, for rays that do not saturate
     bool saturated = false;
@@ -1019,7 +954,6 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
             };
 
             // phase 1: the NEAR_LIGHTS nearest lights
-            MS_STAMP(t_b);
             constexpr int NEAR_LIGHTS = 4;
             const int n1 = min(NEAR_LIGHTS, ni);
             unsigned long long open = __ballot(mine);
@@ -1041,7 +975,6 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
                 }
                 saturated = shortcut & (part >= 1.001f);
             }
-            MS_STAMP(t_c);
             // phase 2: whatever is left, all the remaining lights
             open = __ballot(mine & !saturated);              // identical in every wave
             if (open && ni > n1) sweep(n1, ni, open);
@@ -1061,11 +994,6 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
         out.screen[3*o]     = dn*intensity*(f.lw*t0[0] + f.rw*t1[0]);
         out.screen[3*o + 1] = dn*intensity*(f.lw*t0[1] + f.rw*t1[1]);
         out.screen[3*o + 2] = dn*intensity*(f.lw*t0[2] + f.rw*t1[2]);
-#ifdef MS_DEBUG_TIME
-        MS_STAMP(t_d);
-        out.distances[o] = (float)(t_d - t_start);
-        out.locations[o] = (float)(t_a - t_start); out.dots[o] = (float)(t_b - t_a); out.screen[3*o] = (float)(t_c - t_b);
-#endif
     }
 }
 
@@ -1233,11 +1161,6 @@ __global__ __launch_bounds__(WG) void dynlight_grid_kernel(
         const unsigned long long shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
         blocked = dark | (shadow & unk);
     }
-#ifdef MS_DEBUG_GRID
-    if (dynamic & (wave == 0)) {
-        out.distances[o] = (float)__popcll(need_lights); out.locations[o] = saturated ? 1.f : 0.f; out.dots[o] = (float)__popcll(unk);
-    }
-#endif
     if (dynamic & (wave == 0)) {                             // kernels.cu:261-267, 441-445
         float intensity = 1.f;
         if (!saturated) {
