@@ -59,6 +59,37 @@ def algorithmic_bytes(core):
     return render, physics
 
 
+def env_step_fps(device, n_core_envs=4096, steps=60, warmup=10):
+    """Whole env.step() rates - kernels plus the torch glue of megastep_amd.demo.envs - with random actions, the
+    quantity the reference's docs quote (docs/index.rst:13-25: Explorer 180k FPS, Deathmatch 1.2m FPS on a 2080 Ti).
+    Explorer renders 256 rays -> 64 px, Deathmatch 512 -> 128 px, as in the reference; FPS counts agent-envs."""
+    from megastep_amd import arrdict, cubicasa
+    from megastep_amd.demo import Deathmatch, Explorer
+    pool = cubicasa.sample(256, n_unique=512)
+    geometries = [pool[i % len(pool)] for i in range(n_core_envs)]
+
+    def rate(env, n):
+        env.reset()
+        acts = torch.randint(0, 7, (steps + warmup, n, env.action_space.shape[0]), device=device)
+        for i in range(warmup):
+            env.step(arrdict.arrdict(actions=acts[i]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            env.step(arrdict.arrdict(actions=acts[warmup + i]))
+        torch.cuda.synchronize()
+        return n*steps/(time.perf_counter() - t0)
+
+    out = {}
+    np.random.seed(0); torch.manual_seed(0)
+    out['explorer'] = {'fps': rate(Explorer(n_core_envs, device=device, geometries=geometries), n_core_envs),
+                       'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU'}
+    torch.cuda.empty_cache()
+    out['deathmatch'] = {'fps': rate(Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries), 4*n_core_envs),
+                         'env': f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU'}
+    return out
+
+
 def measured_traffic(args, world):
     """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact command (profiles/rNN_traffic.json,
     written by scratch/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
@@ -116,6 +147,8 @@ def main():
     ap.add_argument('--fov', type=float, default=130.)
     ap.add_argument('--large', action='store_true', help='800-1200 wall segments per env')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--env-fps', action='store_true',
+                    help="also time full env.step() of the reference-shaped Explorer and Deathmatch envs (reported only)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -207,13 +240,17 @@ def main():
             'parallelism': f'env-sharded x{world}, no collectives'},
         'agent_steps_per_sec': value*A,
         'roofline': {
-            'kernel': 'ms_render = render_kernel<1> + dynlight_kernel', 'bound': 'hbm', 'achieved': achieved,
+            'kernel': 'ms_render = render_kernel<1,1> + dynlight_grid_kernel', 'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS, 'traffic': measured_traffic(args, world),
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
             'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(core)
+    if rank == 0 and world == 1 and args.env_fps:
+        del core, scenery, agents
+        torch.cuda.empty_cache()
+        out['env_step'] = env_step_fps(device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

@@ -372,11 +372,10 @@ __device__ inline Filt tex_filter(float x, int w) {
 // IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
 // IMPL 1 ("pairs", default): (line, ray) pairs flattened over all 64 lanes + LDS atomic argmin; rays whose
 //          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
-// 8 waves per SIMD (<= 64 VGPRs): 2048 workgroups resident, so the benchmark's 4096 run in two even rounds.
 // RW = waves per workgroup.  The waves never talk to each other, so RW = 1 lets every wave give its slot and
 // LDS back the moment it is done instead of waiting for the slowest of four.
 template <int IMPL, int RW>
-__global__ __launch_bounds__(RW*WAVE, 8) void render_kernel(
+__global__ __launch_bounds__(RW*WAVE) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans) {
     __shared__ Cand  s_cand[RW][WAVE];       // the chunk's 64 lines
