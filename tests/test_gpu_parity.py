@@ -242,3 +242,66 @@ def test_crowded_rooms_exercise_dynamic_lighting():
     idx = r.indices.cpu().numpy()
     assert ((idx >= 0) & (idx < 32)).mean() > .05, 'expected plenty of rays on agents'
     util.assert_render_matches(c, r, ref.render())
+
+
+@pytest.mark.parametrize('n_envs,n_agents,res,fov', [(3, 1, 256, 130), (2, 2, 64, 170), (2, 1, 1, 90)])
+def test_large_maps_and_extreme_views(n_envs, n_agents, res, fov):
+    """800-1200 wall plans (BASELINE config 5's geometry), a 170 degree fan, a single ray."""
+    from megastep_amd import cuda
+    c, _ = _world(n_envs, n_agents, res, fov, seed=9, large=True)
+    ref = util.OracleWorld(c)
+    np.testing.assert_allclose(c.scenery.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+    ref.pull_baked(c)
+    rng = np.random.RandomState(3)
+    for _ in range(2):
+        util.random_velocities(c, rng, speed=8.)
+        ref.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        util.assert_physics_matches(c, p, *ref.physics())
+        util.assert_render_matches(c, r, ref.render())
+
+
+def test_ragged_edge_cases():
+    """An env without lights, an env with a single wall, an env with more walls than one LDS staging pass of the
+    bake kernels holds (2048), side by side with a normal one."""
+    from megastep_amd import cuda, toys, arrdict
+    rng = np.random.RandomState(0)
+    box = toys.box()
+    many = np.concatenate([box.walls] + [np.array([[[x, y], [x + .03, y + .02]]]) for x in np.linspace(1.5, 5.5, 50) for y in np.linspace(1.5, 5.5, 44)])
+    assert len(many) > 2048
+    geoms = [
+        arrdict.arrdict(walls=box.walls, lights=np.zeros((0, 2)), masks=box.masks, res=.2),          # dark room
+        arrdict.arrdict(walls=box.walls[:1], lights=box.lights, masks=box.masks, res=.2),            # one wall
+        arrdict.arrdict(walls=many, lights=np.array([[3.5, 3.5], [2., 5.]]), masks=box.masks, res=.2),
+        box]
+    from megastep_amd import core, scene
+    np.random.seed(0)
+    scenery = scene.scenery(geoms, 2, device='cuda', random=np.random.RandomState(0))
+    c = core.Core(scenery, res=64, fov=130)
+    c.agents.positions[:] = torch.as_tensor(rng.uniform(2, 5, (4, 2, 2)).astype(np.float32), device=c.device)
+    c.agents.angles[:] = torch.as_tensor(rng.uniform(-180, 180, (4, 2)).astype(np.float32), device=c.device)
+    ref = util.OracleWorld(c)
+    np.testing.assert_allclose(scenery.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+    ref.pull_baked(c)
+    for _ in range(2):
+        util.random_velocities(c, rng, speed=5.)
+        ref.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        util.assert_physics_matches(c, p, *ref.physics())
+        util.assert_render_matches(c, r, ref.render())
+    assert (r.screen[0][r.indices[0] >= 16] > 0).any()        # ambient light only, but not black
+
+
+def test_render_is_deterministic_and_leaves_inputs_alone():
+    from megastep_amd import cuda
+    c, _ = _world(16, 4, 64, 130, seed=4)
+    before = {k: getattr(c.agents, k).clone() for k in ('angles', 'positions', 'angvelocity', 'velocity')}
+    a = cuda.render(c.scenery, c.agents)
+    b = cuda.render(c.scenery, c.agents)
+    for k in ('indices', 'locations', 'dots', 'distances', 'screen'):
+        x, y = getattr(a, k), getattr(b, k)
+        assert torch.equal(torch.nan_to_num(x.float(), nan=-7.), torch.nan_to_num(y.float(), nan=-7.)), k
+    for k, v in before.items():
+        assert torch.equal(getattr(c.agents, k), v), k
