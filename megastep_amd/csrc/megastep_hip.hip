@@ -164,12 +164,6 @@ __device__ inline float collision_cs(P2 p, P2 v, P2 la, P2 lb, float agent_radiu
     return x;
 }
 
-__device__ inline float wave_min(float x) {
-    // inputs are in [+0, 1] and never NaN, so fminf is exact and order-independent here
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fminf(x, __shfl_xor(x, o, WAVE));
-    return x;
-}
 
 // v_readlane_b32 of a float: broadcast lane `l` (wave-uniform) of v through an SGPR, no LDS round trip
 __device__ inline float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -205,85 +199,109 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // ------------------------------------------------------------------------------------------------
 // physics                                                                    kernels.cu:179-230
 // ------------------------------------------------------------------------------------------------
-// A workgroup owns `envs_per_wg` whole envs so that every read of the start-of-step agent state
-// happens before the barrier and every write after it (agents of one env read each other).
+// A workgroup owns `envs_per_wg` whole envs, so that every read of the start-of-step agent state happens
+// before a barrier and every write after it (agents of one env read each other).  Its four waves split each
+// env's wall CHUNKS between them and test every chunk they load against all of the env's agents: a wave waits
+// on a quarter of the loads it would need if it owned one agent.
+//
+// Reach cull (exact): all four sub-tests of collision_cs leave x = 1 for a wall farther from the agent than
+// 1.02|v| + 2r - the crossing and side tests need the wall within |v| + r of p, and an endpoint that far ahead
+// clamps to 1 (0.99 (a.s - backoff) >= 1).  The margin dwarfs rounding.  Lanes test one wall each with cheap
+// arithmetic; the few (agent, wall) pairs in reach are compacted into LDS and only those pay for the ten
+// divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
+// every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
 __global__ __launch_bounds__(WG) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
         const float agent_radius, const float fps, const int envs_per_wg) {
-    extern __shared__ float s_progress[];   // [envs_per_wg*A]
-    __shared__ float4 s_near[WAVES][WAVE];  // per wave: the walls within reach of its agent
+    extern __shared__ float4 s_dyn[];            // per task: (p, v/fps) | reach^2 | progress bits
+    __shared__ float4 s_wall[WAVES][WAVE];       // per wave: walls within reach of ...
+    __shared__ int s_tag[WAVES][WAVE];           // ... this task
     const int N = sc.n_envs, A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tasks = envs_per_wg*A;
     const int env0 = blockIdx.x*envs_per_wg;
+    float4* s_task = s_dyn;
+    float* s_reach2 = reinterpret_cast<float*>(s_task + tasks);
+    unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + tasks);
     const float4* __restrict__ lines4 = reinterpret_cast<const float4*>(sc.lines_vals);
     const float2* __restrict__ pos2 = reinterpret_cast<const float2*>(ag.positions);
     const float2* __restrict__ vel2 = reinterpret_cast<const float2*>(ag.velocity);
 
-    for (int t = wave; t < tasks; t += WAVES) {
+    // one thread per (env, agent): its state, its reach, and the agent-agent tests (kernels.cu:193-200)
+    for (int t = tid; t < tasks; t += WG) {
         const int n = env0 + t/A, a = t % A;
-        if (n >= N) continue;
-        const float2 pp = pos2[n*A + a], mm = vel2[n*A + a];
-        const P2 p0 = p2(pp.x, pp.y);
-        const P2 v0 = p2(mm.x, mm.y)/fps;
-        float x = 1.f;
-        for (int d1 = lane; d1 < A; d1 += WAVE) {
-            if (d1 != a) {
-                const float2 q = pos2[n*A + d1], m1 = vel2[n*A + d1];
-                x = ms_min(x, collision_cc(p0, v0, p2(q.x, q.y), p2(m1.x, m1.y)/fps, agent_radius));
-            }
-        }
-        const int L = sc.lines_widths[n];
-        const float4* __restrict__ ln = lines4 + sc.lines_starts[n];
-        // Reach cull (exact): all four sub-tests of collision_cs leave x = 1 for a wall farther from the
-        // agent than 1.02|v| + 2r - the crossing and side tests need the wall within |v| + r of p, and an
-        // endpoint that far ahead clamps to 1 (0.99 (a.s - backoff) >= 1).  The margin dwarfs rounding.
-        // Lanes test one wall each with cheap arithmetic; the few walls in reach are compacted into LDS
-        // and only those pay for the ten divides and five square roots of the real test.
-        const float r1 = 1.001f*agent_radius;
-        const float reach = 1.02f*len(v0) + 2.f*r1 + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
-        const float reach2 = reach*reach;
-        int cnt = 0;
-        for (int l0 = AF; l0 < L; l0 += WAVE) {
-            const int l = l0 + lane;
-            bool in = false;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (l < L) {
-                w = ln[l];
-                const float pqx = w.x - p0.x, pqy = w.y - p0.y, vx = w.z - w.x, vy = w.w - w.y;
-                float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
-                tc = fminf(fmaxf(tc, 0.f), 1.f);
-                tc = (tc == tc) ? tc : 0.f;
-                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-                in = !(0.9998f*(qx*qx + qy*qy) > reach2);              // NaNs stay in
-            }
-            const unsigned long long m = __ballot(in);
-            const int nk = __popcll(m);
-            if (cnt + nk > WAVE) {                                      // flush a full list first
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (lane < cnt) {
-                    const float4 u = s_near[wave][lane];
-                    x = ms_min(x, collision_cs(p0, v0, p2(u.x, u.y), p2(u.z, u.w), agent_radius));
+        float reach2 = -1.f;                     // envs past the end: nothing is ever in reach
+        if (n < N) {
+            const float2 pp = pos2[n*A + a], mm = vel2[n*A + a];
+            const P2 p0 = p2(pp.x, pp.y);
+            const P2 v0 = p2(mm.x, mm.y)/fps;
+            float x = 1.f;
+            for (int d1 = 0; d1 < A; d1++) {
+                if (d1 != a) {
+                    const float2 q = pos2[n*A + d1], m1 = vel2[n*A + d1];
+                    x = ms_min(x, collision_cc(p0, v0, p2(q.x, q.y), p2(m1.x, m1.y)/fps, agent_radius));
                 }
-                __builtin_amdgcn_wave_barrier();
-                cnt = 0;
             }
-            if (in) s_near[wave][cnt + __popcll(m & ((1ull << lane) - 1ull))] = w;
-            cnt += nk;
+            const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+            reach2 = (reach == reach) ? reach*reach : INFINITY;          // NaN velocities: test everything
+            s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
+            s_prog[t] = f_bits(x);
         }
+        s_reach2[t] = reach2;
+    }
+    __syncthreads();
+
+    int cnt = 0;
+    auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < cnt) {
-            const float4 u = s_near[wave][lane];
-            x = ms_min(x, collision_cs(p0, v0, p2(u.x, u.y), p2(u.z, u.w), agent_radius));
+            const float4 u = s_wall[wave][lane];
+            const int t = s_tag[wave][lane];
+            const float4 tk = s_task[t];
+            const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
+            if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
         }
         __builtin_amdgcn_wave_barrier();
-        x = wave_min(x);
-        if (lane == 0) s_progress[t] = x;
+        cnt = 0;
+    };
+    for (int e = 0; e < envs_per_wg; e++) {
+        const int n = env0 + e;
+        if (n >= N) break;
+        const int L = sc.lines_widths[n];
+        const float4* __restrict__ ln = lines4 + sc.lines_starts[n];
+        for (int l0 = AF + wave*WAVE; l0 < L; l0 += WAVES*WAVE) {
+            const bool live = l0 + lane < L;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) w = ln[l0 + lane];
+            const float vx = w.z - w.x, vy = w.w - w.y;
+            const float inv = __builtin_amdgcn_rcpf(vx*vx + vy*vy);
+            for (int a = 0; a < A; a++) {
+                const int t = e*A + a;
+                const float4 tk = s_task[t];
+                // squared distance from the agent to the segment, shaved so it is a lower bound
+                const float pqx = w.x - tk.x, pqy = w.y - tk.y;
+                float tc = -(pqx*vx + pqy*vy)*inv;
+                tc = fminf(fmaxf(tc, 0.f), 1.f);
+                tc = (tc == tc) ? tc : 0.f;
+                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+                const bool in = live & !(0.9998f*(qx*qx + qy*qy) > s_reach2[t]);      // NaNs stay in
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    const int nk = __popcll(m);
+                    if (cnt + nk > WAVE) flush();
+                    if (in) {
+                        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                        s_wall[wave][pos] = w;
+                        s_tag[wave][pos] = t;
+                    }
+                    cnt += nk;
+                }
+            }
+        }
     }
+    if (cnt) flush();
     __syncthreads();
     // epilogue, kernels.cu:224-227
     float2* __restrict__ pos2w = reinterpret_cast<float2*>(ag.positions);
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(WG) void physics_kernel(
         const int n = env0 + t/A, a = t % A;
         if (n >= N) continue;
         const int i = n*A + a;
-        const float x = s_progress[t];
+        const float x = bits_f(s_prog[t]);
         float2 p = pos2w[i], v = vel2w[i];
         p.x = p.x + x*v.x/fps;
         p.y = p.y + x*v.y/fps;
@@ -1404,7 +1422,7 @@ int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const M
     const int A = sc->n_agents;
     const int envs_per_wg = A >= WAVES ? 1 : WAVES/A;
     const int blocks = (sc->n_envs + envs_per_wg - 1)/envs_per_wg;
-    const size_t shmem = sizeof(float)*(size_t)envs_per_wg*A;
+    const size_t shmem = (sizeof(float)*4 + sizeof(float) + sizeof(unsigned))*(size_t)envs_per_wg*A;
     if (shmem > 64*1024) return MS_EUNSUPPORTED;
     hipLaunchKernelGGL(physics_kernel, dim3(blocks), dim3(WG), shmem, (hipStream_t)stream,
                        *sc, *ag, progress, cfg->agent_radius, cfg->fps, envs_per_wg);
