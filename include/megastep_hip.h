@@ -92,14 +92,15 @@ typedef struct MsRender {
     float* dots;          /* (N, A, R)    ray . line direction,    NaN on a miss  */
     float* distances;     /* (N, A, R)    metres, +inf on a miss                  */
     float* screen;        /* (N, A, R, 3) linear RGB, 0 on a miss                 */
-    /* Optional scratch, not an output: lets ms_render hand the ray groups that need dynamic lighting
-     * from its first kernel to its second as a compact list.  At least MS_RENDER_WORKSPACE_INTS(N, A, R)
-     * ints, contents undefined before and after the call; NULL selects a slower hand-off. */
+    /* Optional scratch, not an output: lets ms_render compute every agent's sin/cos once, ahead of the
+     * raycast, and hand the ray groups that need dynamic lighting from its first kernel to its second as
+     * a compact list.  At least MS_RENDER_WORKSPACE_INTS(N, A, R) 4-byte words, 8-byte aligned, contents
+     * undefined before and after the call; NULL selects slower in-kernel paths. */
     int*   workspace;
 } MsRender;
 
-/* ints of MsRender.workspace needed for N envs, A agents, R rays */
-#define MS_RENDER_WORKSPACE_INTS(N, A, R) (16 + (long long)(N)*(A)*(((R) + 63)/64))
+/* 4-byte words of MsRender.workspace needed for N envs, A agents, R rays */
+#define MS_RENDER_WORKSPACE_INTS(N, A, R) (18 + (long long)(N)*(A)*(((R) + 63)/64) + 2*(long long)(N)*(A))
 
 int         ms_abi_version(void);
 const char* ms_strerror(int code);

@@ -387,6 +387,20 @@ __device__ inline Filt tex_filter(float x, int w) {
     return f;
 }
 
+// First launch of ms_render when a workspace is given: zeroes the queue counter and evaluates every agent's
+// sin/cos (binary64 inside, see sincospi_f) once, instead of once per wavefront of the raycast.
+// Workspace layout: [0] queue length | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
+__global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
+                                                         const int n_agents_total, const int n_fans) {
+    const int i = blockIdx.x*WG + threadIdx.x;
+    if (i == 0) workspace[0] = 0;
+    if (i < n_agents_total) {
+        float s, c;
+        sincospi_f(ag.angles[i]/180.f, s, c);
+        reinterpret_cast<float2*>(workspace + 16 + ((n_fans + 1) & ~1))[i] = make_float2(s, c);
+    }
+}
+
 // IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
 // IMPL 1 ("pairs", default): (line, ray) pairs flattened over all 64 lanes + LDS atomic argmin; rays whose
 //          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
@@ -431,7 +445,12 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     float ag_s = 0.f, ag_c = 0.f;
     float2 ag_p = make_float2(0.f, 0.f);
     if (lane < A) {
-        sincospi_f(ag.angles[n*A + lane]/180.f, ag_s, ag_c);
+        if (out.workspace) {
+            const float2 sc_ = reinterpret_cast<const float2*>(out.workspace + 16 + ((n_fans + 1) & ~1))[n*A + lane];
+            ag_s = sc_.x; ag_c = sc_.y;
+        } else {
+            sincospi_f(ag.angles[n*A + lane]/180.f, ag_s, ag_c);
+        }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
     // --- ray setup (kernels.cu:334-344)
@@ -1444,9 +1463,11 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
     // (kept for A/B verification); both produce the same bits.
     static const bool seq = [] { const char* e = getenv("MEGASTEP_RENDER_IMPL"); return e && e[0] == 's'; }();
-    if (out->workspace && sc->n_agents > 1) {
-        const hipError_t em = hipMemsetAsync(out->workspace, 0, sizeof(int), (hipStream_t)stream);
-        if (em != hipSuccess) return hip_fail(em);
+    if (out->workspace) {
+        if ((uintptr_t)out->workspace % 8) return MS_EINVAL;
+        const int na = sc->n_envs*sc->n_agents;
+        hipLaunchKernelGGL(render_prep_kernel, dim3((na + WG - 1)/WG), dim3(WG), 0, (hipStream_t)stream,
+                           *ag, out->workspace, na, (int)n_fans);
     }
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);

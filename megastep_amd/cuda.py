@@ -330,7 +330,7 @@ def render(scenery, agents):
     distances = torch.empty((n, a, r), dtype=torch.float32, device=dev)
     screen = torch.empty((n, a, r, 3), dtype=torch.float32, device=dev)
     # scratch for the kernels' hand-off of the ray groups that need dynamic lighting (MS_RENDER_WORKSPACE_INTS)
-    workspace = torch.empty(16 + n*a*((r + 63)//64), dtype=torch.int32, device=dev)
+    workspace = torch.empty(18 + n*a*((r + 63)//64) + 2*n*a, dtype=torch.int32, device=dev)
     out = _lib.MsRender(indices.data_ptr(), locations.data_ptr(), dots.data_ptr(), distances.data_ptr(), screen.data_ptr(),
                         workspace.data_ptr())
     with _on(dev):
