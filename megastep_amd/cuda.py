@@ -153,6 +153,8 @@ class Agents:
         if positions.shape != (n, a, 2) or velocity.shape != (n, a, 2) or angvelocity.shape != (n, a):
             raise RuntimeError('agent tensors must be (N, A), (N, A, 2), (N, A), (N, A, 2)')
         self._struct = _lib.MsAgents(angles.data_ptr(), positions.data_ptr(), angvelocity.data_ptr(), velocity.data_ptr())
+        devices = {t.device for t in (angles, positions, angvelocity, velocity)}
+        self._dev = devices.pop() if len(devices) == 1 else None         # None: tensors on mixed devices
 
     angles = property(lambda self: self._angles)
     positions = property(lambda self: self._positions)
@@ -186,6 +188,7 @@ class Scenery:
         self._lights, self._lines, self._textures, self._model = lights, lines, textures, model
         self._baked = Ragged1D(torch.ones_like(textures.vals[:, 0]).contiguous(), textures.widths)
         self._struct = None
+        self._dev = None
 
     n_agents = property(lambda self: self._n_agents)
     lights = property(lambda self: self._lights)
@@ -241,6 +244,12 @@ class Scenery:
                 *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4])
         return self._struct
 
+    def _device(self):
+        """The GPU all of this scenery's tensors live on (checked once; the tensors cannot be swapped out)."""
+        if self._dev is None:
+            self._dev = _require_gpu(*self._tensors())
+        return self._dev
+
     def _tensors(self):
         li, ln, tx = self._lights, self._lines, self._textures
         return (ln.vals, ln.widths, li.vals, li.widths, tx.vals, tx.widths, self._model, self._baked.vals)
@@ -290,10 +299,17 @@ class _on:
             self._guard.__exit__(*exc)
 
 
+def _agents_on(agents, dev):
+    if agents._dev != dev:
+        if agents._dev is None or not agents._dev.type == 'cuda':
+            raise RuntimeError('megastep_amd kernels need GPU (HIP) tensors; the agents are on ' + str(agents._dev or 'several devices'))
+        raise RuntimeError(f'all tensors must live on one device; got {agents._dev} and {dev}')
+
+
 def bake(scenery):
     """Pre-computes the static lighting of every texel into ``scenery.baked`` (reference: wrappers.cpp:61,
     kernels.cu:270-293)."""
-    dev = _require_gpu(*scenery._tensors())
+    dev = scenery._device()
     # bake uses none of the initialize() constants (kernels.cu:238-293), and scene.scenery() calls it before any Core
     # exists, so the config is optional here
     cfg = C.byref(_config) if _config is not None else None
@@ -304,7 +320,8 @@ def bake(scenery):
 def physics(scenery, agents):
     """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
     returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230)."""
-    dev = _require_gpu(scenery.lines.vals, agents.angles, agents.positions, agents.angvelocity, agents.velocity)
+    dev = scenery._device()
+    _agents_on(agents, dev)
     if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery: expected (n_envs, n_agents) = '
                            f'{(len(scenery.lines), scenery.n_agents)}, got {tuple(agents.angles.shape)}')
@@ -318,21 +335,22 @@ def physics(scenery, agents):
 def render(scenery, agents):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`."""
-    dev = _require_gpu(*scenery._tensors(), agents.angles, agents.positions)
+    dev = scenery._device()
+    _agents_on(agents, dev)
     n, a = agents.angles.shape
     if (n, a) != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery')
     cfg = _cfg()
     r = cfg.res
-    indices = torch.empty((n, a, r), dtype=torch.int32, device=dev)
-    locations = torch.empty((n, a, r), dtype=torch.float32, device=dev)
-    dots = torch.empty((n, a, r), dtype=torch.float32, device=dev)
-    distances = torch.empty((n, a, r), dtype=torch.float32, device=dev)
-    screen = torch.empty((n, a, r, 3), dtype=torch.float32, device=dev)
-    # scratch for the kernels' hand-off of the ray groups that need dynamic lighting (MS_RENDER_WORKSPACE_INTS)
-    workspace = torch.empty(18 + n*a*((r + 63)//64) + 2*n*a, dtype=torch.int32, device=dev)
-    out = _lib.MsRender(indices.data_ptr(), locations.data_ptr(), dots.data_ptr(), distances.data_ptr(), screen.data_ptr(),
-                        workspace.data_ptr())
+    # One allocation for the five outputs (reference: five at::empty calls, kernels.cu:461-469) and the kernels'
+    # scratch (MS_RENDER_WORKSPACE_INTS): 7 planes of (n, a, r) words, then the workspace.
+    plane = n*a*r
+    buf = torch.empty(7*plane + 18 + n*a*((r + 63)//64) + 2*n*a, dtype=torch.float32, device=dev)
+    planes = buf[:7*plane].view(7, n, a, r)
+    indices, locations, dots, distances = planes[0].view(torch.int32), planes[1], planes[2], planes[3]
+    screen = planes[4:].view(n, a, r, 3)
+    base = buf.data_ptr()
+    out = _lib.MsRender(base, base + 4*plane, base + 8*plane, base + 12*plane, base + 16*plane, base + 28*plane)
     with _on(dev):
         _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct), C.byref(out),
                                         C.byref(cfg), _stream(dev)))
