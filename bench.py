@@ -92,7 +92,7 @@ def env_step_fps(device, n_core_envs=4096, steps=60, warmup=10):
 
 def measured_traffic(args, world):
     """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact command (profiles/rNN_traffic.json,
-    written by scratch/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
+    written by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950). None when the workload differs from the profiled one."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc.sh lib.so tag  -> prints per-kernel mean counters
+# usage: tools/pmc.sh lib.so tag  -> prints per-kernel mean counters
 lib=$1; tag=$2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 MEGASTEP_HIP_LIB=$PWD/$lib rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --kernel-trace -d gpurun_out/pmc_$tag -o p --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline $BENCH_ARGS > gpurun_out/pmc_$tag.log 2>&1
