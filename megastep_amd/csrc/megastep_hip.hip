@@ -389,11 +389,12 @@ __device__ inline Filt tex_filter(float x, int w) {
 
 // First launch of ms_render when a workspace is given: zeroes the queue counter and evaluates every agent's
 // sin/cos (binary64 inside, see sincospi_f) once, instead of once per wavefront of the raycast.
-// Workspace layout: [0] queue length | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
+// Workspace layout: [0] queue length, [1] rays that took the sequential fold, [2] wavefronts that took its lane-parallel
+// form (telemetry for tests) | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
 __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
                                                          const int n_agents_total, const int n_fans) {
     const int i = blockIdx.x*WG + threadIdx.x;
-    if (i == 0) workspace[0] = 0;
+    if (i == 0) { workspace[0] = 0; workspace[1] = 0; workspace[2] = 0; }
     if (i < n_agents_total) {
         float s, c;
         sincospi_f(ag.angles[i]/180.f, s, c);
@@ -505,45 +506,49 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         s_second[wave][lane] = ~0ull;
         s_third[wave][lane] = ~0ull;
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
+        // pass 1 for one line (lane = line): the ray-independent half of the intersection into LDS, and the
+        // conservative interval [lo, lo + len) of this wave's rays that can hit it
+        auto line_setup = [&](const int l, int& lo, int& len) {
+            float4 w;
+            if (l >= AF) {
+                w = ln[l];
+            } else if (A <= WAVE) {                                     // draw_kernel, kernels.cu:297-318
+                const int la = l / sc.n_model;
+                const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
+                const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
+                const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
+                w.x = c_*mdl.x - s_*mdl.y + px_; w.y = s_*mdl.x + c_*mdl.y + py_;
+                w.z = c_*mdl.z - s_*mdl.w + px_; w.w = s_*mdl.z + c_*mdl.w + py_;
+            } else {
+                w = drawn_line(sc, ag, n, l);
+            }
+            const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
+            const float dbx = w.z - pp.x, dby = w.w - pp.y;
+            s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
+            // agent-frame coordinates of both endpoints
+            float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
+            float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
+            const bool fa = xa >= x_clip, fb = xb >= x_clip;
+            const bool inc = fa | fb | !(xa == xa) | !(xb == xb);       // wholly behind the clip plane: never hit
+            if (fa != fb) {                                             // clip the hidden end to x' = x_clip
+                const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
+                const float yc = ya + t*(yb - ya);
+                if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
+            }
+            const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
+            const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
+            const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
+            // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
+            const float flo = fminf(fmaxf(fminf(ra, rb) - marg - g0, 0.f), 64.f);
+            const float fhi = fmaxf(fminf(fmaxf(ra, rb) + marg - g0, last_local), -1.f);
+            lo = (int)ceilf(flo);
+            len = inc ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+        };
+
         for (int c0 = 0; c0 < L; c0 += WAVE) {
             const int l = c0 + lane;
             int lo = 0, len = 0;
-            if (l < L) {
-                float4 w;
-                if (l >= AF) {
-                    w = ln[l];
-                } else if (A <= WAVE) {                                     // draw_kernel, kernels.cu:297-318
-                    const int la = l / sc.n_model;
-                    const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
-                    const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
-                    const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
-                    w.x = c_*mdl.x - s_*mdl.y + px_; w.y = s_*mdl.x + c_*mdl.y + py_;
-                    w.z = c_*mdl.z - s_*mdl.w + px_; w.w = s_*mdl.z + c_*mdl.w + py_;
-                } else {
-                    w = drawn_line(sc, ag, n, l);
-                }
-                const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
-                const float dbx = w.z - pp.x, dby = w.w - pp.y;
-                s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
-                // agent-frame coordinates of both endpoints
-                float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
-                float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
-                const bool fa = xa >= x_clip, fb = xb >= x_clip;
-                const bool inc = fa | fb | !(xa == xa) | !(xb == xb);       // wholly behind the clip plane: never hit
-                if (fa != fb) {                                             // clip the hidden end to x' = x_clip
-                    const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
-                    const float yc = ya + t*(yb - ya);
-                    if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
-                }
-                const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
-                const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
-                const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
-                // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
-                const float flo = fminf(fmaxf(fminf(ra, rb) - marg - g0, 0.f), 64.f);
-                const float fhi = fmaxf(fminf(fmaxf(ra, rb) + marg - g0, last_local), -1.f);
-                lo = (int)ceilf(flo);
-                len = inc ? max((int)floorf(fhi) - lo + 1, 0) : 0;
-            }
+            if (l < L) line_setup(l, lo, len);
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
@@ -618,23 +623,28 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
         // line order into the ray's own state, which lives in the ray's lane.
         const unsigned long long amb = __ballot(ambiguous);
+        if (amb && out.workspace && lane == 0) {
+            atomicAdd(&out.workspace[1], __popcll(amb));
+            if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
+        }
         if (__popcll(amb) > 6) {
-            // many such rays (a view full of coincident walls): cheaper to let every one of them walk all
-            // the lines itself, lines broadcast from LDS
+            // many such rays (a view full of coincident walls): every one of them walks the lines itself, lines
+            // broadcast from LDS - but only the lines whose interval reaches one of these rays are looked at
             float x = INFINITY;
             int xi = -1;
             for (int c0 = 0; c0 < L; c0 += WAVE) {
                 const int l = c0 + lane;
-                if (l < L) {
-                    const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
-                    s_cand[wave][lane] = Cand{w.x - pp.x, w.y - pp.y, w.z - w.x, w.w - w.y};
-                }
+                int lo = 0, len = 0;
+                if (l < L) line_setup(l, lo, len);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int cn = min(WAVE, L - c0);
-                if (ambiguous) {
-                    for (int j = 0; j < cn; j++) {
+                for (unsigned long long todo = __ballot(len > 0); todo; todo &= todo - 1) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    const int jlo = __builtin_amdgcn_readlane(lo, j), jhi = jlo + __builtin_amdgcn_readlane(len, j) - 1;
+                    const unsigned long long span = ((jhi >= 63) ? ~0ull : ((2ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull);
+                    if (!(span & amb)) continue;
+                    if (ambiguous & (lane >= jlo) & (lane <= jhi)) {
                         const Cand cd = s_cand[wave][j];
                         const float d = rx*cd.vy - ry*cd.vx;
                         const float nt = cd.pqx*ry - cd.pqy*rx;

@@ -354,4 +354,6 @@ def render(scenery, agents):
     with _on(dev):
         _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct), C.byref(out),
                                         C.byref(cfg), _stream(dev)))
-    return Render(indices, locations, dots, distances, screen)
+    result = Render(indices, locations, dots, distances, screen)
+    result._telemetry = buf[7*plane:7*plane + 16].view(torch.int32)      # see render_prep_kernel; read by the tests
+    return result

@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs.
 
 Bar (BASELINE.json north_star): bit-exact collision masks and hit indices; <= 1e-5 on float positions / pixels."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -136,6 +138,10 @@ def test_hysteresis_band_adversarial():
     ref.bake(); ref.pull_baked(c); ref.pull_agents(c)
     r = cuda.render(c.scenery, c.agents)
     util.assert_render_matches(c, r, ref.render())
+    if not os.environ.get('MEGASTEP_RENDER_IMPL', '').startswith('s'):
+        # the scenes are there to drive the sequential-fold fallbacks: make sure they did (render_prep_kernel's telemetry)
+        _, folded_rays, lane_parallel_waves = r._telemetry[:3].tolist()
+        assert folded_rays > 100 and lane_parallel_waves > 5, (folded_rays, lane_parallel_waves)
 
 
 def test_agent_wedged_between_coincident_walls():
