@@ -36,6 +36,15 @@ def shard_scenery(scenery, rank, world_size, device=None):
         textures=move(scenery.textures[l0:l1]),
         model=scenery.model.to(device).clone())
     out.baked.vals.copy_(scenery.baked[l0:l1].vals)
+    # the light grid (what ms_bake caches about which lights reach which cells) is per env too: carry its slice over
+    parent = getattr(scenery, '_lg', None)
+    if parent is not None and parent[0] is not None and out.model.is_cuda:
+        out._as_struct()
+        vals, starts = parent[0], parent[1]
+        c0 = int(starts[start])
+        c1 = int(starts[stop]) if stop < len(starts) else vals.shape[0]
+        if out._lg[0] is not None and out._lg[0].shape[0] == c1 - c0:
+            out._lg[0].copy_(vals[c0:c1])
     return out
 
 

@@ -311,3 +311,28 @@ def test_render_is_deterministic_and_leaves_inputs_alone():
         assert torch.equal(torch.nan_to_num(x.float(), nan=-7.), torch.nan_to_num(y.float(), nan=-7.)), k
     for k, v in before.items():
         assert torch.equal(getattr(c.agents, k), v), k
+
+
+def test_unbaked_scenery_and_shards_render_exactly():
+    """A Scenery that was never baked has an all-unknown light grid and baked == 1: render must still be exact.
+    A shard cut from a baked scenery carries baked lighting and light grid over."""
+    from megastep_amd import core, cuda, cubicasa, scene, sharding
+    np.random.seed(0)
+    gs = cubicasa.sample(6, n_unique=16, seed=3)
+    raw = scene.scenery(gs, 3, device='cuda', random=np.random.RandomState(0), bake=False)
+    for sc, geoms in [(raw, gs)]:
+        c = core.Core(sc, res=64, fov=130)
+        util.spawn(c, geoms, seed=1)
+        c.agents.positions[:, 1] = c.agents.positions[:, 0] + torch.tensor([.4, .1], device=c.device)     # someone to look at
+        ref = util.OracleWorld(c)
+        ref.pull_agents(c)
+        util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())
+    full = scene.scenery(gs, 3, device='cuda', random=np.random.RandomState(0))
+    shard = sharding.shard_scenery(full, 1, 2)
+    assert torch.equal(shard._lg[0], full._lg[0][int(full._lg[1][3]):]) and shard._lg[0].any()
+    c = core.Core(shard, res=64, fov=130)
+    util.spawn(c, gs[3:], seed=2)
+    c.agents.positions[:, 2] = c.agents.positions[:, 0] + torch.tensor([.1, .45], device=c.device)
+    ref = util.OracleWorld(c)
+    ref.pull_agents(c)
+    util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())
