@@ -336,3 +336,39 @@ def test_unbaked_scenery_and_shards_render_exactly():
     ref = util.OracleWorld(c)
     ref.pull_agents(c)
     util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())
+
+
+def test_more_than_64_lights_and_agents():
+    """Past the light grid's 64 lights per env the grid-less lighting kernel takes over (two light groups);
+    past 64 agents per env the per-wave agent cache is bypassed."""
+    from megastep_amd import arrdict, core, cuda, scene, toys
+    rng = np.random.RandomState(0)
+    box = toys.box()
+    pillars = np.concatenate([np.array([[[x, y], [x + .2, y]], [[x + .2, y], [x + .2, y + .2]], [[x + .2, y + .2], [x, y + .2]],
+                                        [[x, y + .2], [x, y]]]) for x, y in rng.uniform(1.5, 5.3, (6, 2))])
+    geom = arrdict.arrdict(walls=np.concatenate([box.walls, pillars]), lights=rng.uniform(1.2, 5.8, (70, 2)), masks=box.masks, res=.2)
+    np.random.seed(0)
+    sc = scene.scenery([geom, geom], 3, device='cuda', random=np.random.RandomState(0))
+    assert sc._as_struct().lg_vals is None                      # no grid for this scenery
+    c = core.Core(sc, res=64, fov=130)
+    c.agents.positions[:] = torch.as_tensor(rng.uniform(2.5, 4.5, (2, 3, 2)).astype(np.float32), device=c.device)
+    c.agents.angles[:] = torch.as_tensor(rng.uniform(-180, 180, (2, 3)).astype(np.float32), device=c.device)
+    ref = util.OracleWorld(c)
+    np.testing.assert_allclose(sc.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+    ref.pull_baked(c); ref.pull_agents(c)
+    r = cuda.render(c.scenery, c.agents)
+    assert ((r.indices >= 0) & (r.indices < 24)).any()
+    util.assert_render_matches(c, r, ref.render())
+
+    crowd = scene.scenery([toys.box(8)], 66, device='cuda', random=np.random.RandomState(0))
+    c = core.Core(crowd, res=16, fov=130)
+    c.agents.positions[:] = torch.as_tensor(rng.uniform(1.5, 8.5, (1, 66, 2)).astype(np.float32), device=c.device)
+    c.agents.angles[:] = torch.as_tensor(rng.uniform(-180, 180, (1, 66)).astype(np.float32), device=c.device)
+    ref = util.OracleWorld(c)
+    ref.bake(); ref.pull_baked(c)
+    util.random_velocities(c, rng, speed=3.)
+    ref.pull_agents(c)
+    p = cuda.physics(c.scenery, c.agents)
+    r = cuda.render(c.scenery, c.agents)
+    util.assert_physics_matches(c, p, *ref.physics())
+    util.assert_render_matches(c, r, ref.render())
