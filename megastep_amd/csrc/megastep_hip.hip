@@ -347,6 +347,146 @@ __device__ inline bool light_blocked(P2 I, P2 U, float ax, float ay, float vx, f
 }
 
 // ------------------------------------------------------------------------------------------------
+// dynamic lighting with the light grid                                     kernels.cu:238-268,432-436
+// ------------------------------------------------------------------------------------------------
+// light_intensity() for the rays of one wavefront that landed on an agent, for sceneries that carry a light grid
+// (MsScenery.lg_vals, filled by ms_bake) and have at most 64 lights per env.  Runs inside render_kernel, by the
+// wave that cast the rays.  Each such ray looks up the cell its hit point is in: lights the grid marks LIT are
+// unblocked, DARK ones blocked - exactly, see lightgrid_kernel - and usually that settles the ray (no UNKNOWN
+// light, or the LIT ones already saturate the sum, see dynlight_kernel).  Only what is left - rays with UNKNOWN
+// lights, those lights only - goes through the corridor sweep + exact tests.  Returns the intensity (for
+// `dynamic` lanes); `s_pair` (LG_PAIRS entries) and `s_shadow` (128 words) are this wave's LDS scratch.
+struct LightPair { float ax, ay, vx, vy, ix, iy; int light; int pad; };
+constexpr int LG_PAIRS = 64;
+
+__device__ inline float grid_light_intensity(
+        const MsScenery& sc, const MsAgents& ag, const int n, const int lane, const bool dynamic, const int nearest_idx,
+        const float cx_l, const float cy_l, const int L, const float4* __restrict__ ln,
+        LightPair* s_pair, unsigned* s_shadow) {
+    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int ni = sc.lights_widths[n];          // <= 64, guaranteed by whoever set lg_vals
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
+    float Ix = 0.f, Iy = 0.f, Ii = 0.f;          // lane i holds light i
+    if (lane < ni) { Ix = lights[3*lane]; Iy = lights[3*lane + 1]; Ii = lights[3*lane + 2]; }
+    const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
+
+    // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
+    uint4 st = make_uint4(0u, 0u, 0u, 0u);
+    if (dynamic) {
+        const float fx = floorf((cx_l - geom.x)/sc.lg_cell), fy = floorf((cy_l - geom.y)/sc.lg_cell);
+        if ((fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w))
+            st = reinterpret_cast<const uint4*>(sc.lg_vals)[sc.lg_starts[n] + (int)fy*(int)geom.z + (int)fx];
+    }
+    const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
+    unsigned long long lit = 0ull, dark = 0ull, need_lights = 0ull;
+    float part = AMBIENT;                        // order-free sum over the lights the grid proves unblocked
+    for (int i = 0; i < ni; i++) {
+        const unsigned wd = (i < 16) ? st.x : (i < 32) ? st.y : (i < 48) ? st.z : st.w;
+        const unsigned s2 = (wd >> (2*(i & 15))) & 3u;
+        if (s2 == 1u) {
+            const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
+            part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+            lit |= 1ull << i;
+        } else if (s2 == 2u) {
+            dark |= 1ull << i;
+        }
+    }
+    const unsigned long long all = (ni >= 64) ? ~0ull : ((1ull << ni) - 1ull);
+    const unsigned long long unk = ~(lit | dark) & all;
+    // saturated: the reference's min(sum, 1) is exactly 1 whatever the unknown lights do (see dynlight_kernel)
+    const bool saturated = dynamic & shortcut & (part >= 1.001f);
+    const bool need = dynamic & !saturated & (unk != 0ull);
+    for (int i = 0; i < ni; i++) if (__ballot(need & (((unk >> i) & 1ull) != 0ull))) need_lights |= 1ull << i;
+
+    unsigned long long blocked = dark;
+    if (need_lights) {                           // uniform: some ray still has lights to test against the walls
+        s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u;
+        unsigned long long todo = __ballot(need);
+        while (todo) {                           // one target agent at a time
+            const int target = __builtin_amdgcn_readlane(my_target, __ffsll((long long)todo) - 1);
+            const bool mine = need & (my_target == target);
+            const unsigned long long open = __ballot(mine);
+            todo &= ~open;
+            // the lights any of this target's rays still needs
+            unsigned long long tl_mask = 0ull;
+            for (unsigned long long m = need_lights; m; m &= m - 1) {
+                const int i = __ffsll((long long)m) - 1;
+                if (__ballot(mine & (((unk >> i) & 1ull) != 0ull))) tl_mask |= 1ull << i;
+            }
+            const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
+            // extent of the hit points around the target, + float slack
+            float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
+            rho = wave_max_f(rho) + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
+            // corridor frame of light `lane`: unit vector e from the light to the target, length el
+            const float dx = T.x - Ix, dy = T.y - Iy;
+            const float el = sqrtf(dx*dx + dy*dy);
+            const float ex = dx/el, ey = dy/el;
+
+            int cnt = 0;
+            auto flush = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const LightPair pr = s_pair[min(lane, cnt - 1)];
+                const P2 I = p2(pr.ix, pr.iy);
+                for (unsigned long long rays = open; rays; rays &= rays - 1) {
+                    const int jr = __ffsll((long long)rays) - 1;
+                    const P2 C = p2(readlane_f(cx_l, jr), readlane_f(cy_l, jr));
+                    if ((lane < cnt) && light_blocked(I, C - I, pr.ax, pr.ay, pr.vx, pr.vy))
+                        atomicOr(&s_shadow[2*jr + (pr.light >> 5)], 1u << (pr.light & 31));
+                }
+                __builtin_amdgcn_wave_barrier();
+                cnt = 0;
+            };
+            for (int l0 = AF; l0 < L; l0 += WAVE) {
+                const bool live = l0 + lane < L;
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) w = ln[l0 + lane];
+                // wall relative to the target, and its margin
+                const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
+                const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
+                for (unsigned long long lm = tl_mask; lm; lm &= lm - 1) {
+                    const int i = __ffsll((long long)lm) - 1;
+                    const float cex = readlane_f(ex, i), cey = readlane_f(ey, i), cel = readlane_f(el, i);
+                    // coordinates along / across the corridor, origin at the target, light at -cel
+                    const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
+                    const float ub = cex*bx + cey*by, vb = cex*by - cey*bx;
+                    const bool outside = ((ua > m) & (ub > m)) | ((ua < -cel - m) & (ub < -cel - m)) |
+                                         ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
+                    const bool keep = live & !outside;
+                    const unsigned long long km = __ballot(keep);
+                    if (km) {
+                        const int nk = __popcll(km);
+                        if (cnt + nk > LG_PAIRS) flush();
+                        if (keep) s_pair[cnt + __popcll(km & ((1ull << lane) - 1ull))] =
+                            LightPair{w.x, w.y, w.z - w.x, w.w - w.y, readlane_f(Ix, i), readlane_f(Iy, i), i, 0};
+                        cnt += nk;
+                    }
+                }
+            }
+            if (cnt) flush();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // swept lights: the walls' verdict; the others: the grid's
+        const unsigned long long shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
+        blocked = dark | (shadow & unk);
+        __builtin_amdgcn_wave_barrier();
+    }
+    float intensity = 1.f;
+    if (__ballot(dynamic & !saturated)) {        // kernels.cu:261-267, in light order
+        float acc = AMBIENT;
+        for (int i = 0; i < ni; i++) {
+            const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
+            const float d2 = len2(I - p2(cx_l, cy_l));
+            if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+        }
+        if (!saturated) intensity = ms_min(acc, 1.f);
+    }
+    return intensity;
+}
+
+// ------------------------------------------------------------------------------------------------
 // render = draw + raycast + shader                                            kernels.cu:297-475
 // ------------------------------------------------------------------------------------------------
 #ifndef MS_GROUPS
@@ -411,10 +551,20 @@ template <int IMPL, int RW>
 __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans) {
-    __shared__ Cand  s_cand[RW][WAVE];       // the chunk's 64 lines
-    __shared__ float s_screen[RW][3*WAVE];
+    // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
+    //      0 cand   (64 x 16 B)  the chunk's 64 lines               | lighting: (wall, light) pair list, 2 KiB
+    //   1024 ray    (64 x 16 B)  per ray: rx, ry, near              |
+    //   2048 best   (64 x 8 B)   per ray: least key                 | lighting: shadow words, 512 B
+    //   2560 second, 3072 third                                     |
+    //   3584 info   (64 x 4 B)   per line: (first pair << 6) | first ray
+    //   3840 mark   (64 x 4 B)   pair window: which line starts here
+    //   4096 screen (192 x 4 B)  RGB staging
+    constexpr int LDS_PER_WAVE = 4864;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);
+    float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][4096]);
 
     // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
     // logical blocks so the fans of one env (and its lines) stay behind one L2.
@@ -497,14 +647,16 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         // wall corner, coincident walls): with the third-best clearly behind, the fold of those two in line
         // order settles it; failing that the ray is re-done by the literal sequential fold below.
         // ------------------------------------------------------------------------------------------
-        __shared__ int s_info[RW][WAVE];                   // per line: (first pair << 6) | first ray
-        __shared__ int s_mark[RW][WAVE];                   // pair window: which line starts here
-        __shared__ float4 s_ray[RW][WAVE];                 // per ray: rx, ry, near
-        __shared__ unsigned long long s_best[RW][WAVE], s_second[RW][WAVE], s_third[RW][WAVE];
-        s_ray[wave][lane] = make_float4(rx, ry, near, 0.f);
-        s_best[wave][lane] = ~0ull;
-        s_second[wave][lane] = ~0ull;
-        s_third[wave][lane] = ~0ull;
+        float4* const s_ray_w = reinterpret_cast<float4*>(&s_raw[wave][1024]);
+        unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][2048]);
+        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][2560]);
+        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][3072]);
+        int* const s_info_w = reinterpret_cast<int*>(&s_raw[wave][3584]);
+        int* const s_mark_w = reinterpret_cast<int*>(&s_raw[wave][3840]);
+        s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
+        s_best_w[lane] = ~0ull;
+        s_second_w[lane] = ~0ull;
+        s_third_w[lane] = ~0ull;
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection into LDS, and the
         // conservative interval [lo, lo + len) of this wave's rays that can hit it
@@ -524,7 +676,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             }
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
             const float dbx = w.z - pp.x, dby = w.w - pp.y;
-            s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
+            s_cand_w[lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
             // agent-frame coordinates of both endpoints
             float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
             float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
@@ -552,24 +704,24 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
-            s_info[wave][lane] = (first << 6) | (lo & 63);
+            s_info_w[lane] = (first << 6) | (lo & 63);
             int carry = -1;
             for (int p0 = 0; p0 < P; p0 += WAVE) {
                 // which line owns pair p0 + lane: lines mark their first pair, a max-scan spreads the marks
-                s_mark[wave][lane] = -1;
-                if ((len > 0) & (first >= p0) & (first < p0 + WAVE)) s_mark[wave][first - p0] = lane;
+                s_mark_w[lane] = -1;
+                if ((len > 0) & (first >= p0) & (first < p0 + WAVE)) s_mark_w[first - p0] = lane;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int owner = max(wave_scan_max(s_mark[wave][lane]), carry);
+                const int owner = max(wave_scan_max(s_mark_w[lane]), carry);
                 carry = __builtin_amdgcn_readlane(owner, 63);
                 const int p = p0 + lane;
                 const bool valid = p < P;
                 const int j = valid ? owner : 0;
-                const int info = s_info[wave][j];
+                const int info = s_info_w[j];
                 const int rr = valid ? (info & 63) + (p - (info >> 6)) : 0;  // ray of this pair, wave-local
-                const Cand cd = s_cand[wave][j];
-                const float4 ray = s_ray[wave][rr];
+                const Cand cd = s_cand_w[j];
+                const float4 ray = s_ray_w[rr];
                 const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
                 const float nt = cd.pqx*ray.y - cd.pqy*ray.x;                // cross(PQ, ru)
                 const float ad = fabsf(d);
@@ -581,12 +733,12 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                     if (ray.z < sv) {                                        // beyond the near plane, kernels.cu:369
                         const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)(c0 + j);
                         // keep the three smallest keys: whatever loses at one level drops to the next
-                        const unsigned long long old1 = atomicMin(&s_best[wave][rr], key);
+                        const unsigned long long old1 = atomicMin(&s_best_w[rr], key);
                         const unsigned long long lose1 = old1 > key ? old1 : key;
                         if (lose1 != ~0ull) {
-                            const unsigned long long old2 = atomicMin(&s_second[wave][rr], lose1);
+                            const unsigned long long old2 = atomicMin(&s_second_w[rr], lose1);
                             const unsigned long long lose2 = old2 > lose1 ? old2 : lose1;
-                            if (lose2 != ~0ull) atomicMin(&s_third[wave][rr], lose2);
+                            if (lose2 != ~0ull) atomicMin(&s_third_w[rr], lose2);
                         }
                     }
                 }
@@ -595,7 +747,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long best = s_best[wave][lane], second = s_second[wave][lane], third = s_third[wave][lane];
+        const unsigned long long best = s_best_w[lane], second = s_second_w[lane], third = s_third_w[lane];
         bool ambiguous = false;
         if (best != ~0ull) {
             const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
@@ -645,7 +797,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                     const unsigned long long span = ((jhi >= 63) ? ~0ull : ((2ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull);
                     if (!(span & amb)) continue;
                     if (ambiguous & (lane >= jlo) & (lane <= jhi)) {
-                        const Cand cd = s_cand[wave][j];
+                        const Cand cd = s_cand_w[j];
                         const float d = rx*cd.vy - ry*cd.vx;
                         const float nt = cd.pqx*ry - cd.pqy*rx;
                         const float ad = fabsf(d);
@@ -715,7 +867,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                 const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
                 const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
                 const float dbx = w.z - pp.x, dby = w.w - pp.y;
-                s_cand[wave][lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
+                s_cand_w[lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
                 // agent-frame coordinates of both endpoints
                 float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
                 float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
@@ -759,7 +911,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                 const bool active = my_mask != 0ull;
                 const int j = active ? __ffsll((long long)my_mask) - 1 : 0;
                 my_mask &= my_mask - 1ull;
-                const Cand cd = s_cand[wave][j];
+                const Cand cd = s_cand_w[j];
                 const float d = rx*cd.vy - ry*cd.vx;                       // cross(ru, v)
                 const float nt = cd.pqx*ry - cd.pqy*rx;                    // cross(PQ, ru)
                 const float ad = fabsf(d);
@@ -800,24 +952,32 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     }
 
     // ---- pass 3: shade (kernels.cu:407-450)
+    const bool is_hit = (nearest_idx >= 0) & (r < R);
+    const bool dynamic = is_hit & (nearest_idx < AF);
+    float intensity = 0.f;
+    // Rays that landed on an agent (dynamic) are lit from the lights (kernels.cu:432-436).  With a light grid
+    // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
+    // ray group is queued for dynlight_kernel, launched right behind this kernel.
+    if (__ballot(dynamic)) {
+        if (sc.lg_vals) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
+            intensity = grid_light_intensity(sc, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
+                reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]));
+        } else if (out.workspace) {
+            if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
+        }
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     Filt f = Filt{0, 0, 0.f, 0.f};
     int tstart = 0;
-    const bool is_hit = (nearest_idx >= 0) & (r < R);
     if (is_hit) {
         const int start = base + nearest_idx;
         f = tex_filter(loc, sc.textures_widths[start]);
         tstart = sc.textures_starts[start];
     }
-    float intensity = 0.f;
-    const bool dynamic = is_hit & (nearest_idx < AF);
     if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
-
-    // Rays that landed on an agent (dynamic) are lit by dynlight_kernel, launched right behind this one;
-    // they leave here black, and their ray group is queued for it.
-    if (out.workspace && __ballot(dynamic)) {
-        if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
-    }
 
     if (is_hit) {
         const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
@@ -828,7 +988,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         s2 = dn*intensity*(f.lw*tl[2] + f.rw*tr[2]);
     }
     // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
-    s_screen[wave][3*lane] = s0; s_screen[wave][3*lane + 1] = s1; s_screen[wave][3*lane + 2] = s2;
+    s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -837,7 +997,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int j = lane + k*WAVE;
-        if (j < nfl) scr[j] = s_screen[wave][j];
+        if (j < nfl) scr[j] = s_screen_w[j];
     }
 }
 
@@ -862,7 +1022,6 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
 //     surviving (wall, light) pairs are compacted into the wave's LDS pair list.
 //   * lane = pair, loop over the open rays: the reference's obstructed() test; a hit ORs the light's
 //     bit into that ray's shadow words (LDS atomic, shared by the four waves).
-struct LightPair { float ax, ay, vx, vy, ix, iy; int light; int pad; };
 
 __global__ __launch_bounds__(WG) void dynlight_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out, const int R) {
@@ -1036,188 +1195,6 @@ __global__ __launch_bounds__(WG) void dynlight_kernel(
     }
     if (dynamic & (wave == 0)) {                             // kernels.cu:441-445
         const float intensity = saturated ? 1.f : ms_min(acc, 1.f);
-        const float dn = 1 - dt*dt;
-        out.screen[3*o]     = dn*intensity*(f.lw*t0[0] + f.rw*t1[0]);
-        out.screen[3*o + 1] = dn*intensity*(f.lw*t0[1] + f.rw*t1[1]);
-        out.screen[3*o + 2] = dn*intensity*(f.lw*t0[2] + f.rw*t1[2]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// dynamic lighting with the light grid
-// ------------------------------------------------------------------------------------------------
-// Same job and launch shape as dynlight_kernel, for sceneries that carry a light grid (MsScenery.lg_vals,
-// filled by ms_bake) and have at most 64 lights per env.  Each agent-hit ray looks up the cell its hit point
-// is in: lights the grid marks LIT are unblocked, DARK ones blocked - exactly, see lightgrid_kernel - and
-// usually that settles the ray (no UNKNOWN light, or the LIT ones already saturate the sum).  Only what is
-// left - rays with UNKNOWN lights, those lights only - goes through the corridor sweep + exact tests.
-__global__ __launch_bounds__(WG) void dynlight_grid_kernel(
-        const MsScenery sc, const MsAgents ag, const MsRender out, const int R) {
-    __shared__ LightPair s_pair[WAVES][PAIRS];
-    __shared__ unsigned s_shadow[2*WAVE];        // per ray: 64 light bits, OR-ed by all waves
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int fan = blockIdx.x;
-    if (out.workspace) {                         // compact list from render_kernel: the busy groups start first
-        if (fan >= out.workspace[0]) return;
-        fan = out.workspace[16 + fan];
-    }
-    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int G = (R + WAVE - 1)/WAVE, F = A*G;
-    const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
-    const int r = g*WAVE + lane;
-    const size_t o = ((size_t)n*A + a)*R + r;
-    // everything that does not depend on the indices is requested before they are looked at
-    const int L = sc.lines_widths[n];
-    const int base = sc.lines_starts[n];
-    const int ni = sc.lights_widths[n];          // <= 64, checked by the host
-    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
-    const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
-    const int lg_base = sc.lg_starts[n];
-    float Ix = 0.f, Iy = 0.f, Ii = 0.f;          // lane i holds light i
-    if (lane < ni) { Ix = lights[3*lane]; Iy = lights[3*lane + 1]; Ii = lights[3*lane + 2]; }
-    int nearest_idx = -1;
-    float loc = 0.f, dt = 0.f;
-    if (r < R) { nearest_idx = out.indices[o]; loc = out.locations[o]; dt = out.dots[o]; }
-    const bool dynamic = (nearest_idx >= 0) & (nearest_idx < AF);
-    if (!__ballot(dynamic)) return;              // uniform across the workgroup: every wave sees the same 64 rays
-
-    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
-    float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
-    Filt f = Filt{0, 0, 0.f, 0.f};
-    float t0[3] = {0.f, 0.f, 0.f}, t1[3] = {0.f, 0.f, 0.f};
-    if (dynamic) {
-        hw = ln[nearest_idx];                               // the agent line render_kernel drew and published (kernels.cu:316-317)
-        const int start = base + nearest_idx;
-        f = tex_filter(loc, sc.textures_widths[start]);
-        const int tstart = sc.textures_starts[start];
-        const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
-        const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
-        #pragma unroll
-        for (int k = 0; k < 3; k++) { t0[k] = tl[k]; t1[k] = tr[k]; }
-    }
-    const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
-    const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
-
-    // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
-    uint4 st = make_uint4(0u, 0u, 0u, 0u);
-    if (dynamic) {
-        const float fx = floorf((cx_l - geom.x)/sc.lg_cell), fy = floorf((cy_l - geom.y)/sc.lg_cell);
-        if ((fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w))
-            st = reinterpret_cast<const uint4*>(sc.lg_vals)[lg_base + (int)fy*(int)geom.z + (int)fx];
-    }
-    const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
-    unsigned long long lit = 0ull, dark = 0ull, need_lights = 0ull;
-    float part = AMBIENT;                        // order-free sum over the lights the grid proves unblocked
-    for (int i = 0; i < ni; i++) {
-        const unsigned wd = (i < 16) ? st.x : (i < 32) ? st.y : (i < 48) ? st.z : st.w;
-        const unsigned s2 = (wd >> (2*(i & 15))) & 3u;
-        if (s2 == 1u) {
-            const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
-            part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
-            lit |= 1ull << i;
-        } else if (s2 == 2u) {
-            dark |= 1ull << i;
-        }
-    }
-    const unsigned long long all = (ni >= 64) ? ~0ull : ((1ull << ni) - 1ull);
-    const unsigned long long unk = ~(lit | dark) & all;
-    // saturated: the reference's min(sum, 1) is exactly 1 whatever the unknown lights do (see dynlight_kernel)
-    const bool saturated = dynamic & shortcut & (part >= 1.001f);
-    const bool need = dynamic & !saturated & (unk != 0ull);
-    for (int i = 0; i < ni; i++) if (__ballot(need & (((unk >> i) & 1ull) != 0ull))) need_lights |= 1ull << i;
-
-    unsigned long long blocked = dark;
-    if (need_lights) {                           // uniform: some ray still has lights to test against the walls
-        if (wave == 0) { s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u; }
-        __syncthreads();
-        unsigned long long todo = __ballot(need);
-        while (todo) {                           // one target agent at a time
-            const int target = __builtin_amdgcn_readlane(my_target, __ffsll((long long)todo) - 1);
-            const bool mine = need & (my_target == target);
-            const unsigned long long open = __ballot(mine);
-            todo &= ~open;
-            // the lights any of this target's rays still needs
-            unsigned long long tl_mask = 0ull;
-            for (unsigned long long m = need_lights; m; m &= m - 1) {
-                const int i = __ffsll((long long)m) - 1;
-                if (__ballot(mine & (((unk >> i) & 1ull) != 0ull))) tl_mask |= 1ull << i;
-            }
-            const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
-            // extent of the hit points around the target, + float slack
-            float rho = mine ? sqrtf((cx_l - T.x)*(cx_l - T.x) + (cy_l - T.y)*(cy_l - T.y)) : 0.f;
-            rho = wave_max_f(rho) + 2e-3f + 1e-4f*(fabsf(T.x) + fabsf(T.y));
-            // corridor frame of light `lane`: unit vector e from the light to the target, length el
-            const float dx = T.x - Ix, dy = T.y - Iy;
-            const float el = sqrtf(dx*dx + dy*dy);
-            const float ex = dx/el, ey = dy/el;
-
-            int cnt = 0;
-            auto flush = [&]() {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (int p0 = 0; p0 < cnt; p0 += WAVE) {
-                    const LightPair pr = s_pair[wave][min(p0 + lane, cnt - 1)];
-                    const P2 I = p2(pr.ix, pr.iy);
-                    for (unsigned long long rays = open; rays; rays &= rays - 1) {
-                        const int jr = __ffsll((long long)rays) - 1;
-                        const P2 C = p2(readlane_f(cx_l, jr), readlane_f(cy_l, jr));
-                        if ((p0 + lane < cnt) && light_blocked(I, C - I, pr.ax, pr.ay, pr.vx, pr.vy))
-                            atomicOr(&s_shadow[2*jr + (pr.light >> 5)], 1u << (pr.light & 31));
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                cnt = 0;
-            };
-            // this wave's share of the walls: chunks wave, wave + 4, ...
-            const int first = AF + wave*WAVE;
-            float4 wn = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (first + lane < L) wn = ln[first + lane];
-            for (int l0 = first; l0 < L; l0 += WAVES*WAVE) {
-                const bool live = l0 + lane < L;
-                const float4 w = wn;
-                if (l0 + WAVES*WAVE + lane < L) wn = ln[l0 + WAVES*WAVE + lane];      // next chunk in flight
-                // wall relative to the target, and its margin
-                const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
-                const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
-                for (unsigned long long lm = tl_mask; lm; lm &= lm - 1) {
-                    const int i = __ffsll((long long)lm) - 1;
-                    const float cex = readlane_f(ex, i), cey = readlane_f(ey, i), cel = readlane_f(el, i);
-                    // coordinates along / across the corridor, origin at the target, light at -cel
-                    const float ua = cex*ax + cey*ay, va = cex*ay - cey*ax;
-                    const float ub = cex*bx + cey*by, vb = cex*by - cey*bx;
-                    const bool outside = ((ua > m) & (ub > m)) | ((ua < -cel - m) & (ub < -cel - m)) |
-                                         ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
-                    const bool keep = live & !outside;
-                    const unsigned long long km = __ballot(keep);
-                    if (km) {
-                        const int nk = __popcll(km);
-                        if (cnt + nk > PAIRS) flush();
-                        if (keep) s_pair[wave][cnt + __popcll(km & ((1ull << lane) - 1ull))] =
-                            LightPair{w.x, w.y, w.z - w.x, w.w - w.y, readlane_f(Ix, i), readlane_f(Iy, i), i, 0};
-                        cnt += nk;
-                    }
-                }
-            }
-            if (cnt) flush();
-        }
-        __syncthreads();
-        // swept lights: the walls' verdict; the others: the grid's
-        const unsigned long long shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
-        blocked = dark | (shadow & unk);
-    }
-    if (dynamic & (wave == 0)) {                             // kernels.cu:261-267, 441-445
-        float intensity = 1.f;
-        if (!saturated) {
-            float acc = AMBIENT;
-            for (int i = 0; i < ni; i++) {                   // in light order
-                const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
-                const float d2 = len2(I - p2(cx_l, cy_l));
-                if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
-            }
-            intensity = ms_min(acc, 1.f);
-        }
         const float dn = 1 - dt*dt;
         out.screen[3*o]     = dn*intensity*(f.lw*t0[0] + f.rw*t1[0]);
         out.screen[3*o + 1] = dn*intensity*(f.lw*t0[1] + f.rw*t1[1]);
@@ -1479,20 +1456,22 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
         hipLaunchKernelGGL(render_prep_kernel, dim3((na + WG - 1)/WG), dim3(WG), 0, (hipStream_t)stream,
                            *ag, out->workspace, na, (int)n_fans);
     }
+    // the light grid is all or nothing: render_kernel lights agent-hit rays itself when it is there
+    MsScenery scn = *sc;
+    const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
+    if (!grid) scn.lg_vals = nullptr;
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     if (seq)
         hipLaunchKernelGGL((render_kernel<0, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
     else
         hipLaunchKernelGGL((render_kernel<1, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           *sc, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
-    if (sc->n_agents > 1) {  // with one agent per env no ray can land on an agent line (own lines sit inside the near plane)
-        if (sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f)
-            hipLaunchKernelGGL(dynlight_grid_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
-        else
-            hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, *sc, *ag, *out, R);
-    }
+                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+    // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
+    // inside the near plane), so there is nothing to light.
+    if (!grid && sc->n_agents > 1)
+        hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, scn, *ag, *out, R);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
