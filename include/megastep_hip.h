@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 3
+#define MS_ABI_VERSION 4
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -64,17 +64,27 @@ typedef struct MsScenery {
     /* Optional light grid (lg_vals NULL = none; no counterpart in the reference): a per-env uniform grid over the
      * floorplan that caches, for every cell and each of the env's first 64 lights, whether the light reaches the
      * cell.  Written by ms_bake, read by ms_render's dynamic lighting, exact by construction: a cell is only ever
-     * marked when EVERY point in it provably has that status, anything else stays 0 and is worked out per ray.
+     * marked when EVERY point in it provably has that status; anything else stays 0 (unknown) and is worked out
+     * per ray - against the cell's candidate list (the walls that could not be ruled out for the cell and that
+     * light) when it has one, against every wall otherwise.
      *   lg_vals   (sum cells, 4) uint32, 2 bits per light: 0 unknown, 1 lit, 2 dark; must start zeroed
      *   lg_starts (N,)   first cell of env n
      *   lg_geom   (N, 4) float: x and y of the grid's origin, cells along x, cells along y
      *   lg_cell   cell size in metres;  lg_max_cells  max over envs of cells (launch bound for ms_bake)
+     *   lg_list   (sum cells, 2) uint32, optional (NULL together with lg_pool), must start zeroed:
+     *             [first pool word of the cell's candidates, 0x80000000 | how many]; second word 0 = no list
+     *   lg_pool   (lg_pool_size,) uint32: word 0 is ms_bake's allocation cursor, then candidates
+     *             0x80000000 | light << 24 | wall (index among the env's static lines).  A pool that runs out
+     *             only costs speed: the cells that did not fit go without a list.
      * Only for sceneries with at most 64 lights in every env: pass lg_vals = NULL otherwise. */
     unsigned*    lg_vals;
     const int*   lg_starts;
     const float* lg_geom;
     float        lg_cell;
     int          lg_max_cells;
+    unsigned*    lg_list;
+    unsigned*    lg_pool;
+    int          lg_pool_size;
 } MsScenery;
 
 /* Replaces `Agents` (common.h:157-177). Updated IN PLACE by ms_physics. */

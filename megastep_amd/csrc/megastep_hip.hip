@@ -373,46 +373,112 @@ __device__ inline float grid_light_intensity(
 
     // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
     uint4 st = make_uint4(0u, 0u, 0u, 0u);
+    uint2 lst = make_uint2(0u, 0u);              // the cell's candidate list: first pool word, 0x80000000 | count
     if (dynamic) {
         const float fx = floorf((cx_l - geom.x)/sc.lg_cell), fy = floorf((cy_l - geom.y)/sc.lg_cell);
-        if ((fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w))
-            st = reinterpret_cast<const uint4*>(sc.lg_vals)[sc.lg_starts[n] + (int)fy*(int)geom.z + (int)fx];
-    }
-    const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
-    unsigned long long lit = 0ull, dark = 0ull, need_lights = 0ull;
-    float part = AMBIENT;                        // order-free sum over the lights the grid proves unblocked
-    for (int i = 0; i < ni; i++) {
-        const unsigned wd = (i < 16) ? st.x : (i < 32) ? st.y : (i < 48) ? st.z : st.w;
-        const unsigned s2 = (wd >> (2*(i & 15))) & 3u;
-        if (s2 == 1u) {
-            const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
-            part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
-            lit |= 1ull << i;
-        } else if (s2 == 2u) {
-            dark |= 1ull << i;
+        if ((fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w)) {
+            const size_t cell_id = (size_t)sc.lg_starts[n] + (int)fy*(int)geom.z + (int)fx;
+            st = reinterpret_cast<const uint4*>(sc.lg_vals)[cell_id];
+            if (sc.lg_list) lst = reinterpret_cast<const uint2*>(sc.lg_list)[cell_id];
         }
     }
-    const unsigned long long all = (ni >= 64) ? ~0ull : ((1ull << ni) - 1ull);
-    const unsigned long long unk = ~(lit | dark) & all;
+    const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
+    // ---- the sum over the lights the grid proves unblocked, in light order.  Rays around one target mostly share
+    // a cell, so: one pass per distinct verdict word set, scalar loop over its LIT bits (01 in the 2-bit fields)
+    float part = AMBIENT;
+    for (unsigned long long rem = __ballot(dynamic); rem; ) {
+        const int j = __ffsll((long long)rem) - 1;
+        const unsigned sw[4] = {(unsigned)__builtin_amdgcn_readlane((int)st.x, j), (unsigned)__builtin_amdgcn_readlane((int)st.y, j),
+                                (unsigned)__builtin_amdgcn_readlane((int)st.z, j), (unsigned)__builtin_amdgcn_readlane((int)st.w, j)};
+        const bool same = dynamic & (st.x == sw[0]) & (st.y == sw[1]) & (st.z == sw[2]) & (st.w == sw[3]);
+        rem &= ~__ballot(same);
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            for (unsigned lw = sw[k] & ~(sw[k] >> 1) & 0x55555555u; lw; lw &= lw - 1) {
+                const int i = 16*k + ((__ffs((int)lw) - 1) >> 1);
+                const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
+                if (same) part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+            }
+        }
+    }
+    // does the grid leave any of this ray's lights open?  (fields 00, among the first ni)
+    bool has_unk = false;
+    {
+        const unsigned wd[4] = {st.x, st.y, st.z, st.w};
+        #pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int nv = min(max(ni - 16*k, 0), 16);
+            const unsigned valid = (nv == 16) ? 0x55555555u : (((1u << (2*nv)) - 1u) & 0x55555555u);
+            has_unk |= (~(wd[k] | (wd[k] >> 1)) & valid) != 0u;
+        }
+    }
     // saturated: the reference's min(sum, 1) is exactly 1 whatever the unknown lights do (see dynlight_kernel)
     const bool saturated = dynamic & shortcut & (part >= 1.001f);
-    const bool need = dynamic & !saturated & (unk != 0ull);
-    for (int i = 0; i < ni; i++) if (__ballot(need & (((unk >> i) & 1ull) != 0ull))) need_lights |= 1ull << i;
+    const bool need = dynamic & !saturated & has_unk;
+    // Everyone else is done: with no light left open the reference's in-order sum over the unblocked lights IS `part`
+    if (!__ballot(need)) return saturated ? 1.f : ms_min(part, 1.f);
 
-    unsigned long long blocked = dark;
-    if (need_lights) {                           // uniform: some ray still has lights to test against the walls
+    // ---- the rest is the rare path: rays with lights the grid leaves open
+    auto status = [&](int i) {                   // light i's 2-bit verdict for this ray's cell; i is wave-uniform
+        const unsigned wd = (i < 16) ? st.x : (i < 32) ? st.y : (i < 48) ? st.z : st.w;
+        return (wd >> (2*(i & 15))) & 3u;
+    };
+    unsigned long long shadow = 0ull;            // open lights the walls turn out to block
+    // (1) rays whose cell has a candidate list: only those (light, wall) pairs can matter anywhere in the cell.
+    // All the wave's (ray, candidate) pairs are laid end to end and dealt to the lanes, 64 at a time, so that the
+    // dependent loads (candidate -> wall) are paid once per round rather than once per candidate.
+    const bool sweep = need & (lst.y == 0u);     // no list (outside the grid, pool exhausted, ...): all the walls
+    const int n_cd = (need & !sweep) ? (int)(lst.y & 0x7fffffffu) : 0;
+    if (__ballot(n_cd > 0)) {
         s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u;
-        unsigned long long todo = __ballot(need);
-        while (todo) {                           // one target agent at a time
+        int pj = -1, pk = 0, fill = 0;           // this lane's pair: ray, candidate; lanes dealt so far
+        auto round = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int src = max(pj, 0);
+            const int at = __shfl((int)lst.x, src, WAVE) + pk;
+            const P2 C = p2(__shfl(cx_l, src, WAVE), __shfl(cy_l, src, WAVE));
+            if (pj >= 0) {
+                const unsigned e = sc.lg_pool[at];
+                const int i = (int)((e >> 24) & 63u);
+                const float4 w = ln[AF + (int)(e & 0xffffffu)];
+                const P2 I = p2(lights[3*i], lights[3*i + 1]);
+                if (light_blocked(I, C - I, w.x, w.y, w.z - w.x, w.w - w.y)) atomicOr(&s_shadow[2*pj + (i >> 5)], 1u << (i & 31));
+            }
+            pj = -1; fill = 0;
+        };
+        for (unsigned long long rays = __ballot(n_cd > 0); rays; rays &= rays - 1) {
+            const int j = __ffsll((long long)rays) - 1;
+            const int c = __builtin_amdgcn_readlane(n_cd, j);
+            for (int k0 = 0; k0 < c; ) {
+                const int take = min(c - k0, WAVE - fill);
+                if ((lane >= fill) & (lane < fill + take)) { pj = j; pk = k0 + lane - fill; }
+                fill += take; k0 += take;
+                if (fill == WAVE) round();
+            }
+        }
+        if (fill) round();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (n_cd > 0) shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // (2) rays without a list: the corridor sweep over all the walls, one target agent at a time
+    if (__ballot(sweep)) {
+        unsigned long long need_lights = 0ull;
+        for (int i = 0; i < ni; i++) if (__ballot(sweep & (status(i) == 0u))) need_lights |= 1ull << i;
+        s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u;
+        unsigned long long todo = __ballot(sweep);
+        while (todo) {
             const int target = __builtin_amdgcn_readlane(my_target, __ffsll((long long)todo) - 1);
-            const bool mine = need & (my_target == target);
+            const bool mine = sweep & (my_target == target);
             const unsigned long long open = __ballot(mine);
             todo &= ~open;
             // the lights any of this target's rays still needs
             unsigned long long tl_mask = 0ull;
             for (unsigned long long m = need_lights; m; m &= m - 1) {
                 const int i = __ffsll((long long)m) - 1;
-                if (__ballot(mine & (((unk >> i) & 1ull) != 0ull))) tl_mask |= 1ull << i;
+                if (__ballot(mine & (status(i) == 0u))) tl_mask |= 1ull << i;
             }
             const float2 T = reinterpret_cast<const float2*>(ag.positions)[n*A + target];
             // extent of the hit points around the target, + float slack
@@ -440,10 +506,11 @@ __device__ inline float grid_light_intensity(
                 cnt = 0;
             };
             for (int l0 = AF; l0 < L; l0 += WAVE) {
+                // lane = wall: a wall can only shadow the target from a light if it reaches into the corridor
+                // light -> target; surviving (wall, light) pairs go to the LDS pair list
                 const bool live = l0 + lane < L;
                 float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live) w = ln[l0 + lane];
-                // wall relative to the target, and its margin
                 const float ax = w.x - T.x, ay = w.y - T.y, bx = w.z - T.x, by = w.w - T.y;
                 const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
                 for (unsigned long long lm = tl_mask; lm; lm &= lm - 1) {
@@ -468,21 +535,19 @@ __device__ inline float grid_light_intensity(
             if (cnt) flush();
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // swept lights: the walls' verdict; the others: the grid's
-        const unsigned long long shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
-        blocked = dark | (shadow & unk);
+        if (sweep) shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
         __builtin_amdgcn_wave_barrier();
     }
-    float intensity = 1.f;
-    if (__ballot(dynamic & !saturated)) {        // kernels.cu:261-267, in light order
-        float acc = AMBIENT;
-        for (int i = 0; i < ni; i++) {
-            const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
-            const float d2 = len2(I - p2(cx_l, cy_l));
-            if (!((blocked >> i) & 1ull)) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
-        }
-        if (!saturated) intensity = ms_min(acc, 1.f);
+    // (3) the reference's sum (kernels.cu:261-267) in light order: the grid's verdict where it has one, else the walls'
+    float acc = AMBIENT;
+    for (int i = 0; i < ni; i++) {
+        const unsigned s2 = status(i);
+        const bool unblocked = (s2 == 1u) | ((s2 == 0u) & !((shadow >> i) & 1ull));
+        const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
+        const float d2 = len2(I - p2(cx_l, cy_l));
+        if (need & unblocked) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
     }
+    const float intensity = saturated ? 1.f : ms_min(need ? acc : part, 1.f);
     return intensity;
 }
 
@@ -1282,14 +1347,79 @@ __global__ __launch_bounds__(WG) void bake_kernel(const MsScenery sc) {
 //         s in (d, .999-d), d = 2e-3, ~1e3 rounding errors).  For a fixed light and wall those conditions are
 //         affine inequalities in the point, so they hold on the whole cell, and obstructed() is true there.
 //   else  the cell stays UNKNOWN (0) for that light and ms_render tests rays in it against the walls.
+//   else  the cell stays UNKNOWN (0) for that light and ms_render tests rays in it against walls - against the
+//         cell's CANDIDATES for that light, the walls the LIT test could not rule out: any other wall provably
+//         blocks no point of the cell (the LIT argument, wall by wall).  lightlist_kernel, a second pass, collects
+//         them: (light, wall) pairs of the cell's unknown lights, stored back to back in a pool (lg_pool) that
+//         cells draw from with an atomic cursor; a cell whose list does not fit (pool exhausted, or more than
+//         LG_MAX_CANDS pairs - only cells far outside the walls) gets no list and its rays meet every wall.
 constexpr float LG_SLACK = 0.01f;
 constexpr int LG_LIGHTS = 64;          // lights per env the grid covers
+constexpr int LG_MAX_CANDS = 96;       // longest candidate list a cell may have
+
+struct LgCell {                        // a grid cell grown by LG_SLACK
+    float x0, y0, x1, y1, rho;
+    P2 ctr;
+};
+struct LgView {                        // the cell as one light sees it
+    P2 I, U0, U1, U2, U3;              // light; corners relative to it
+    float ex, ey, el;                  // corridor frame: unit vector light -> cell centre, its length
+};
+
+__device__ inline LgCell lg_cell_of(const float4 geom, const float cell, const int c) {
+    const int nx = (int)geom.z;
+    const int ix = c % nx, iy = c / nx;
+    LgCell k;
+    k.x0 = geom.x + ix*cell - LG_SLACK; k.y0 = geom.y + iy*cell - LG_SLACK;
+    k.x1 = k.x0 + cell + 2*LG_SLACK;    k.y1 = k.y0 + cell + 2*LG_SLACK;
+    k.ctr = p2(.5f*(k.x0 + k.x1), .5f*(k.y0 + k.y1));
+    k.rho = .5f*sqrtf((k.x1 - k.x0)*(k.x1 - k.x0) + (k.y1 - k.y0)*(k.y1 - k.y0)) + 5e-3f + 1e-4f*(fabsf(k.ctr.x) + fabsf(k.ctr.y));
+    return k;
+}
+
+__device__ inline LgView lg_view_of(const LgCell& k, const P2 I) {
+    LgView v;
+    v.I = I;
+    const float dx = k.ctr.x - I.x, dy = k.ctr.y - I.y;
+    v.el = sqrtf(dx*dx + dy*dy);
+    v.ex = dx/v.el; v.ey = dy/v.el;
+    v.U0 = p2(k.x0, k.y0) - I; v.U1 = p2(k.x1, k.y0) - I; v.U2 = p2(k.x1, k.y1) - I; v.U3 = p2(k.x0, k.y1) - I;
+    return v;
+}
+
+// Can wall w = (ax, ay, vx, vy) shadow any point of the cell from the light?  false only when provably not.
+__device__ inline bool lg_touches(const LgCell& k, const LgView& v, const float4 w) {
+    const float ax = w.x - k.ctr.x, ay = w.y - k.ctr.y, bx = ax + w.z, by = ay + w.w;
+    const float m = k.rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
+    const float ua = v.ex*ax + v.ey*ay, va = v.ex*ay - v.ey*ax;
+    const float ub = v.ex*bx + v.ey*by, vb = v.ex*by - v.ey*bx;
+    const bool outside = ((ua > m) & (ub > m)) | ((ua < -v.el - m) & (ub < -v.el - m)) |
+                         ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
+    if (outside) return false;                   // nowhere near the corridor light -> cell; NaNs fall through to true
+    // Near the corridor, but does its shadow - the wedge behind the wall as seen from the light, bounded by the
+    // lines light-a, light-b and the wall itself - reach the cell at all?  Not if all four corners lie, by 5 mm,
+    // beyond one of those three lines.
+    const P2 V = p2(w.z, w.w), PQ = p2(w.x, w.y) - v.I, PB = PQ + V;
+    constexpr float MG2 = 5e-3f*5e-3f;
+    const float sb = cross(PQ, PB);                                  // which side of light-a is b on
+    const float la2 = len2(PQ), lb2 = len2(PB), lv2 = len2(V);
+    const float a0 = cross(PQ, v.U0), a1 = cross(PQ, v.U1), a2 = cross(PQ, v.U2), a3 = cross(PQ, v.U3);
+    const float b0 = cross(PB, v.U0), b1 = cross(PB, v.U1), b2 = cross(PB, v.U2), b3 = cross(PB, v.U3);
+    const float si = -cross(V, PQ);                                  // which side of the wall is the light on
+    const float w0_ = cross(V, v.U0 - PQ), w1_ = cross(V, v.U1 - PQ), w2_ = cross(V, v.U2 - PQ), w3_ = cross(V, v.U3 - PQ);
+    auto beyond = [](float side, float c, float l2) { return (side*c < 0.f) & (c*c > MG2*l2); };
+    auto same = [](float side, float c, float l2) { return (side*c > 0.f) & (c*c > MG2*l2); };
+    const bool opp_a = beyond(sb, a0, la2) & beyond(sb, a1, la2) & beyond(sb, a2, la2) & beyond(sb, a3, la2);
+    const bool opp_b = beyond(-sb, b0, lb2) & beyond(-sb, b1, lb2) & beyond(-sb, b2, lb2) & beyond(-sb, b3, lb2);
+    const bool front = same(si, w0_, lv2) & same(si, w1_, lv2) & same(si, w2_, lv2) & same(si, w3_, lv2);
+    return !(opp_a | opp_b | front);
+}
 
 __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
     __shared__ float4 s_wall[BAKE_WALLS];        // (ax, ay, vx, vy)
     const int n = blockIdx.y, tid = threadIdx.x;
     const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
-    const int nx = (int)geom.z, ncell = nx*(int)geom.w;
+    const int ncell = (int)geom.z*(int)geom.w;
     if ((int)blockIdx.x*WG >= ncell) return;     // uniform: whole workgroups leave together
     const int c = blockIdx.x*WG + tid;
     const bool live = c < ncell;
@@ -1299,12 +1429,7 @@ __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
     const int num_i = min(sc.lights_widths[n], LG_LIGHTS);
     const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
     const int n_walls = max(L - AF, 0);
-    const float cell = sc.lg_cell;
-    const int ix = c % nx, iy = c / nx;
-    const float x0 = geom.x + ix*cell - LG_SLACK, y0 = geom.y + iy*cell - LG_SLACK;
-    const float x1 = x0 + cell + 2*LG_SLACK, y1 = y0 + cell + 2*LG_SLACK;
-    const P2 ctr = p2(.5f*(x0 + x1), .5f*(y0 + y1));
-    const float rho = .5f*sqrtf((x1 - x0)*(x1 - x0) + (y1 - y0)*(y1 - y0)) + 5e-3f + 1e-4f*(fabsf(ctr.x) + fabsf(ctr.y));
+    const LgCell k = lg_cell_of(geom, sc.lg_cell, c);
     unsigned long long touched = 0ull, dark = 0ull;
 
     for (int w0 = 0; w0 < n_walls; w0 += BAKE_WALLS) {       // uniform trip count: barriers are safe
@@ -1319,49 +1444,19 @@ __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
         for (int i = 0; i < num_i; i++) {
             const unsigned long long bit = 1ull << i;
             if (dark & bit) continue;
-            const P2 I = p2(lights[3*i], lights[3*i + 1]);
-            // corridor frame: unit vector e from the light to the cell centre, length el
-            const float dx = ctr.x - I.x, dy = ctr.y - I.y;
-            const float el = sqrtf(dx*dx + dy*dy);
-            const float ex = dx/el, ey = dy/el;
-            // the four corners as seen from the light
-            const P2 U0 = p2(x0, y0) - I, U1 = p2(x1, y0) - I, U2 = p2(x1, y1) - I, U3 = p2(x0, y1) - I;
-            for (int k = 0; k < staged; k++) {
-                const float4 w = s_wall[k];
-                const float ax = w.x - ctr.x, ay = w.y - ctr.y, bx = ax + w.z, by = ay + w.w;
-                const float m = rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
-                const float ua = ex*ax + ey*ay, va = ex*ay - ey*ax;
-                const float ub = ex*bx + ey*by, vb = ex*by - ey*bx;
-                const bool outside = ((ua > m) & (ub > m)) | ((ua < -el - m) & (ub < -el - m)) |
-                                     ((va > m) & (vb > m)) | ((va < -m) & (vb < -m));
-                if (outside) continue;                       // NaNs fall through to `touched`
-                // Near the corridor, but does its shadow - the wedge behind the wall as seen from the light,
-                // bounded by the lines light-a, light-b and the wall itself - reach the cell at all?  Not if all
-                // four corners lie, by 5 mm, beyond one of those three lines.
-                const P2 V = p2(w.z, w.w), PQ = p2(w.x, w.y) - I, PB = PQ + V;
-                {
-                    constexpr float MG2 = 5e-3f*5e-3f;
-                    const float sb = cross(PQ, PB);                                  // which side of light-a is b on
-                    const float la2 = len2(PQ), lb2 = len2(PB), lv2 = len2(V);
-                    const float a0 = cross(PQ, U0), a1 = cross(PQ, U1), a2 = cross(PQ, U2), a3 = cross(PQ, U3);
-                    const float b0 = cross(PB, U0), b1 = cross(PB, U1), b2 = cross(PB, U2), b3 = cross(PB, U3);
-                    const float si = -cross(V, PQ);                                  // which side of the wall is the light on
-                    const float w0_ = cross(V, U0 - PQ), w1_ = cross(V, U1 - PQ), w2_ = cross(V, U2 - PQ), w3_ = cross(V, U3 - PQ);
-                    auto beyond = [](float side, float c, float l2) { return (side*c < 0.f) & (c*c > MG2*l2); };
-                    auto same = [](float side, float c, float l2) { return (side*c > 0.f) & (c*c > MG2*l2); };
-                    const bool opp_a = beyond(sb, a0, la2) & beyond(sb, a1, la2) & beyond(sb, a2, la2) & beyond(sb, a3, la2);
-                    const bool opp_b = beyond(-sb, b0, lb2) & beyond(-sb, b1, lb2) & beyond(-sb, b2, lb2) & beyond(-sb, b3, lb2);
-                    const bool front = same(si, w0_, lv2) & same(si, w1_, lv2) & same(si, w2_, lv2) & same(si, w3_, lv2);
-                    if (opp_a | opp_b | front) continue;
-                }
+            const LgView v = lg_view_of(k, p2(lights[3*i], lights[3*i + 1]));
+            for (int j = 0; j < staged; j++) {
+                const float4 w = s_wall[j];
+                if (!lg_touches(k, v, w)) continue;
                 touched |= bit;
                 // does this wall shadow the whole cell?
+                const P2 V = p2(w.z, w.w), PQ = p2(w.x, w.y) - v.I;
                 const float c1 = cross(PQ, V);
-                const float d0 = cross(U0, V), d1 = cross(U1, V), d2 = cross(U2, V), d3 = cross(U3, V);
+                const float d0 = cross(v.U0, V), d1 = cross(v.U1, V), d2 = cross(v.U2, V), d3 = cross(v.U3, V);
                 const float sg = d0 < 0.f ? -1.f : 1.f;
                 const float e0 = sg*d0, e1 = sg*d1, e2 = sg*d2, e3 = sg*d3, cc = sg*c1;
                 bool full = (e0 >= 1e-2f) & (e1 >= 1e-2f) & (e2 >= 1e-2f) & (e3 >= 1e-2f);
-                const float n0 = sg*cross(PQ, U0), n1 = sg*cross(PQ, U1), n2 = sg*cross(PQ, U2), n3 = sg*cross(PQ, U3);
+                const float n0 = sg*cross(PQ, v.U0), n1 = sg*cross(PQ, v.U1), n2 = sg*cross(PQ, v.U2), n3 = sg*cross(PQ, v.U3);
                 constexpr float D = 2e-3f;
                 full &= (n0 > D*e0) & (n0 < (1.f - D)*e0) & (n1 > D*e1) & (n1 < (1.f - D)*e1) &
                         (n2 > D*e2) & (n2 < (1.f - D)*e2) & (n3 > D*e3) & (n3 < (1.f - D)*e3);
@@ -1378,6 +1473,72 @@ __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
             wd[i >> 4] |= st << (2*(i & 15));
         }
         reinterpret_cast<uint4*>(sc.lg_vals)[sc.lg_starts[n] + c] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+    }
+}
+
+// Second pass: the candidate lists of the cells' UNKNOWN lights.  Same thread-per-cell layout; a cell counts its
+// candidates, claims that many pool words, then walks the walls again to write them.
+__global__ __launch_bounds__(WG) void lightlist_kernel(const MsScenery sc) {
+    __shared__ float4 s_wall[BAKE_WALLS];        // (ax, ay, vx, vy)
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
+    const int ncell = (int)geom.z*(int)geom.w;
+    if ((int)blockIdx.x*WG >= ncell) return;
+    const int c = blockIdx.x*WG + tid;
+    const bool live = c < ncell;
+    const int AF = sc.n_agents*sc.n_model;
+    const int L = sc.lines_widths[n];
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
+    const int num_i = min(sc.lights_widths[n], LG_LIGHTS);
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const int n_walls = max(L - AF, 0);
+    const LgCell k = lg_cell_of(geom, sc.lg_cell, c);
+    const size_t cell_id = (size_t)sc.lg_starts[n] + c;
+    uint4 st = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (live) st = reinterpret_cast<const uint4*>(sc.lg_vals)[cell_id];
+    unsigned long long unk = 0ull;
+    for (int i = 0; i < num_i; i++) {
+        const unsigned wd = (i < 16) ? st.x : (i < 32) ? st.y : (i < 48) ? st.z : st.w;
+        if (((wd >> (2*(i & 15))) & 3u) == 0u) unk |= 1ull << i;
+    }
+    const bool indexable = n_walls <= (1 << 24);
+
+    int count = 0, first = 0, written = 0;
+    for (int pass = 0; pass < 2; pass++) {       // 0: count, 1: write
+        if (pass == 1 && live) {
+            if (indexable & (count <= LG_MAX_CANDS)) {
+                if (count > 0) {
+                    const unsigned at = atomicAdd(&sc.lg_pool[0], (unsigned)count);
+                    if ((unsigned long long)at + count + 1ull > (unsigned long long)sc.lg_pool_size) count = -1;   // pool exhausted
+                    first = 1 + (int)at;
+                }
+            } else {
+                count = -1;
+            }
+        }
+        for (int w0 = 0; w0 < n_walls; w0 += BAKE_WALLS) {
+            __syncthreads();
+            const int staged = min(BAKE_WALLS, n_walls - w0);
+            for (int i = tid; i < staged; i += WG) {
+                const float4 w = ln[AF + w0 + i];
+                s_wall[i] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
+            }
+            __syncthreads();
+            if (!live || count < 0 || (pass == 0 && count > LG_MAX_CANDS)) continue;
+            for (unsigned long long m = unk; m; m &= m - 1) {
+                const int i = __ffsll((long long)m) - 1;
+                const LgView v = lg_view_of(k, p2(lights[3*i], lights[3*i + 1]));
+                for (int j = 0; j < staged; j++) {
+                    if (!lg_touches(k, v, s_wall[j])) continue;
+                    if (pass == 0) count++;
+                    else sc.lg_pool[first + written++] = 0x80000000u | ((unsigned)i << 24) | (unsigned)(w0 + j);
+                }
+            }
+        }
+    }
+    if (live) {
+        // [first candidate, 0x80000000 | count]; second word 0: no list
+        reinterpret_cast<uint2*>(sc.lg_list)[cell_id] = count < 0 ? make_uint2(0u, 0u) : make_uint2((unsigned)first, 0x80000000u | (unsigned)written);
     }
 }
 
@@ -1486,7 +1647,14 @@ int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
     if (sc->lg_vals) {
         if (!sc->lg_starts || !sc->lg_geom || !(sc->lg_cell > 0.f) || sc->lg_max_cells <= 0 || ((uintptr_t)sc->lg_vals % 16) ||
             ((uintptr_t)sc->lg_geom % 16)) return MS_EINVAL;
-        hipLaunchKernelGGL(lightgrid_kernel, dim3((sc->lg_max_cells + WG - 1)/WG, sc->n_envs), dim3(WG), 0, (hipStream_t)stream, *sc);
+        if ((sc->lg_list != nullptr) != (sc->lg_pool != nullptr) || (sc->lg_pool && sc->lg_pool_size < 1) ||
+            ((uintptr_t)sc->lg_list % 8)) return MS_EINVAL;
+        const dim3 cells((sc->lg_max_cells + WG - 1)/WG, sc->n_envs);
+        hipLaunchKernelGGL(lightgrid_kernel, cells, dim3(WG), 0, (hipStream_t)stream, *sc);
+        if (sc->lg_list) {
+            if (hipMemsetAsync(sc->lg_pool, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) return hip_fail(hipGetLastError());
+            hipLaunchKernelGGL(lightlist_kernel, cells, dim3(WG), 0, (hipStream_t)stream, *sc);
+        }
     }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);

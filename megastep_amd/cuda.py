@@ -188,6 +188,7 @@ class Scenery:
         self._lights, self._lines, self._textures, self._model = lights, lines, textures, model
         self._baked = Ragged1D(torch.ones_like(textures.vals[:, 0]).contiguous(), textures.widths)
         self._struct = None
+        self._lg = None             # the light grid's tensors; made by _as_struct unless sharding carried one over
         self._dev = None
 
     n_agents = property(lambda self: self._n_agents)
@@ -204,10 +205,12 @@ class Scenery:
                                textures=self._textures[s:t], model=self._model, baked=self._baked[s:t])
 
     LIGHT_GRID_CELL = .25
+    LIGHT_GRID_POOL = 12        # pool words per cell (4 bytes each) for the candidate lists
 
     def _light_grid(self):
         """Storage and geometry of the light grid (see include/megastep_hip.h): a uniform grid over each env's walls,
-        half a metre of slack around them. `bake` fills it in; zeros mean 'unknown', which is always safe."""
+        half a metre of slack around them: per cell the lights' verdicts and a candidate list drawn from a shared pool.
+        `bake` fills it in; zeros mean 'unknown, test every wall', which is always safe."""
         ln = self._lines
         dev = ln.vals.device
         n_envs, cell = len(ln), self.LIGHT_GRID_CELL
@@ -225,15 +228,20 @@ class Scenery:
         cells = (dims[:, 0]*dims[:, 1]).long()
         starts = (cells.cumsum(0) - cells).to(torch.int32)
         geom = torch.cat([origin, dims], 1).float().contiguous()
-        vals = torch.zeros((int(cells.sum()), 4), dtype=torch.int32, device=dev)
-        return vals, starts.contiguous(), geom, cell, int(cells.max())
+        total = int(cells.sum())
+        vals = torch.zeros((total, 4), dtype=torch.int32, device=dev)
+        lists = torch.zeros((total, 2), dtype=torch.int32, device=dev)
+        pool = torch.zeros(min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1), dtype=torch.int32, device=dev)
+        return vals, starts.contiguous(), geom, cell, int(cells.max()), lists, pool
 
     def _as_struct(self):
         if self._struct is None:
             li, ln, tx = self._lights, self._lines, self._textures
             # the grid holds 64 lights per env; sceneries beyond that go without
             few_lights = len(li.widths) == 0 or int(li.widths.max()) <= 64
-            self._lg = lg = self._light_grid() if few_lights else (None, None, None, 0., 0)
+            if self._lg is None:
+                self._lg = self._light_grid() if few_lights else (None, None, None, 0., 0, None, None)
+            lg = self._lg
             self._struct = _lib.MsScenery(
                 len(ln), self._n_agents, self._model.shape[0],
                 li.vals.data_ptr(), li.widths.data_ptr(), li.starts.data_ptr(),
@@ -241,7 +249,8 @@ class Scenery:
                 tx.vals.data_ptr(), tx.widths.data_ptr(), tx.starts.data_ptr(), tx.inverse.data_ptr(),
                 self._model.data_ptr(), self._baked.vals.data_ptr(),
                 ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0],
-                *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4])
+                *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4],
+                *(t.data_ptr() if t is not None else None for t in lg[5:7]), lg[6].shape[0] if lg[6] is not None else 0)
         return self._struct
 
     def _device(self):

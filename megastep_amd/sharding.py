@@ -39,13 +39,28 @@ def shard_scenery(scenery, rank, world_size, device=None):
     # the light grid (what ms_bake caches about which lights reach which cells) is per env too: carry its slice over
     parent = getattr(scenery, '_lg', None)
     if parent is not None and parent[0] is not None and out.model.is_cuda:
-        out._as_struct()
-        vals, starts = parent[0], parent[1]
-        c0 = int(starts[start])
-        c1 = int(starts[stop]) if stop < len(starts) else vals.shape[0]
-        if out._lg[0] is not None and out._lg[0].shape[0] == c1 - c0:
-            out._lg[0].copy_(vals[c0:c1])
+        out._lg = _shard_light_grid(parent, start, stop, device)
     return out
+
+
+def _shard_light_grid(lg, start, stop, device):
+    """Envs [start, stop) of a baked light grid (cuda.Scenery._light_grid's tuple): the verdict rows as they are, the
+    candidate lists repacked into a pool of their own (the parent's pool is filled in no particular order)."""
+    vals, starts, geom, cell, _, lists, pool = lg
+    c0 = int(starts[start])
+    c1 = int(starts[stop]) if stop < len(starts) else vals.shape[0]
+    sub_starts = (starts[start:stop] - c0).to(device).contiguous()
+    sub_geom = geom[start:stop].to(device).contiguous().clone()
+    cells = (sub_geom[:, 2]*sub_geom[:, 3]).long()
+    rows = lists[c0:c1].long() & 0xffffffff
+    count = torch.where(rows[:, 1] != 0, rows[:, 1] & 0x7fffffff, torch.zeros_like(rows[:, 1]))
+    first = count.cumsum(0) - count                                   # 0-based position in the new pool's payload
+    cell_of = torch.repeat_interleave(torch.arange(len(count), device=count.device), count)
+    src = rows[cell_of, 0] + (torch.arange(int(count.sum()), device=count.device) - first[cell_of])
+    sub_pool = torch.cat([count.sum()[None].to(pool.dtype), pool[src]])
+    sub_lists = torch.stack([torch.where(rows[:, 1] != 0, first + 1, torch.zeros_like(first)), rows[:, 1]], 1).to(torch.int32)
+    return (vals[c0:c1].to(device).contiguous().clone(), sub_starts.to(torch.int32), sub_geom, cell, int(cells.max()),
+            sub_lists.to(device).contiguous(), sub_pool.to(device).contiguous())
 
 
 def max_over_ranks(seconds, device=None):

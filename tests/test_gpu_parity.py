@@ -197,9 +197,10 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
     evaluate the reference's obstructed() test against all walls."""
     c, _ = _world(6, 2, 64, 130, seed=3)
     sc = c.scenery
-    vals, starts, geom, cell, _ = (t.cpu().numpy() if torch.is_tensor(t) else t for t in sc._lg)
+    vals, starts, geom, cell, _, lists, pool = (t.cpu().numpy() if torch.is_tensor(t) else t for t in sc._lg)
+    pool = pool.astype(np.uint32)
     rng = np.random.RandomState(0)
-    n_lit = n_dark = 0
+    n_lit = n_dark = n_open = n_listed = n_cells = 0
     for e in range(6):
         walls = sc.lines[e].cpu().numpy()[16:]
         lights = sc.lights[e].cpu().numpy()
@@ -211,18 +212,32 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
             pts = (np.array([ox + ix*cell, oy + iy*cell]) + rng.uniform(0, cell, (24, 2))).astype(np.float32)
             pts = np.concatenate([pts, np.array([[ox + ix*cell, oy + iy*cell], [ox + (ix + 1)*cell, oy + (iy + 1)*cell]], np.float32)])
             words = vals[starts[e] + cidx].astype(np.uint32)
+            first, header = lists[starts[e] + cidx].astype(np.uint32)
+            listed = header != 0
+            cands = pool[int(first):int(first) + int(header & 0x7fffffff)] if listed else []
+            n_listed += int(listed); n_cells += 1
             for i, light in enumerate(lights[:64]):
                 state = (words[i >> 4] >> np.uint32(2*(i & 15))) & 3
-                if state == 0:
+                if state == 0 and not listed:
                     continue
                 blocked = _obstructed(light[:2].astype(np.float32), pts, walls).any(1)
+                if state == 0:
+                    # an open light: the candidate walls alone must reproduce every point's verdict
+                    mine = [int(c & 0xffffff) for c in cands if (int(c) >> 24) & 63 == i]
+                    assert all(int(c) >> 31 for c in cands)
+                    few = _obstructed(light[:2].astype(np.float32), pts, walls[mine]).any(1) if mine else np.zeros(len(pts), bool)
+                    assert (few == blocked).all(), (e, cidx, i, 'candidate list misses a blocker')
+                    n_open += 1
+                    continue
                 if state == 1:
                     assert not blocked.any(), (e, cidx, i, 'LIT cell has a shadowed point')
                     n_lit += 1
                 else:
                     assert blocked.all(), (e, cidx, i, 'DARK cell has a lit point')
                     n_dark += 1
-    assert n_lit > 50 and n_dark > 1000, (n_lit, n_dark)
+    assert n_lit > 50 and n_dark > 1000 and n_open > 100, (n_lit, n_dark, n_open)
+    assert n_listed > .9*n_cells, (n_listed, n_cells)          # the pool is rarely short
+    assert 0 < int(pool[0]) < len(pool)
 
 
 def test_crowded_rooms_exercise_dynamic_lighting():
