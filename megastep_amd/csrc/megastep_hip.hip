@@ -649,13 +649,6 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     const int base = sc.lines_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
 
-    // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
-    // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
-    // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
-    if (g == 0) {
-        for (int m = lane; m < sc.n_model; m += WAVE) ln[a*sc.n_model + m] = drawn_line(sc, ag, n, a*sc.n_model + m);
-    }
-
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
     // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
     float ag_s = 0.f, ag_c = 0.f;
@@ -668,6 +661,29 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             sincospi_f(ag.angles[n*A + lane]/180.f, ag_s, ag_c);
         }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
+    }
+    // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
+    // there is one.  Lanes exchange data in here: call it from wave-uniform control flow only.
+    auto agent_line = [&](const int l_) {
+        const int l = min(max(l_, 0), AF - 1);
+        if (A > WAVE) return drawn_line(sc, ag, n, l);
+        const int la = l / sc.n_model;
+        const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
+        const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
+        const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
+        float4 w;
+        w.x = c_*mdl.x - s_*mdl.y + px_; w.y = s_*mdl.x + c_*mdl.y + py_;
+        w.z = c_*mdl.z - s_*mdl.w + px_; w.w = s_*mdl.z + c_*mdl.w + py_;
+        return w;
+    };
+    // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
+    // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
+    // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
+    if (g == 0) {
+        for (int m0 = 0; m0 < sc.n_model; m0 += WAVE) {
+            const float4 w = agent_line(a*sc.n_model + m0 + lane);
+            if (m0 + lane < sc.n_model) ln[a*sc.n_model + m0 + lane] = w;
+        }
     }
     // --- ray setup (kernels.cu:334-344)
     float sn, cs;
@@ -725,19 +741,14 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection into LDS, and the
         // conservative interval [lo, lo + len) of this wave's rays that can hit it
-        auto line_setup = [&](const int l, int& lo, int& len) {
-            float4 w;
-            if (l >= AF) {
-                w = ln[l];
-            } else if (A <= WAVE) {                                     // draw_kernel, kernels.cu:297-318
-                const int la = l / sc.n_model;
-                const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
-                const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
-                const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
-                w.x = c_*mdl.x - s_*mdl.y + px_; w.y = s_*mdl.x + c_*mdl.y + py_;
-                w.z = c_*mdl.z - s_*mdl.w + px_; w.w = s_*mdl.z + c_*mdl.w + py_;
-            } else {
-                w = drawn_line(sc, ag, n, l);
+        auto line_setup = [&](const int c0, int& lo, int& len) {       // every lane comes in; dead ones leave with len 0
+            const int l = c0 + lane;
+            const bool live = l < L;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live & (l >= AF)) w = ln[l];
+            if (c0 < AF) {                                              // chunk with agent lines in it
+                const float4 aw = agent_line(l);
+                if (l < AF) w = aw;
             }
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
             const float dbx = w.z - pp.x, dby = w.w - pp.y;
@@ -759,13 +770,12 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             const float flo = fminf(fmaxf(fminf(ra, rb) - marg - g0, 0.f), 64.f);
             const float fhi = fmaxf(fminf(fmaxf(ra, rb) + marg - g0, last_local), -1.f);
             lo = (int)ceilf(flo);
-            len = inc ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+            len = (live & inc) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
         };
 
         for (int c0 = 0; c0 < L; c0 += WAVE) {
-            const int l = c0 + lane;
             int lo = 0, len = 0;
-            if (l < L) line_setup(l, lo, len);
+            line_setup(c0, lo, len);
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
@@ -850,9 +860,8 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             float x = INFINITY;
             int xi = -1;
             for (int c0 = 0; c0 < L; c0 += WAVE) {
-                const int l = c0 + lane;
                 int lo = 0, len = 0;
-                if (l < L) line_setup(l, lo, len);
+                line_setup(c0, lo, len);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -882,8 +891,10 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             for (int c0 = 0; c0 < L; c0 += WAVE) {
                 const int l = c0 + lane;
                 float pqx = 0.f, pqy = 0.f, vx = 0.f, vy = 0.f;
+                float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 < AF) aw = agent_line(l);
                 if (l < L) {
-                    const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                    const float4 w = (l < AF) ? aw : ln[l];
                     pqx = w.x - pp.x; pqy = w.y - pp.y; vx = w.z - w.x; vy = w.w - w.y;
                 }
                 for (unsigned long long todo = amb; todo; todo &= todo - 1) {
@@ -928,8 +939,10 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             float bound2 = (nearest_idx >= 0) ? nearest_s*nearest_s*(rx*rx + ry*ry) : INFINITY;
             #pragma unroll
             for (int o = 1; o < GSIZE; o <<= 1) bound2 = fmaxf(bound2, __shfl_xor(bound2, o, WAVE));
+            float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 < AF) aw = agent_line(l);
             if (l < L) {
-                const float4 w = (l < AF) ? drawn_line(sc, ag, n, l) : ln[l];
+                const float4 w = (l < AF) ? aw : ln[l];
                 const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
                 const float dbx = w.z - pp.x, dby = w.w - pp.y;
                 s_cand_w[lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
@@ -998,8 +1011,10 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (__ballot((nearest_idx >= 0) & (nearest_idx < AF))) aw = agent_line(nearest_idx);
     if (nearest_idx >= 0) {
-        hw = (nearest_idx < AF) ? drawn_line(sc, ag, n, nearest_idx) : ln[nearest_idx];
+        hw = (nearest_idx < AF) ? aw : ln[nearest_idx];
         const float vx = hw.z - hw.x, vy = hw.w - hw.y;
         const float d = rx*vy - ry*vx;
         const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
