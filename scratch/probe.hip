@@ -24,7 +24,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "../../include/megastep_hip.h"
+#include "megastep_hip.h"
 
 namespace {
 
@@ -199,11 +199,10 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // ------------------------------------------------------------------------------------------------
 // physics                                                                    kernels.cu:179-230
 // ------------------------------------------------------------------------------------------------
-// ONE WAVEFRONT PER ENV (workgroup = 64 threads): the step is a chain of dependent loads around very little
-// arithmetic, so what matters is how many envs are in flight and how few round trips each needs.  A wave asks for
-// its first wall chunks before anything else, reads the agents (lane = agent) while they travel, and keeps
-// PHYS_AHEAD chunks in flight through the sweep; agents of one env read each other's start-of-step state, which
-// one wave orders for free (all reads sit before the first write in program order).
+// A workgroup owns `envs_per_wg` whole envs, so that every read of the start-of-step agent state happens
+// before a barrier and every write after it (agents of one env read each other).  Its four waves split each
+// env's wall CHUNKS between them and test every chunk they load against all of the env's agents: a wave waits
+// on a quarter of the loads it would need if it owned one agent.
 //
 // Reach cull (exact): all four sub-tests of collision_cs leave x = 1 for a wall farther from the agent than
 // 1.02|v| + 2r - the crossing and side tests need the wall within |v| + r of p, and an endpoint that far ahead
@@ -211,61 +210,46 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // arithmetic; the few (agent, wall) pairs in reach are compacted into LDS and only those pay for the ten
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
-constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
-
-__global__ __launch_bounds__(WAVE) void physics_kernel(
+__global__ __launch_bounds__(WG) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps) {
-    extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach^2 | progress bits
-    __shared__ float4 s_wall[WAVE];              // walls within reach of ...
-    __shared__ int s_tag[WAVE];                  // ... this agent
-    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int lane = threadIdx.x;
-    const int n = blockIdx.x;
+        const float agent_radius, const float fps, const int envs_per_wg) {
+    extern __shared__ float4 s_dyn[];            // per task: (p, v/fps) | reach^2 | progress bits
+    __shared__ float4 s_wall[WAVES][WAVE];       // per wave: walls within reach of ...
+    __shared__ int s_tag[WAVES][WAVE];           // ... this task
+    const int N = sc.n_envs, A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tasks = envs_per_wg*A;
+    const int env0 = blockIdx.x*envs_per_wg;
     float4* s_task = s_dyn;
-    float* s_reach2 = reinterpret_cast<float*>(s_task + A);
-    unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + A);
+    float* s_reach2 = reinterpret_cast<float*>(s_task + tasks);
+    unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + tasks);
+    const float4* __restrict__ lines4 = reinterpret_cast<const float4*>(sc.lines_vals);
     const float2* __restrict__ pos2 = reinterpret_cast<const float2*>(ag.positions);
     const float2* __restrict__ vel2 = reinterpret_cast<const float2*>(ag.velocity);
 
-    // the first wall chunks are requested before anything else: nothing below depends on them until the sweep
-    const int L = sc.lines_widths[n];
-    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
-    float4 w[PHYS_AHEAD];
-    #pragma unroll
-    for (int k = 0; k < PHYS_AHEAD; k++) {
-        const int l = AF + k*WAVE + lane;
-        w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l < L) w[k] = ln[l];
-    }
-
-    // one lane per agent: its state and reach ...
-    float2 my_p = make_float2(0.f, 0.f), my_v = make_float2(0.f, 0.f);   // agent `lane`, kept for the epilogue
-    float my_w = 0.f, my_ang = 0.f;
-    if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
-    for (int t = lane; t < A; t += WAVE) {
-        const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
-        const P2 p0 = p2(pp.x, pp.y);
-        const P2 v0 = p2(mm.x, mm.y)/fps;
-        const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
-        s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
-        s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ... and the agent-agent tests (kernels.cu:193-200)
-    for (int t = lane; t < A; t += WAVE) {
-        const float4 me = s_task[t];
-        float x = 1.f;
-        for (int d1 = 0; d1 < A; d1++) {
-            if (d1 != t) {
-                const float4 o = s_task[d1];
-                x = ms_min(x, collision_cc(p2(me.x, me.y), p2(me.z, me.w), p2(o.x, o.y), p2(o.z, o.w), agent_radius));
+    // one thread per (env, agent): its state, its reach, and the agent-agent tests (kernels.cu:193-200)
+    for (int t = tid; t < tasks; t += WG) {
+        const int n = env0 + t/A, a = t % A;
+        float reach2 = -1.f;                     // envs past the end: nothing is ever in reach
+        if (n < N) {
+            const float2 pp = pos2[n*A + a], mm = vel2[n*A + a];
+            const P2 p0 = p2(pp.x, pp.y);
+            const P2 v0 = p2(mm.x, mm.y)/fps;
+            float x = 1.f;
+            for (int d1 = 0; d1 < A; d1++) {
+                if (d1 != a) {
+                    const float2 q = pos2[n*A + d1], m1 = vel2[n*A + d1];
+                    x = ms_min(x, collision_cc(p0, v0, p2(q.x, q.y), p2(m1.x, m1.y)/fps, agent_radius));
+                }
             }
+            const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+            reach2 = (reach == reach) ? reach*reach : INFINITY;          // NaN velocities: test everything
+            s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
+            s_prog[t] = f_bits(x);
         }
-        s_prog[t] = f_bits(x);
+        s_reach2[t] = reach2;
     }
+    __syncthreads();
 
     int cnt = 0;
     auto flush = [&]() {
@@ -273,8 +257,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < cnt) {
-            const float4 u = s_wall[lane];
-            const int t = s_tag[lane];
+            const float4 u = s_wall[wave][lane];
+            const int t = s_tag[wave][lane];
             const float4 tk = s_task[t];
             const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
             if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
@@ -282,24 +266,22 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
     };
-    // lane = wall: which agents is it within reach of?  Those (wall, agent) pairs are compacted into LDS and get
-    // the exact test, one pair per lane (kernels.cu:202-221)
-    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
-        #pragma unroll
-        for (int k = 0; k < PHYS_AHEAD; k++) {
-            const float4 u = w[k];
-            const bool live = l0 + k*WAVE + lane < L;
-            // the chunk PHYS_AHEAD further on takes this one's place
-            const int nl = l0 + (k + PHYS_AHEAD)*WAVE + lane;
-            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nl < L) w[k] = ln[nl];
-            if (l0 + k*WAVE >= L) continue;                             // uniform
-            const float vx = u.z - u.x, vy = u.w - u.y;
+    for (int e = 0; e < envs_per_wg; e++) {
+        const int n = env0 + e;
+        if (n >= N) break;
+        const int L = sc.lines_widths[n];
+        const float4* __restrict__ ln = lines4 + sc.lines_starts[n];
+        for (int l0 = AF + wave*WAVE; l0 < L; l0 += WAVES*WAVE) {
+            const bool live = l0 + lane < L;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) w = ln[l0 + lane];
+            const float vx = w.z - w.x, vy = w.w - w.y;
             const float inv = __builtin_amdgcn_rcpf(vx*vx + vy*vy);
-            for (int t = 0; t < A; t++) {
+            for (int a = 0; a < A; a++) {
+                const int t = e*A + a;
                 const float4 tk = s_task[t];
                 // squared distance from the agent to the segment, shaved so it is a lower bound
-                const float pqx = u.x - tk.x, pqy = u.y - tk.y;
+                const float pqx = w.x - tk.x, pqy = w.y - tk.y;
                 float tc = -(pqx*vx + pqy*vy)*inv;
                 tc = fminf(fmaxf(tc, 0.f), 1.f);
                 tc = (tc == tc) ? tc : 0.f;
@@ -311,8 +293,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
                     if (cnt + nk > WAVE) flush();
                     if (in) {
                         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                        s_wall[pos] = u;
-                        s_tag[pos] = t;
+                        s_wall[wave][pos] = w;
+                        s_tag[wave][pos] = t;
                     }
                     cnt += nk;
                 }
@@ -320,20 +302,21 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         }
     }
     if (cnt) flush();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __syncthreads();
     // epilogue, kernels.cu:224-227
     float2* __restrict__ pos2w = reinterpret_cast<float2*>(ag.positions);
     float2* __restrict__ vel2w = reinterpret_cast<float2*>(ag.velocity);
-    for (int t = lane; t < A; t += WAVE) {
-        const int i = n*A + t;
+    for (int t = tid; t < tasks; t += WG) {
+        const int n = env0 + t/A, a = t % A;
+        if (n >= N) continue;
+        const int i = n*A + a;
         const float x = bits_f(s_prog[t]);
-        float2 p = my_p, v = my_v;
-        float w_ = my_w, ang = my_ang;
-        if (t != lane) { p = pos2w[i]; v = vel2w[i]; w_ = ag.angvelocity[i]; ang = ag.angles[i]; }
+        float2 p = pos2w[i], v = vel2w[i];
         p.x = p.x + x*v.x/fps;
         p.y = p.y + x*v.y/fps;
         pos2w[i] = p;
-        ag.angles[i] = normalize_degrees(ang + x*w_/fps);
+        float w = ag.angvelocity[i];
+        ag.angles[i] = normalize_degrees(ag.angles[i] + x*w/fps);
         if (x < 1) {
             vel2w[i] = make_float2(0.f, 0.f);
             ag.angvelocity[i] = 0.f;
@@ -640,10 +623,12 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     //   2560 second, 3072 third                                     |
     //   3584 info   (64 x 4 B)   per line: (first pair << 6) | first ray
     //   3840 mark   (64 x 4 B)   pair window: which line starts here
-    //   4096 screen (192 x 4 B)  RGB staging
+    //   4096 screen (192 x 4 B)  RGB staging; during the raycast: per-ray and per-group depth bounds
     constexpr int LDS_PER_WAVE = 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
+    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int Psum = 0;
+#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);
     float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][4096]);
@@ -751,6 +736,8 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][3072]);
         int* const s_info_w = reinterpret_cast<int*>(&s_raw[wave][3584]);
         int* const s_mark_w = reinterpret_cast<int*>(&s_raw[wave][3840]);
+        float* const s_depth_w = reinterpret_cast<float*>(&s_raw[wave][4096]);     // culling bounds; the screen
+        float* const s_group_w = reinterpret_cast<float*>(&s_raw[wave][4352]);     // staging area is idle until the end
         s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
         s_best_w[lane] = ~0ull;
         s_second_w[lane] = ~0ull;
@@ -758,7 +745,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection into LDS, and the
         // conservative interval [lo, lo + len) of this wave's rays that can hit it
-        auto line_setup = [&](const int c0, int& lo, int& len) {       // every lane comes in; dead ones leave with len 0
+        auto line_setup = [&](const int c0, int& lo, int& len, float& smin) {   // every lane comes in; dead ones leave with len 0
             const int l = c0 + lane;
             const bool live = l < L;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -780,6 +767,10 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                 const float yc = ya + t*(yb - ya);
                 if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
             }
+            // In the agent frame a ray is (1, ray_y), so a hit's ray parameter s IS its x' coordinate, and x' is
+            // linear along the line: no hit on this line can have s below the smaller end (NaN: never culls)
+            smin = fminf(xa, xb);
+            smin = ((xa == xa) & (xb == xb)) ? smin : -INFINITY;
             const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
             const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
             const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
@@ -790,14 +781,42 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             len = (live & inc) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
         };
 
+        TICK(0)
         for (int c0 = 0; c0 < L; c0 += WAVE) {
             int lo = 0, len = 0;
-            line_setup(c0, lo, len);
+            float smin = 0.f;
+            line_setup(c0, lo, len, smin);
+            TICK(1)
+            if (c0 > 0) {
+                // Depth culling.  Each ray's least key so far bounds its final one from above, and a hit more than
+                // 3e-4 behind that can neither win nor come within the 1e-4 hysteresis band of the winner or of
+                // anything in the winner's band - which is all the resolution below looks at (the literal fold,
+                // for rays it cannot settle, sees every line).  So a line whose nearest point is that far behind
+                // every ray of its interval is dropped.  Bounds: per ray for intervals of one or two rays, per
+                // group of eight rays for wider ones.
+                const unsigned long long bk = s_best_w[lane];
+                float gb = (bk == ~0ull) ? INFINITY : bits_f((uint32_t)(bk >> 32));
+                gb = ((float)lane > last_local) ? 0.f : gb;             // rays past the last one never hit anything
+                s_depth_w[lane] = gb;
+                gb = fmaxf(gb, __shfl_xor(gb, 1, WAVE)); gb = fmaxf(gb, __shfl_xor(gb, 2, WAVE)); gb = fmaxf(gb, __shfl_xor(gb, 4, WAVE));
+                if ((lane & 7) == 0) s_group_w[lane >> 3] = gb;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int hi = min(lo + max(len, 1) - 1, WAVE - 1), lo_ = min(lo, WAVE - 1);
+                const int g_lo = lo_ >> 3, g_hi = hi >> 3;
+                const float near2 = fmaxf(s_depth_w[lo_], s_depth_w[hi]);
+                const float wide = fmaxf(fmaxf(s_group_w[g_lo], s_group_w[min(g_lo + 1, g_hi)]), s_group_w[g_hi]);
+                const float bound = (len <= 2) ? near2 : (g_hi - g_lo <= 2) ? wide : INFINITY;
+                if (smin > bound*(1.f + 1e-4f) + 4e-4f) len = 0;
+            }
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
             s_info_w[lane] = (first << 6) | (lo & 63);
             int carry = -1;
+            TICK(2)
+            Psum += P;
             for (int p0 = 0; p0 < P; p0 += WAVE) {
                 // which line owns pair p0 + lane: lines mark their first pair, a max-scan spreads the marks
                 s_mark_w[lane] = -1;
@@ -837,6 +856,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                 __builtin_amdgcn_wave_barrier();
             }
             __builtin_amdgcn_wave_barrier();
+            TICK(3)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long best = s_best_w[lane], second = s_second_w[lane], third = s_third_w[lane];
@@ -878,7 +898,8 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             int xi = -1;
             for (int c0 = 0; c0 < L; c0 += WAVE) {
                 int lo = 0, len = 0;
-                line_setup(c0, lo, len);
+                float smin = 0.f;
+                line_setup(c0, lo, len, smin);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1025,6 +1046,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
 
     }
 
+    TICK(4)
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1048,6 +1070,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         out.distances[o] = nearest_s*rlen;
     }
 
+    TICK(5)
     // ---- pass 3: shade (kernels.cu:407-450)
     const bool is_hit = (nearest_idx >= 0) & (r < R);
     const bool dynamic = is_hit & (nearest_idx < AF);
@@ -1066,6 +1089,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
         }
     }
+    TICK(6)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     Filt f = Filt{0, 0, 0.f, 0.f};
     int tstart = 0;
@@ -1095,6 +1119,13 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     for (int k = 0; k < 3; k++) {
         const int j = lane + k*WAVE;
         if (j < nfl) scr[j] = s_screen_w[j];
+    }
+    TICK(7)
+    {
+        int v = Psum;
+        #pragma unroll
+        for (int k = 0; k < 8; k++) if (lane == k) v = (int)T_[k];
+        if (lane < 9) reinterpret_cast<int*>(out.distances)[((size_t)n*A + a)*R + g*WAVE + lane] = v;
     }
 }
 
@@ -1618,10 +1649,13 @@ void ms_host_sincospi(float x, float* s, float* c) { sincospi_f(x, *s, *c); }
 
 int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
-    const size_t shmem = (sizeof(float)*4 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
-    if (shmem > 60*1024) return MS_EUNSUPPORTED;
-    hipLaunchKernelGGL(physics_kernel, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
-                       *sc, *ag, progress, cfg->agent_radius, cfg->fps);
+    const int A = sc->n_agents;
+    const int envs_per_wg = A >= WAVES ? 1 : WAVES/A;
+    const int blocks = (sc->n_envs + envs_per_wg - 1)/envs_per_wg;
+    const size_t shmem = (sizeof(float)*4 + sizeof(float) + sizeof(unsigned))*(size_t)envs_per_wg*A;
+    if (shmem > 64*1024) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(physics_kernel, dim3(blocks), dim3(WG), shmem, (hipStream_t)stream,
+                       *sc, *ag, progress, cfg->agent_radius, cfg->fps, envs_per_wg);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }

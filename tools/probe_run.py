@@ -18,7 +18,7 @@ for i in range(60):
             for k in (1,3,7):
                 print('section', k, 'p50 %.0f p90 %.0f p99 %.0f max %.0f' % (*[torch.quantile(d[:,k], q).item() for q in (.5,.9,.99)], d[:,k].max().item()))
 acc/=cnt
-names=['prologue','pass1 line_setup','scan+info','pass2 pairs','resolve+fallback','loc/dot+out','lighting','shade+store','pairs']
+names=['prologue','pass1 line_setup','cull+scan+info','pass2 pairs','resolve+fallback','loc/dot+out','lighting','shade+store','pairs']
 tot=acc[:8].sum()
 for n,v in zip(names,acc):
     print('%-18s %10.0f cyc/wave  %.1f%%' % (n, v, 100*v/tot))
