@@ -216,14 +216,15 @@ constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
 __global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
         const float agent_radius, const float fps) {
-    extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach^2 | progress bits
-    __shared__ float4 s_wall[WAVE];              // walls within reach of ...
+    extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
+    __shared__ float4 s_wall[WAVE];              // walls near ...
     __shared__ int s_tag[WAVE];                  // ... this agent
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int lane = threadIdx.x;
     const int n = blockIdx.x;
     float4* s_task = s_dyn;
-    float* s_reach2 = reinterpret_cast<float*>(s_task + A);
+    float4* s_box = s_task + A;
+    float* s_reach2 = reinterpret_cast<float*>(s_box + A);
     unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + A);
     const float2* __restrict__ pos2 = reinterpret_cast<const float2*>(ag.positions);
     const float2* __restrict__ vel2 = reinterpret_cast<const float2*>(ag.velocity);
@@ -249,22 +250,21 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         const P2 v0 = p2(mm.x, mm.y)/fps;
         const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
         s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
+        s_box[t] = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
         s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
+        s_prog[t] = f_bits(1.f);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ... and the agent-agent tests (kernels.cu:193-200)
-    for (int t = lane; t < A; t += WAVE) {
-        const float4 me = s_task[t];
-        float x = 1.f;
-        for (int d1 = 0; d1 < A; d1++) {
-            if (d1 != t) {
-                const float4 o = s_task[d1];
-                x = ms_min(x, collision_cc(p2(me.x, me.y), p2(me.z, me.w), p2(o.x, o.y), p2(o.z, o.w), agent_radius));
-            }
+    // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane
+    for (int i = lane; i < A*A; i += WAVE) {
+        const int t = i / A, d1 = i - t*A;
+        if (d1 != t) {
+            const float4 me = s_task[t], o = s_task[d1];
+            const float x = collision_cc(p2(me.x, me.y), p2(me.z, me.w), p2(o.x, o.y), p2(o.z, o.w), agent_radius);
+            if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
         }
-        s_prog[t] = f_bits(x);
     }
 
     int cnt = 0;
@@ -276,14 +276,23 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             const float4 u = s_wall[lane];
             const int t = s_tag[lane];
             const float4 tk = s_task[t];
-            const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
-            if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+            // squared distance from the agent to the segment, shaved so it is a lower bound
+            const float vx = u.z - u.x, vy = u.w - u.y;
+            const float pqx = u.x - tk.x, pqy = u.y - tk.y;
+            float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+            tc = fminf(fmaxf(tc, 0.f), 1.f);
+            tc = (tc == tc) ? tc : 0.f;
+            const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+            if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {             // NaNs stay in
+                const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
+                if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
     };
-    // lane = wall: which agents is it within reach of?  Those (wall, agent) pairs are compacted into LDS and get
-    // the exact test, one pair per lane (kernels.cu:202-221)
+    // lane = wall: which agents' reach boxes does its bounding box touch?  Those (wall, agent) pairs are compacted
+    // into LDS and get the distance test and then the exact one, one pair per lane (kernels.cu:202-221)
     for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
@@ -294,17 +303,11 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (nl < L) w[k] = ln[nl];
             if (l0 + k*WAVE >= L) continue;                             // uniform
-            const float vx = u.z - u.x, vy = u.w - u.y;
-            const float inv = __builtin_amdgcn_rcpf(vx*vx + vy*vy);
+            const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
+            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
             for (int t = 0; t < A; t++) {
-                const float4 tk = s_task[t];
-                // squared distance from the agent to the segment, shaved so it is a lower bound
-                const float pqx = u.x - tk.x, pqy = u.y - tk.y;
-                float tc = -(pqx*vx + pqy*vy)*inv;
-                tc = fminf(fmaxf(tc, 0.f), 1.f);
-                tc = (tc == tc) ? tc : 0.f;
-                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-                const bool in = live & !(0.9998f*(qx*qx + qy*qy) > s_reach2[t]);      // NaNs stay in
+                const float4 bx = s_box[t];
+                const bool in = live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w)));
                 const unsigned long long m = __ballot(in);
                 if (m) {
                     const int nk = __popcll(m);
@@ -1618,7 +1621,7 @@ void ms_host_sincospi(float x, float* s, float* c) { sincospi_f(x, *s, *c); }
 
 int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
-    const size_t shmem = (sizeof(float)*4 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
+    const size_t shmem = (sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
     if (shmem > 60*1024) return MS_EUNSUPPORTED;
     hipLaunchKernelGGL(physics_kernel, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
                        *sc, *ag, progress, cfg->agent_radius, cfg->fps);
