@@ -616,6 +616,24 @@ __device__ inline Filt tex_filter(float x, int w) {
 // sin/cos (binary64 inside, see sincospi_f) once, instead of once per wavefront of the raycast.
 // Workspace layout: [0] queue length, [1] rays that took the sequential fold, [2] wavefronts that took its lane-parallel
 // form (telemetry for tests) | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
+// Launch-invariant values the host works out once per ms_render call instead of every wave doing so on the VALU:
+// culling constants, and exact unsigned division by F = A*G, G and M via multiply-high (Granlund & Montgomery).
+struct Divisor { unsigned mul, sh1, sh2; };
+struct RenderConsts {
+    float x_clip, c_b;
+    Divisor by_f, by_g, by_m;
+};
+__host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
+    unsigned s = 0;
+    while ((1ull << s) < d) s++;
+    const unsigned long long m = ((1ull << 32)*((1ull << s) - d))/d + 1ull;
+    return Divisor{(unsigned)m, s < 1u ? s : 1u, s > 1u ? s - 1u : 0u};
+}
+__device__ inline int div_by(int n, const Divisor d) {     // n >= 0
+    const unsigned t = __umulhi(d.mul, (unsigned)n);
+    return (int)((t + (((unsigned)n - t) >> d.sh1)) >> d.sh2);
+}
+
 __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
                                                          const int n_agents_total, const int n_fans) {
     const int i = blockIdx.x*WG + threadIdx.x;
@@ -635,7 +653,7 @@ __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int*
 template <int IMPL, int RW>
 __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
-        const float agent_radius, const float half_screen, const int R, const int n_fans) {
+        const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
     //      0 cand   (64 x 16 B)  the chunk's 64 lines               | lighting: (wall, light) pair list, 2 KiB
     //   1024 ray    (64 x 16 B)  per ray: rx, ry, near              |
@@ -661,7 +679,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
-    const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
+    const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
     const int r = g*WAVE + lane;
     const int r_last = min(g*WAVE + WAVE - 1, R - 1);
 
@@ -687,7 +705,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     auto agent_line = [&](const int l_) {
         const int l = min(max(l_, 0), AF - 1);
         if (A > WAVE) return drawn_line(sc, ag, n, l);
-        const int la = l / sc.n_model;
+        const int la = div_by(l, rc.by_m);
         const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
         const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
         const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
@@ -724,8 +742,8 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     // Screen-space bookkeeping for the culling below.  In the agent frame (x' forward, y' left) a point
     // is seen at screen coordinate ys = y'/x', i.e. at the continuous ray index c_a - ys*c_b (ray_y inverted).
     // Nothing with x' below x_clip can be hit: a hit has x' = s > agent_radius/|ru| > 2 x_clip.
-    const float c_a = 0.5f*(Rf - 1.f), c_b = 0.5f*Rf/half_screen;
-    const float x_clip = 0.5f*agent_radius/sqrtf(1.f + half_screen*half_screen);
+    const float c_a = 0.5f*(Rf - 1.f), c_b = rc.c_b;                      // c_b = R/2/half_screen
+    const float x_clip = rc.x_clip;                                        // agent_radius/2/sqrt(1 + half_screen^2)
     const float g0 = (float)(g*WAVE);
     const int my_group = lane/GSIZE;
 
@@ -1653,14 +1671,20 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
     if (!grid) scn.lg_vals = nullptr;
+    RenderConsts rc;
+    rc.x_clip = 0.5f*cfg->agent_radius/sqrtf(1.f + half_screen*half_screen);
+    rc.c_b = 0.5f*(float)R/half_screen;
+    rc.by_f = divisor_of((unsigned)(sc->n_agents*G));
+    rc.by_g = divisor_of((unsigned)G);
+    rc.by_m = divisor_of((unsigned)sc->n_model);
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     if (seq)
         hipLaunchKernelGGL((render_kernel<0, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else
         hipLaunchKernelGGL((render_kernel<1, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.
     if (!grid && sc->n_agents > 1)
