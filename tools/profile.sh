@@ -12,25 +12,25 @@ python - <<PY
 import pandas as pd, json
 out='$out'
 st = pd.read_csv(f'{out}/stats/bench_kernel_stats.csv')
-st = st[st.Name.str.contains('render_kernel|physics_kernel|dynlight|bake_kernel|lightgrid')]
+st = st[st.Name.str.contains('render_kernel|render_prep|physics_kernel|dynlight|bake_kernel|lightgrid|lightlist')]
 print(st[['Name','Calls','AverageNs','MinNs','MaxNs']].to_string())
 res = {}
 for c, f in [('FETCH_SIZE','fetch'),('WRITE_SIZE','write')]:
     d = pd.read_csv(f'{out}/{f}/bench_counter_collection.csv')
-    d['k'] = d.Kernel_Name.str.extract(r'(render_kernel|physics_kernel|dynlight_grid_kernel|dynlight_kernel)')
+    d['k'] = d.Kernel_Name.str.extract(r'(render_kernel|render_prep_kernel|physics_kernel|dynlight_kernel)')
     g = d[d.k.notna() & (d.Counter_Name==c)].groupby('k').Counter_Value.mean()
     res[c] = g.to_dict(); print(c, '(KB per launch, raw counter)', g.round(0).to_dict())
 json.dump(res, open(f'{out}/traffic_raw.json','w'))
 # HBM bytes per ms_render launch: FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide
 # coalesced read; calibrated on physics_kernel's 16 B/lane wall stream), WRITE_SIZE (KB) as reported.
-rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) for k in ('render_kernel', 'dynlight_grid_kernel', 'dynlight_kernel'))
+rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) for k in ('render_kernel', 'render_prep_kernel', 'dynlight_kernel'))
 pb = 2*1024*res['FETCH_SIZE'].get('physics_kernel', 0) + 1024*res['WRITE_SIZE'].get('physics_kernel', 0)
 json.dump({'workload': {'envs': 4096, 'agents': 4, 'res': 64, 'large': False},
            'render_bytes_per_launch': rb, 'physics_bytes_per_launch': pb, 'raw_counters_KB': res,
            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'},
           open(f'{out}/traffic.json','w'), indent=1)
 sq = pd.read_csv(f'{out}/sq/bench_counter_collection.csv')
-sq['k'] = sq.Kernel_Name.str.extract(r'(render_kernel|physics_kernel|dynlight_grid_kernel|dynlight_kernel)')
+sq['k'] = sq.Kernel_Name.str.extract(r'(render_kernel|render_prep_kernel|physics_kernel|dynlight_kernel)')
 g = sq[sq.k.notna()].groupby(['k','Counter_Name']).Counter_Value.mean().unstack()
 g.to_csv(f'{out}/sq_counters_mean_per_launch.csv')
 print(g.round(0).to_string())
