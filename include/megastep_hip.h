@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 4
+#define MS_ABI_VERSION 5
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -95,7 +95,8 @@ typedef struct MsAgents {
     float* velocity;      /* (N, A, 2) metres / second   */
 } MsAgents;
 
-/* Replaces `Render` (common.h:216-222). Caller-allocated outputs. */
+/* Replaces `Render` (common.h:216-222). Caller-allocated outputs.  With a light grid in the scenery any of the
+ * five per-ray outputs may be NULL (not wanted: skipped); without one all five are required. */
 typedef struct MsRender {
     int*   indices;       /* (N, A, R)    line index within the env, -1 on a miss */
     float* locations;     /* (N, A, R)    position along the line, NaN on a miss  */
@@ -107,6 +108,16 @@ typedef struct MsRender {
      * a compact list.  At least MS_RENDER_WORKSPACE_INTS(N, A, R) 4-byte words, 8-byte aligned, contents
      * undefined before and after the call; NULL selects slower in-kernel paths. */
     int*   workspace;
+    /* Optional pooled observations, written by the render kernel itself instead of by a chain of host-side tensor
+     * ops over the per-ray outputs (replaces modules.py:138-145,170-184,211-224: downsample().mean(), Depth, RGB).
+     * Each pixel is the mean over `obs_subsample` adjacent rays; obs_subsample must be a power of two dividing
+     * both 64 and the resolution.  NULL = not wanted.
+     *   obs_rgb    (N, A, 3, R/obs_subsample)  channel-major, as the reference's RGB module returns it
+     *   obs_depth  (N, A, R/obs_subsample)     mean of 1 - clamp((distance - agent_radius)/obs_max_depth, 0, 1) */
+    float* obs_rgb;
+    float* obs_depth;
+    int    obs_subsample;
+    float  obs_max_depth;
 } MsRender;
 
 /* 4-byte words of MsRender.workspace needed for N envs, A agents, R rays */

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -42,7 +42,8 @@ class MsAgents(C.Structure):
 
 class MsRender(C.Structure):
     _fields_ = [('indices', C.c_void_p), ('locations', C.c_void_p), ('dots', C.c_void_p), ('distances', C.c_void_p),
-                ('screen', C.c_void_p), ('workspace', C.c_void_p)]
+                ('screen', C.c_void_p), ('workspace', C.c_void_p), ('obs_rgb', C.c_void_p), ('obs_depth', C.c_void_p),
+                ('obs_subsample', C.c_int), ('obs_max_depth', C.c_float)]
 
 
 #: every symbol include/megastep_hip.h declares

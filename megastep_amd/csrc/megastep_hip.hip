@@ -650,8 +650,10 @@ __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int*
 //          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
 // RW = waves per workgroup.  The waves never talk to each other, so RW = 1 lets every wave give its slot and
 // LDS back the moment it is done instead of waiting for the slowest of four.
-template <int IMPL, int RW>
-__global__ __launch_bounds__(RW*WAVE) void render_kernel(
+// OBS = 1: any of the five per-ray outputs may be NULL, and pooled observations are written on request (the plain
+// instantiation stays within 80 VGPRs: six waves per SIMD)
+template <int IMPL, int RW, int OBS>
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
@@ -1062,11 +1064,12 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         dt = dtop/(dbot + 1.e-6f);
     }
     const size_t o = ((size_t)n*A + a)*R + r;
+    const float dist = nearest_s*rlen;
     if (r < R) {
-        out.indices[o] = nearest_idx;
-        out.locations[o] = loc;
-        out.dots[o] = dt;
-        out.distances[o] = nearest_s*rlen;
+        if (!OBS || out.indices) out.indices[o] = nearest_idx;
+        if (!OBS || out.locations) out.locations[o] = loc;
+        if (!OBS || out.dots) out.dots[o] = dt;
+        if (!OBS || out.distances) out.distances[o] = dist;
     }
 
     // ---- pass 3: shade (kernels.cu:407-450)
@@ -1105,17 +1108,41 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         s1 = dn*intensity*(f.lw*tl[1] + f.rw*tr[1]);
         s2 = dn*intensity*(f.lw*tl[2] + f.rw*tr[2]);
     }
-    // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
-    s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nfl = 3*(r_last - g*WAVE + 1);
-    float* __restrict__ scr = out.screen + 3*(((size_t)n*A + a)*R + g*WAVE);
-    #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int j = lane + k*WAVE;
-        if (j < nfl) scr[j] = s_screen_w[j];
+    if (!OBS || out.screen) {
+        // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
+        s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nfl = 3*(r_last - g*WAVE + 1);
+        float* __restrict__ scr = out.screen + 3*(((size_t)n*A + a)*R + g*WAVE);
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int j = lane + k*WAVE;
+            if (j < nfl) scr[j] = s_screen_w[j];
+        }
+    }
+    // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
+    // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
+    if (OBS && (out.obs_rgb || out.obs_depth)) {
+        const int sub = out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
+        float p0 = s0, p1 = s1, p2 = s2;
+        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/out.obs_max_depth, 0.f), 1.f);
+        for (int o2 = 1; o2 < sub; o2 <<= 1) {
+            p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE);
+            p2 += __shfl_xor(p2, o2, WAVE); pd += __shfl_xor(pd, o2, WAVE);
+        }
+        if (((lane & (sub - 1)) == 0) & (r < R)) {
+            const float fs = (float)sub;
+            const int W = R/sub, px = r/sub;
+            const size_t na = (size_t)n*A + a;
+            if (out.obs_rgb) {
+                out.obs_rgb[(na*3 + 0)*W + px] = p0/fs;
+                out.obs_rgb[(na*3 + 1)*W + px] = p1/fs;
+                out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
+            }
+            if (out.obs_depth) out.obs_depth[na*W + px] = pd/fs;
+        }
     }
 }
 
@@ -1648,9 +1675,12 @@ int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const M
 }
 
 int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {
-    if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !out->indices || !out->locations ||
-        !out->dots || !out->distances || !out->screen || !sc->textures_vals || !sc->textures_widths ||
+    if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !sc->textures_vals || !sc->textures_widths ||
         !sc->textures_starts || !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
+    if (out->obs_rgb || out->obs_depth) {
+        const int sub = out->obs_subsample;
+        if (sub < 1 || (sub & (sub - 1)) || sub > WAVE || cfg->res % sub || !(out->obs_max_depth > 0.f)) return MS_EINVAL;
+    }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
     const int G = (R + WAVE - 1)/WAVE;
@@ -1671,6 +1701,12 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
     if (!grid) scn.lg_vals = nullptr;
+    // the second kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
+    const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
+    const bool pooled = out->obs_rgb || out->obs_depth;
+    if (!all_planes && !(grid || sc->n_agents == 1)) return MS_EINVAL;
+    if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
+    const bool obs = pooled || !all_planes;
     RenderConsts rc;
     rc.x_clip = 0.5f*cfg->agent_radius/sqrtf(1.f + half_screen*half_screen);
     rc.c_b = 0.5f*(float)R/half_screen;
@@ -1679,12 +1715,16 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_m = divisor_of((unsigned)sc->n_model);
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
-    if (seq)
-        hipLaunchKernelGGL((render_kernel<0, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    const dim3 rgrid(rblocks), rblock(RW*WAVE);
+    const hipStream_t hs = (hipStream_t)stream;
+    if (seq && obs)
+        hipLaunchKernelGGL((render_kernel<0, RW, 1>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else if (seq)
+        hipLaunchKernelGGL((render_kernel<0, RW, 0>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else if (obs)
+        hipLaunchKernelGGL((render_kernel<1, RW, 1>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else
-        hipLaunchKernelGGL((render_kernel<1, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+        hipLaunchKernelGGL((render_kernel<1, RW, 0>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.
     if (!grid && sc->n_agents > 1)

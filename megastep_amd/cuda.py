@@ -265,16 +265,21 @@ class Scenery:
 
 
 class Render:
-    """Result of :func:`render` (reference: common.h:216-222, wrappers.cpp:147-164)."""
+    """Result of :func:`render` (reference: common.h:216-222, wrappers.cpp:147-164). Fields that were not asked for
+    are ``None``; ``obs_rgb``/``obs_depth`` are the pooled observations when the call asked for them."""
 
-    def __init__(self, indices, locations, dots, distances, screen):
+    def __init__(self, indices, locations, dots, distances, screen, obs_rgb=None, obs_depth=None, obs_subsample=None):
         self._t = (indices, locations, dots, distances, screen)
+        self._obs = (obs_rgb, obs_depth, obs_subsample)
 
     indices = property(lambda self: self._t[0])
     locations = property(lambda self: self._t[1])
     dots = property(lambda self: self._t[2])
     distances = property(lambda self: self._t[3])
     screen = property(lambda self: self._t[4])
+    obs_rgb = property(lambda self: self._obs[0])
+    obs_depth = property(lambda self: self._obs[1])
+    obs_subsample = property(lambda self: self._obs[2])
 
 
 class Physics:
@@ -341,9 +346,17 @@ def physics(scenery, agents):
     return Physics(progress)
 
 
-def render(scenery, agents):
+FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
+
+
+def render(scenery, agents, fields=None, pooled=None):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
-    (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`."""
+    (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
+
+    Two extensions over the reference, both off by default: ``fields`` names the per-ray outputs that are wanted
+    (the others are neither written nor allocated), and ``pooled=dict(subsample=s, max_depth=d, rgb=True, depth=True)``
+    has the kernel write the mean-pooled observations of ``modules.RGB`` / ``modules.Depth`` itself
+    (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s))."""
     dev = scenery._device()
     _agents_on(agents, dev)
     n, a = agents.angles.shape
@@ -351,18 +364,38 @@ def render(scenery, agents):
         raise RuntimeError('agents do not match the scenery')
     cfg = _cfg()
     r = cfg.res
-    # One allocation for the five outputs (reference: five at::empty calls, kernels.cu:461-469) and the kernels'
-    # scratch (MS_RENDER_WORKSPACE_INTS): 7 planes of (n, a, r) words, then the workspace.
+    want = FIELDS if fields is None else tuple(fields)
+    if any(f not in FIELDS for f in want):
+        raise RuntimeError(f'fields must be among {FIELDS}')
+    sub, max_depth, w = 1, 1., r
+    n_rgb = n_depth = 0
+    if pooled is not None:
+        sub, max_depth = int(pooled.get('subsample', 1)), float(pooled.get('max_depth', 10.))
+        if sub < 1 or sub & (sub - 1) or 64 % sub or r % sub:
+            raise RuntimeError('pooled subsample must be a power of two dividing 64 and the resolution')
+        w = r//sub
+        n_rgb = 3*n*a*w if pooled.get('rgb', True) else 0
+        n_depth = n*a*w if pooled.get('depth', True) else 0
+    # One allocation for the wanted outputs (reference: five at::empty calls, kernels.cu:461-469), the pooled
+    # observations and the kernels' scratch (MS_RENDER_WORKSPACE_INTS), in words of 4 bytes.
     plane = n*a*r
-    buf = torch.empty(7*plane + 18 + n*a*((r + 63)//64) + 2*n*a, dtype=torch.float32, device=dev)
-    planes = buf[:7*plane].view(7, n, a, r)
-    indices, locations, dots, distances = planes[0].view(torch.int32), planes[1], planes[2], planes[3]
-    screen = planes[4:].view(n, a, r, 3)
+    sizes = [plane*(3 if f == 'screen' else 1) if f in want else 0 for f in FIELDS] + [n_rgb, n_depth]
+    sizes = [(x + 3) & ~3 for x in sizes]                                # keep every piece 16-byte aligned
+    offs = [0]
+    for x in sizes:
+        offs.append(offs[-1] + x)
+    buf = torch.empty(offs[-1] + 18 + n*a*((r + 63)//64) + 2*n*a, dtype=torch.float32, device=dev)
     base = buf.data_ptr()
-    out = _lib.MsRender(base, base + 4*plane, base + 8*plane, base + 12*plane, base + 16*plane, base + 28*plane)
+    ptr = lambda i: base + 4*offs[i] if sizes[i] else None
+    piece = lambda i, shape: buf[offs[i]:offs[i] + int(torch.Size(shape).numel())].view(shape) if sizes[i] else None
+    outs = [piece(i, (n, a, r, 3) if f == 'screen' else (n, a, r)) for i, f in enumerate(FIELDS)]
+    if outs[0] is not None:
+        outs[0] = outs[0].view(torch.int32)
+    obs_rgb, obs_depth = piece(5, (n, a, 3, w)), piece(6, (n, a, w))
+    out = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth)
     with _on(dev):
         _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct), C.byref(out),
                                         C.byref(cfg), _stream(dev)))
-    result = Render(indices, locations, dots, distances, screen)
-    result._telemetry = buf[7*plane:7*plane + 16].view(torch.int32)      # see render_prep_kernel; read by the tests
+    result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None)
+    result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel; read by the tests
     return result

@@ -68,7 +68,8 @@ class Deathmatch:
         return hits.reshape(-1)
 
     def _observe(self):
-        r = modules.render(self.core)
+        # pooled RGB-D straight from the render kernel; shooting only needs the line each ray landed on
+        r = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices',))
         line_idxs = modules.downsample(r.indices, self._rgb.subsample)[..., self._rgb.subsample//2]
         obj_idxs = torch.div(line_idxs, len(self.core.scenery.model), rounding_mode='floor')
         mask = (0 <= line_idxs) & (obj_idxs < self.core.n_agents)

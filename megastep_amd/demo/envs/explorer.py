@@ -60,7 +60,8 @@ class Explorer:
         return reward
 
     def _observe(self, reset):
-        r = modules.render(self.core)
+        # pooled RGB-D straight from the render kernel; the reward only needs which texel each ray landed on
+        r = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices', 'locations'))
         obs = arrdict.arrdict(rgb=self._rgb(r), d=self._depth(r), imu=self._imu())
         return obs, self._reward(r, reset)
 

@@ -76,12 +76,33 @@ def unpack(d):
     return arrdict.arrdict({k: unpack(getattr(d, k)) for k in dir(d) if not k.startswith('_')})
 
 
-def render(core):
+def render(core, observers=None, fields=None):
     """Calls :func:`cuda.render` and reshapes for torch convs: every field gets a height-1 axis, ``screen`` becomes
-    (n_env, n_agent, 3, 1, res) (reference: modules.py:126-136)."""
-    r = unpack(cuda.render(core.scenery, core.agents))
-    r = arrdict.arrdict({k: v.unsqueeze(2) for k, v in r.items()})
-    r['screen'] = r.screen.permute(0, 1, 4, 2, 3)
+    (n_env, n_agent, 3, 1, res) (reference: modules.py:126-136).
+
+    Beyond the reference: pass the :class:`RGB` / :class:`Depth` modules that will consume the result as ``observers``
+    and their mean-pooled observations come straight out of the render kernel (they pick them up from the result
+    instead of running a chain of tensor ops over the full-resolution outputs), and name in ``fields`` the
+    full-resolution outputs that are still needed (default: all five) - the others are not even written."""
+    pooled = None
+    if observers:
+        subs = {o.subsample for o in observers}
+        depth = [o for o in observers if isinstance(o, Depth)]
+        if len(subs) != 1 or len({o.max_depth for o in depth}) > 1:
+            raise ValueError('observers of one render must share their subsample and max_depth')
+        pooled = dict(subsample=subs.pop(), max_depth=depth[0].max_depth if depth else 10.,
+                      rgb=any(isinstance(o, RGB) for o in observers), depth=bool(depth))
+    raw = cuda.render(core.scenery, core.agents, fields=fields, pooled=pooled)
+    r = arrdict.arrdict({k: getattr(raw, k).unsqueeze(2) for k in cuda.FIELDS if getattr(raw, k) is not None})
+    if 'screen' in r:
+        r['screen'] = r.screen.permute(0, 1, 4, 2, 3)
+    if pooled is not None:
+        r['pooled_subsample'] = pooled['subsample']
+        if raw.obs_rgb is not None:
+            r['pooled_rgb'] = raw.obs_rgb.unsqueeze(3)                       # (n_env, n_agent, 3, 1, res/subsample)
+        if raw.obs_depth is not None:
+            r['pooled_depth'] = raw.obs_depth.unsqueeze(2).unsqueeze(3)      # (n_env, n_agent, 1, 1, res/subsample)
+            r['pooled_max_depth'] = pooled['max_depth']
     return r
 
 
@@ -103,6 +124,9 @@ class Depth:
 
     def __call__(self, r=None):
         r = render(self.core) if r is None else r
+        if 'pooled_depth' in r and r.pooled_subsample == self.subsample and r.pooled_max_depth == self.max_depth:
+            self._last_obs = r.pooled_depth                  # the render kernel has done it (see render())
+            return self._last_obs
         depth = 1 - ((r.distances - self.core.agent_radius)/self.max_depth).clamp(0, 1)
         self._last_obs = downsample(depth, self.subsample).mean(-1).unsqueeze(3)
         return self._last_obs
@@ -121,6 +145,9 @@ class RGB:
 
     def __call__(self, r=None):
         r = render(self.core) if r is None else r
+        if 'pooled_rgb' in r and r.pooled_subsample == self.subsample:
+            self._last_obs = r.pooled_rgb                    # the render kernel has done it (see render())
+            return self._last_obs
         self._last_obs = downsample(r.screen, self.subsample).mean(-1)
         return self._last_obs
 

@@ -387,3 +387,58 @@ def test_more_than_64_lights_and_agents():
     r = cuda.render(c.scenery, c.agents)
     util.assert_physics_matches(c, p, *ref.physics())
     util.assert_render_matches(c, r, ref.render())
+
+
+@pytest.mark.parametrize('n_agents,res,subsample', [(3, 256, 4), (4, 64, 1), (2, 128, 8), (1, 96, 2), (2, 512, 4)])
+def test_fused_observations_match_the_host_modules(n_agents, res, subsample):
+    """The pooled RGB-D the render kernel writes itself against the reference's chain of tensor ops
+    (modules.py:138-145,170-184,211-224) on the full-resolution outputs of the same scene - and against the oracle's
+    render run through the same modules on the CPU."""
+    from megastep_amd import cuda, modules
+    c, _ = _world(6, n_agents, res, 130, seed=11)
+    rgb, depth = modules.RGB(c, subsample=subsample), modules.Depth(c, subsample=subsample, max_depth=7.)
+    full = modules.render(c)
+    want_rgb, want_d = rgb(full).clone(), depth(full).clone()
+    fused = modules.render(c, observers=(rgb, depth), fields=('indices',))
+    assert set(fused.keys()) >= {'indices', 'pooled_rgb', 'pooled_depth'} and 'screen' not in fused and 'distances' not in fused
+    got_rgb, got_d = rgb(fused), depth(fused)
+    assert got_rgb.shape == want_rgb.shape == (6, n_agents, 3, 1, res//subsample)
+    assert got_d.shape == want_d.shape == (6, n_agents, 1, 1, res//subsample)
+    assert torch.equal(fused.indices, full.indices)
+    torch.testing.assert_close(got_rgb, want_rgb, rtol=0, atol=1e-6)
+    torch.testing.assert_close(got_d, want_d, rtol=0, atol=1e-6)
+    # the oracle's render through the same modules, on the CPU
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c); ref.pull_agents(c)
+    o = ref.render()
+    class CpuCore: agent_radius, res = c.agent_radius, c.res
+    from megastep_amd import arrdict
+    r_cpu = arrdict.arrdict(distances=torch.as_tensor(o['distances']).unsqueeze(2),
+                            screen=torch.as_tensor(o['screen']).unsqueeze(2).permute(0, 1, 4, 2, 3))
+    cpu_rgb = modules.RGB(CpuCore, n_agents=n_agents, subsample=subsample)(r_cpu)
+    cpu_d = modules.Depth(CpuCore, n_agents=n_agents, subsample=subsample, max_depth=7.)(r_cpu)
+    np.testing.assert_allclose(got_rgb.cpu().numpy(), cpu_rgb.numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(got_d.cpu().numpy(), cpu_d.numpy(), rtol=0, atol=1e-5)
+    assert float(got_rgb.max()) > 0 and 0 < float(got_d.mean()) < 1
+
+
+def test_unwanted_outputs_are_skipped_and_wanted_ones_unchanged():
+    from megastep_amd import cuda
+    c, _ = _world(5, 3, 100, 90, seed=4)
+    full = cuda.render(c.scenery, c.agents)
+    for fields in [('indices',), ('distances', 'screen'), ('locations', 'dots'), cuda.FIELDS]:
+        part = cuda.render(c.scenery, c.agents, fields=fields)
+        for f in cuda.FIELDS:
+            if f in fields:
+                assert torch.equal(getattr(part, f), getattr(full, f), ) or \
+                    torch.equal(torch.nan_to_num(getattr(part, f), nan=-7.), torch.nan_to_num(getattr(full, f), nan=-7.)), f
+            else:
+                assert getattr(part, f) is None
+    only_obs = cuda.render(c.scenery, c.agents, fields=(), pooled=dict(subsample=4, max_depth=10.))
+    assert only_obs.indices is None and only_obs.obs_rgb.shape == (5, 3, 3, 25) and only_obs.obs_depth.shape == (5, 3, 25)
+    with pytest.raises(RuntimeError):
+        cuda.render(c.scenery, c.agents, fields=())                              # nothing asked for at all
+    with pytest.raises(RuntimeError):
+        cuda.render(c.scenery, c.agents, pooled=dict(subsample=3))               # not a power of two
+    with pytest.raises(RuntimeError):
+        cuda.render(c.scenery, c.agents, pooled=dict(subsample=8))               # does not divide 100
