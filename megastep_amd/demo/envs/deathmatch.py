@@ -46,8 +46,8 @@ class Deathmatch:
     def _reset(self, reset=None):
         reset = (self._health <= 0) if reset is None else reset
         self._spawner(reset)
-        self._health[reset] = 1.
-        self._damage[reset] = 0.
+        self._health.masked_fill_(reset, 1.)
+        self._damage.masked_fill_(reset, 0.)
         return reset.reshape(-1)
 
     def _shoot(self, opponents):

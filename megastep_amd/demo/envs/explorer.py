@@ -21,42 +21,49 @@ class Explorer:
 
         sc = self.core.scenery
         self._tex_to_env = sc.lines.inverse[sc.textures.inverse.long()].long()
-        self._seen = torch.full_like(self._tex_to_env, False)
         self._potential = self.core.env_full(0.)
         self._lengths = torch.zeros(self.core.n_envs, device=self.core.device, dtype=torch.int)
         self.device = self.core.device
-        # bookkeeping for the incremental reward: which ray last claimed a texel, and each env's texel range
-        self._claim = torch.full_like(self._tex_to_env, -1)
-        line_ends = sc.lines.ends.long()
-        self._tex_ends = sc.textures.ends.long()[line_ends - 1]
-        self._tex_starts = torch.cat([self._tex_ends.new_zeros(1), self._tex_ends[:-1]])
+        # Bookkeeping for the incremental reward, laid out so that a step needs neither a pass over every texel nor
+        # a host sync: a texel counts as seen while its stamp equals its env's epoch (a respawn bumps the epoch and
+        # thereby forgets the env's texels); `_claim` records which ray last landed on a texel. One extra slot at the
+        # end of both arrays takes the rays that hit nothing; it always reads as seen.
+        n_tex = len(self._tex_to_env)
+        self._epoch = torch.ones(self.core.n_envs, device=self.device, dtype=torch.int32)
+        self._stamp = torch.zeros(n_tex + 1, device=self.device, dtype=torch.int32)
+        self._claim = torch.full((n_tex + 1,), -1, device=self.device, dtype=torch.long)
+        self._trash = torch.tensor(n_tex, device=self.device)
+
+    @property
+    def _seen(self):
+        """Per texel: has its env seen it since the env's last respawn."""
+        return self._stamp[:-1] == self._epoch[self._tex_to_env]
 
     def _tex_indices(self, aux):
+        """The texel every ray landed on, (n_env, n_agent, 1, res); the trash slot for rays that hit nothing."""
         sc = self.core.scenery
-        mask = aux.indices >= 0
-        result = torch.full_like(aux.indices, -1, dtype=torch.long)
-        tex_n = (sc.lines.starts[:, None, None, None] + aux.indices)[mask].long()
-        tex_w = sc.textures.widths[tex_n].float()
-        tex_i = torch.min(torch.floor(tex_w*aux.locations[mask]), tex_w - 1)
-        result[mask] = sc.textures.starts[tex_n].long() + tex_i.long()
-        return result.unsqueeze(2)
+        valid = aux.indices >= 0
+        line = (sc.lines.starts[:, None, None, None] + aux.indices.clamp(min=0)).long()
+        tex_w = sc.textures.widths[line].float()
+        tex_i = torch.min(torch.floor(tex_w*aux.locations), tex_w - 1)
+        tex = sc.textures.starts[line].long() + torch.where(valid, tex_i, torch.zeros_like(tex_i)).long()
+        return torch.where(valid, tex, self._trash)
 
     def _reward(self, r, reset):
         """Reward = newly seen texels per env (reference: explorer.py:45-58). The reference re-counts every texel of
         every env each step (a scatter_add over all of them); here only the texels this step's rays landed on are
         touched: a texel is counted once, by whichever of the rays on it holds the claim, if it was unseen before."""
         tex = self._tex_indices(r).reshape(-1)
-        tex = tex[tex >= 0]
         rays = torch.arange(len(tex), device=tex.device)
+        epoch = self._epoch.repeat_interleave(len(tex)//self.core.n_envs)     # of the env each ray belongs to
         self._claim[tex] = rays                              # duplicates: some single ray wins each texel
-        fresh = (self._claim[tex] == rays) & ~self._seen[tex]
-        self._seen[tex] = True
-        potential = self._potential.clone()
-        potential.scatter_add_(0, self._tex_to_env[tex], fresh.float())
+        fresh = (self._claim[tex] == rays) & (self._stamp[tex] != epoch) & (tex != self._trash)
+        self._stamp[tex] = epoch
+        potential = self._potential + fresh.view(self.core.n_envs, -1).sum(1).float()
         reward = (potential - self._potential)/(self.core.res//self._rgb.subsample)
         self._potential = potential
         # Should I render twice so that the last reward is accurate?
-        reward[reset] = 0.
+        reward = reward.masked_fill(reset, 0.)
         return reward
 
     def _observe(self, reset):
@@ -67,13 +74,9 @@ class Explorer:
 
     def _reset(self, reset=None):
         self._respawner(reset.unsqueeze(-1))
-        envs = reset.nonzero().squeeze(-1)
-        if len(envs):                                        # forget what the respawned envs had seen
-            starts, lens = self._tex_starts[envs], self._tex_ends[envs] - self._tex_starts[envs]
-            offsets = torch.arange(int(lens.sum()), device=envs.device) - torch.repeat_interleave(lens.cumsum(0) - lens, lens)
-            self._seen[torch.repeat_interleave(starts, lens) + offsets] = False
-        self._potential[reset] = 0
-        self._lengths[reset] = 0
+        self._epoch += reset.int()                           # forget what the respawned envs had seen
+        self._potential = self._potential.masked_fill(reset, 0)
+        self._lengths.masked_fill_(reset, 0)
 
     @torch.no_grad()
     def reset(self):

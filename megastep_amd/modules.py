@@ -195,14 +195,18 @@ class RandomSpawns:
         self._spawns = arrdict.torchify(arrdict.arrdict(positions=positions, angles=angles)).to(core.device)
 
     def __call__(self, reset):
-        """``reset`` is an (n_env, n_agent) bool mask; the marked agents get a new pose and zero velocity."""
-        core = self.core
-        required = reset.nonzero(as_tuple=True)
-        choices = torch.randint_like(required[0], 0, self._spawns.angles.shape[1])
-        core.agents.angles[required] = self._spawns.angles[(*required, choices)]
-        core.agents.positions[required] = self._spawns.positions[(*required, choices)]
-        core.agents.velocity[required] = 0.
-        core.agents.angvelocity[required] = 0.
+        """``reset`` is an (n_env, n_agent) bool mask; the marked agents get a new pose and zero velocity.
+
+        Same draw as the reference (a uniform choice among the first ``spawns.shape[1]`` spawn points), but made for
+        every agent and applied through the mask, so the step needs no ``nonzero`` and with it no host sync."""
+        agents = self.core.agents
+        choices = torch.randint(0, self._spawns.angles.shape[1], reset.shape, device=reset.device)
+        angles = self._spawns.angles.gather(2, choices[..., None]).squeeze(2)
+        positions = self._spawns.positions.gather(2, choices[..., None, None].expand(-1, -1, 1, 2)).squeeze(2)
+        agents.angles[:] = torch.where(reset, angles, agents.angles)
+        agents.positions[:] = torch.where(reset[..., None], positions, agents.positions)
+        agents.velocity[:] = torch.where(reset[..., None], torch.zeros_like(agents.velocity), agents.velocity)
+        agents.angvelocity[:] = torch.where(reset, torch.zeros_like(agents.angvelocity), agents.angvelocity)
 
 
 class RandomLifespans:
@@ -217,9 +221,9 @@ class RandomLifespans:
         self._reset(core.agent_full(True))
 
     def _reset(self, reset):
-        self._lifespans[reset] = 0
+        self._lifespans.masked_fill_(reset, 0)
         fresh = torch.randint_like(self._max_lifespans, self.min_lifespan, self.max_lifespan)
-        self._max_lifespans[reset] = fresh[reset]
+        self._max_lifespans[:] = torch.where(reset, fresh, self._max_lifespans)
 
     def __call__(self, reset=None):
         self._lifespans += 1
