@@ -78,14 +78,28 @@ def env_step_fps(device, n_core_envs=4096, steps=60, warmup=10):
         for i in range(steps):
             env.step(arrdict.arrdict(actions=acts[warmup + i]))
         torch.cuda.synchronize()
-        return n*steps/(time.perf_counter() - t0)
+        eager = n*steps/(time.perf_counter() - t0)
+        # the same step captured once in a HIP graph and replayed (possible because nothing in it syncs with the host)
+        static = acts[0].clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            env.step(arrdict.arrdict(actions=static))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            static.copy_(acts[warmup + i])
+            graph.replay()
+        torch.cuda.synchronize()
+        return eager, n*steps/(time.perf_counter() - t0)
 
     out = {}
     np.random.seed(0); torch.manual_seed(0)
-    out['explorer'] = {'fps': rate(Explorer(n_core_envs, device=device, geometries=geometries), n_core_envs),
+    eager, graphed = rate(Explorer(n_core_envs, device=device, geometries=geometries), n_core_envs)
+    out['explorer'] = {'fps': eager, 'fps_hip_graph': graphed,
                        'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU'}
     torch.cuda.empty_cache()
-    out['deathmatch'] = {'fps': rate(Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries), 4*n_core_envs),
+    eager, graphed = rate(Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries), 4*n_core_envs)
+    out['deathmatch'] = {'fps': eager, 'fps_hip_graph': graphed,
                          'env': f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU'}
     return out
 
