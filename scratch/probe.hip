@@ -199,10 +199,11 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // ------------------------------------------------------------------------------------------------
 // physics                                                                    kernels.cu:179-230
 // ------------------------------------------------------------------------------------------------
-// A workgroup owns `envs_per_wg` whole envs, so that every read of the start-of-step agent state happens
-// before a barrier and every write after it (agents of one env read each other).  Its four waves split each
-// env's wall CHUNKS between them and test every chunk they load against all of the env's agents: a wave waits
-// on a quarter of the loads it would need if it owned one agent.
+// ONE WAVEFRONT PER ENV (workgroup = 64 threads): the step is a chain of dependent loads around very little
+// arithmetic, so what matters is how many envs are in flight and how few round trips each needs.  A wave asks for
+// its first wall chunks before anything else, reads the agents (lane = agent) while they travel, and keeps
+// PHYS_AHEAD chunks in flight through the sweep; agents of one env read each other's start-of-step state, which
+// one wave orders for free (all reads sit before the first write in program order).
 //
 // Reach cull (exact): all four sub-tests of collision_cs leave x = 1 for a wall farther from the agent than
 // 1.02|v| + 2r - the crossing and side tests need the wall within |v| + r of p, and an endpoint that far ahead
@@ -210,46 +211,61 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // arithmetic; the few (agent, wall) pairs in reach are compacted into LDS and only those pay for the ten
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
-__global__ __launch_bounds__(WG) void physics_kernel(
+constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
+
+__global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps, const int envs_per_wg) {
-    extern __shared__ float4 s_dyn[];            // per task: (p, v/fps) | reach^2 | progress bits
-    __shared__ float4 s_wall[WAVES][WAVE];       // per wave: walls within reach of ...
-    __shared__ int s_tag[WAVES][WAVE];           // ... this task
-    const int N = sc.n_envs, A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tasks = envs_per_wg*A;
-    const int env0 = blockIdx.x*envs_per_wg;
+        const float agent_radius, const float fps) {
+    extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
+    __shared__ float4 s_wall[WAVE];              // walls near ...
+    __shared__ int s_tag[WAVE];                  // ... this agent
+    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    const int lane = threadIdx.x;
+    const int n = blockIdx.x;
     float4* s_task = s_dyn;
-    float* s_reach2 = reinterpret_cast<float*>(s_task + tasks);
-    unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + tasks);
-    const float4* __restrict__ lines4 = reinterpret_cast<const float4*>(sc.lines_vals);
+    float4* s_box = s_task + A;
+    float* s_reach2 = reinterpret_cast<float*>(s_box + A);
+    unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + A);
     const float2* __restrict__ pos2 = reinterpret_cast<const float2*>(ag.positions);
     const float2* __restrict__ vel2 = reinterpret_cast<const float2*>(ag.velocity);
 
-    // one thread per (env, agent): its state, its reach, and the agent-agent tests (kernels.cu:193-200)
-    for (int t = tid; t < tasks; t += WG) {
-        const int n = env0 + t/A, a = t % A;
-        float reach2 = -1.f;                     // envs past the end: nothing is ever in reach
-        if (n < N) {
-            const float2 pp = pos2[n*A + a], mm = vel2[n*A + a];
-            const P2 p0 = p2(pp.x, pp.y);
-            const P2 v0 = p2(mm.x, mm.y)/fps;
-            float x = 1.f;
-            for (int d1 = 0; d1 < A; d1++) {
-                if (d1 != a) {
-                    const float2 q = pos2[n*A + d1], m1 = vel2[n*A + d1];
-                    x = ms_min(x, collision_cc(p0, v0, p2(q.x, q.y), p2(m1.x, m1.y)/fps, agent_radius));
-                }
-            }
-            const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
-            reach2 = (reach == reach) ? reach*reach : INFINITY;          // NaN velocities: test everything
-            s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
-            s_prog[t] = f_bits(x);
-        }
-        s_reach2[t] = reach2;
+    // the first wall chunks are requested before anything else: nothing below depends on them until the sweep
+    const int L = sc.lines_widths[n];
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
+    float4 w[PHYS_AHEAD];
+    #pragma unroll
+    for (int k = 0; k < PHYS_AHEAD; k++) {
+        const int l = AF + k*WAVE + lane;
+        w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (l < L) w[k] = ln[l];
     }
-    __syncthreads();
+
+    // one lane per agent: its state and reach ...
+    float2 my_p = make_float2(0.f, 0.f), my_v = make_float2(0.f, 0.f);   // agent `lane`, kept for the epilogue
+    float my_w = 0.f, my_ang = 0.f;
+    if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
+    for (int t = lane; t < A; t += WAVE) {
+        const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
+        const P2 p0 = p2(pp.x, pp.y);
+        const P2 v0 = p2(mm.x, mm.y)/fps;
+        const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+        s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
+        s_box[t] = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
+        s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
+        s_prog[t] = f_bits(1.f);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane
+    for (int i = lane; i < A*A; i += WAVE) {
+        const int t = i / A, d1 = i - t*A;
+        if (d1 != t) {
+            const float4 me = s_task[t], o = s_task[d1];
+            const float x = collision_cc(p2(me.x, me.y), p2(me.z, me.w), p2(o.x, o.y), p2(o.z, o.w), agent_radius);
+            if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+        }
+    }
 
     int cnt = 0;
     auto flush = [&]() {
@@ -257,44 +273,49 @@ __global__ __launch_bounds__(WG) void physics_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (lane < cnt) {
-            const float4 u = s_wall[wave][lane];
-            const int t = s_tag[wave][lane];
+            const float4 u = s_wall[lane];
+            const int t = s_tag[lane];
             const float4 tk = s_task[t];
-            const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
-            if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+            // squared distance from the agent to the segment, shaved so it is a lower bound
+            const float vx = u.z - u.x, vy = u.w - u.y;
+            const float pqx = u.x - tk.x, pqy = u.y - tk.y;
+            float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+            tc = fminf(fmaxf(tc, 0.f), 1.f);
+            tc = (tc == tc) ? tc : 0.f;
+            const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+            if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {             // NaNs stay in
+                const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
+                if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+            }
         }
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
     };
-    for (int e = 0; e < envs_per_wg; e++) {
-        const int n = env0 + e;
-        if (n >= N) break;
-        const int L = sc.lines_widths[n];
-        const float4* __restrict__ ln = lines4 + sc.lines_starts[n];
-        for (int l0 = AF + wave*WAVE; l0 < L; l0 += WAVES*WAVE) {
-            const bool live = l0 + lane < L;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) w = ln[l0 + lane];
-            const float vx = w.z - w.x, vy = w.w - w.y;
-            const float inv = __builtin_amdgcn_rcpf(vx*vx + vy*vy);
-            for (int a = 0; a < A; a++) {
-                const int t = e*A + a;
-                const float4 tk = s_task[t];
-                // squared distance from the agent to the segment, shaved so it is a lower bound
-                const float pqx = w.x - tk.x, pqy = w.y - tk.y;
-                float tc = -(pqx*vx + pqy*vy)*inv;
-                tc = fminf(fmaxf(tc, 0.f), 1.f);
-                tc = (tc == tc) ? tc : 0.f;
-                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-                const bool in = live & !(0.9998f*(qx*qx + qy*qy) > s_reach2[t]);      // NaNs stay in
+    // lane = wall: which agents' reach boxes does its bounding box touch?  Those (wall, agent) pairs are compacted
+    // into LDS and get the distance test and then the exact one, one pair per lane (kernels.cu:202-221)
+    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
+        #pragma unroll
+        for (int k = 0; k < PHYS_AHEAD; k++) {
+            const float4 u = w[k];
+            const bool live = l0 + k*WAVE + lane < L;
+            // the chunk PHYS_AHEAD further on takes this one's place
+            const int nl = l0 + (k + PHYS_AHEAD)*WAVE + lane;
+            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nl < L) w[k] = ln[nl];
+            if (l0 + k*WAVE >= L) continue;                             // uniform
+            const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
+            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
+            for (int t = 0; t < A; t++) {
+                const float4 bx = s_box[t];
+                const bool in = live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w)));
                 const unsigned long long m = __ballot(in);
                 if (m) {
                     const int nk = __popcll(m);
                     if (cnt + nk > WAVE) flush();
                     if (in) {
                         const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                        s_wall[wave][pos] = w;
-                        s_tag[wave][pos] = t;
+                        s_wall[pos] = u;
+                        s_tag[pos] = t;
                     }
                     cnt += nk;
                 }
@@ -302,21 +323,20 @@ __global__ __launch_bounds__(WG) void physics_kernel(
         }
     }
     if (cnt) flush();
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // epilogue, kernels.cu:224-227
     float2* __restrict__ pos2w = reinterpret_cast<float2*>(ag.positions);
     float2* __restrict__ vel2w = reinterpret_cast<float2*>(ag.velocity);
-    for (int t = tid; t < tasks; t += WG) {
-        const int n = env0 + t/A, a = t % A;
-        if (n >= N) continue;
-        const int i = n*A + a;
+    for (int t = lane; t < A; t += WAVE) {
+        const int i = n*A + t;
         const float x = bits_f(s_prog[t]);
-        float2 p = pos2w[i], v = vel2w[i];
+        float2 p = my_p, v = my_v;
+        float w_ = my_w, ang = my_ang;
+        if (t != lane) { p = pos2w[i]; v = vel2w[i]; w_ = ag.angvelocity[i]; ang = ag.angles[i]; }
         p.x = p.x + x*v.x/fps;
         p.y = p.y + x*v.y/fps;
         pos2w[i] = p;
-        float w = ag.angvelocity[i];
-        ag.angles[i] = normalize_degrees(ag.angles[i] + x*w/fps);
+        ag.angles[i] = normalize_degrees(ang + x*w_/fps);
         if (x < 1) {
             vel2w[i] = make_float2(0.f, 0.f);
             ag.angvelocity[i] = 0.f;
@@ -596,6 +616,24 @@ __device__ inline Filt tex_filter(float x, int w) {
 // sin/cos (binary64 inside, see sincospi_f) once, instead of once per wavefront of the raycast.
 // Workspace layout: [0] queue length, [1] rays that took the sequential fold, [2] wavefronts that took its lane-parallel
 // form (telemetry for tests) | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
+// Launch-invariant values the host works out once per ms_render call instead of every wave doing so on the VALU:
+// culling constants, and exact unsigned division by F = A*G, G and M via multiply-high (Granlund & Montgomery).
+struct Divisor { unsigned mul, sh1, sh2; };
+struct RenderConsts {
+    float x_clip, c_b;
+    Divisor by_f, by_g, by_m;
+};
+__host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
+    unsigned s = 0;
+    while ((1ull << s) < d) s++;
+    const unsigned long long m = ((1ull << 32)*((1ull << s) - d))/d + 1ull;
+    return Divisor{(unsigned)m, s < 1u ? s : 1u, s > 1u ? s - 1u : 0u};
+}
+__device__ inline int div_by(int n, const Divisor d) {     // n >= 0
+    const unsigned t = __umulhi(d.mul, (unsigned)n);
+    return (int)((t + (((unsigned)n - t) >> d.sh1)) >> d.sh2);
+}
+
 __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
                                                          const int n_agents_total, const int n_fans) {
     const int i = blockIdx.x*WG + threadIdx.x;
@@ -612,10 +650,12 @@ __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int*
 //          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
 // RW = waves per workgroup.  The waves never talk to each other, so RW = 1 lets every wave give its slot and
 // LDS back the moment it is done instead of waiting for the slowest of four.
-template <int IMPL, int RW>
-__global__ __launch_bounds__(RW*WAVE) void render_kernel(
+// OBS = 1: any of the five per-ray outputs may be NULL, and pooled observations are written on request (the plain
+// instantiation stays within 80 VGPRs: six waves per SIMD)
+template <int IMPL, int RW, int OBS>
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
-        const float agent_radius, const float half_screen, const int R, const int n_fans) {
+        const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
     //      0 cand   (64 x 16 B)  the chunk's 64 lines               | lighting: (wall, light) pair list, 2 KiB
     //   1024 ray    (64 x 16 B)  per ray: rx, ry, near              |
@@ -623,7 +663,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     //   2560 second, 3072 third                                     |
     //   3584 info   (64 x 4 B)   per line: (first pair << 6) | first ray
     //   3840 mark   (64 x 4 B)   pair window: which line starts here
-    //   4096 screen (192 x 4 B)  RGB staging; during the raycast: per-ray and per-group depth bounds
+    //   4096 screen (192 x 4 B)  RGB staging
     constexpr int LDS_PER_WAVE = 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
@@ -643,7 +683,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
-    const int n = fan / F, rem = fan - n*F, a = rem / G, g = rem - a*G;
+    const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
     const int r = g*WAVE + lane;
     const int r_last = min(g*WAVE + WAVE - 1, R - 1);
 
@@ -669,7 +709,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     auto agent_line = [&](const int l_) {
         const int l = min(max(l_, 0), AF - 1);
         if (A > WAVE) return drawn_line(sc, ag, n, l);
-        const int la = l / sc.n_model;
+        const int la = div_by(l, rc.by_m);
         const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
         const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
         const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
@@ -706,8 +746,8 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
     // Screen-space bookkeeping for the culling below.  In the agent frame (x' forward, y' left) a point
     // is seen at screen coordinate ys = y'/x', i.e. at the continuous ray index c_a - ys*c_b (ray_y inverted).
     // Nothing with x' below x_clip can be hit: a hit has x' = s > agent_radius/|ru| > 2 x_clip.
-    const float c_a = 0.5f*(Rf - 1.f), c_b = 0.5f*Rf/half_screen;
-    const float x_clip = 0.5f*agent_radius/sqrtf(1.f + half_screen*half_screen);
+    const float c_a = 0.5f*(Rf - 1.f), c_b = rc.c_b;                      // c_b = R/2/half_screen
+    const float x_clip = rc.x_clip;                                        // agent_radius/2/sqrt(1 + half_screen^2)
     const float g0 = (float)(g*WAVE);
     const int my_group = lane/GSIZE;
 
@@ -736,8 +776,6 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][3072]);
         int* const s_info_w = reinterpret_cast<int*>(&s_raw[wave][3584]);
         int* const s_mark_w = reinterpret_cast<int*>(&s_raw[wave][3840]);
-        float* const s_depth_w = reinterpret_cast<float*>(&s_raw[wave][4096]);     // culling bounds; the screen
-        float* const s_group_w = reinterpret_cast<float*>(&s_raw[wave][4352]);     // staging area is idle until the end
         s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
         s_best_w[lane] = ~0ull;
         s_second_w[lane] = ~0ull;
@@ -745,7 +783,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection into LDS, and the
         // conservative interval [lo, lo + len) of this wave's rays that can hit it
-        auto line_setup = [&](const int c0, int& lo, int& len, float& smin) {   // every lane comes in; dead ones leave with len 0
+        auto line_setup = [&](const int c0, int& lo, int& len) {       // every lane comes in; dead ones leave with len 0
             const int l = c0 + lane;
             const bool live = l < L;
             float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -767,10 +805,6 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
                 const float yc = ya + t*(yb - ya);
                 if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
             }
-            // In the agent frame a ray is (1, ray_y), so a hit's ray parameter s IS its x' coordinate, and x' is
-            // linear along the line: no hit on this line can have s below the smaller end (NaN: never culls)
-            smin = fminf(xa, xb);
-            smin = ((xa == xa) & (xb == xb)) ? smin : -INFINITY;
             const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
             const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
             const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
@@ -784,32 +818,8 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         TICK(0)
         for (int c0 = 0; c0 < L; c0 += WAVE) {
             int lo = 0, len = 0;
-            float smin = 0.f;
-            line_setup(c0, lo, len, smin);
+            line_setup(c0, lo, len);
             TICK(1)
-            if (c0 > 0) {
-                // Depth culling.  Each ray's least key so far bounds its final one from above, and a hit more than
-                // 3e-4 behind that can neither win nor come within the 1e-4 hysteresis band of the winner or of
-                // anything in the winner's band - which is all the resolution below looks at (the literal fold,
-                // for rays it cannot settle, sees every line).  So a line whose nearest point is that far behind
-                // every ray of its interval is dropped.  Bounds: per ray for intervals of one or two rays, per
-                // group of eight rays for wider ones.
-                const unsigned long long bk = s_best_w[lane];
-                float gb = (bk == ~0ull) ? INFINITY : bits_f((uint32_t)(bk >> 32));
-                gb = ((float)lane > last_local) ? 0.f : gb;             // rays past the last one never hit anything
-                s_depth_w[lane] = gb;
-                gb = fmaxf(gb, __shfl_xor(gb, 1, WAVE)); gb = fmaxf(gb, __shfl_xor(gb, 2, WAVE)); gb = fmaxf(gb, __shfl_xor(gb, 4, WAVE));
-                if ((lane & 7) == 0) s_group_w[lane >> 3] = gb;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int hi = min(lo + max(len, 1) - 1, WAVE - 1), lo_ = min(lo, WAVE - 1);
-                const int g_lo = lo_ >> 3, g_hi = hi >> 3;
-                const float near2 = fmaxf(s_depth_w[lo_], s_depth_w[hi]);
-                const float wide = fmaxf(fmaxf(s_group_w[g_lo], s_group_w[min(g_lo + 1, g_hi)]), s_group_w[g_hi]);
-                const float bound = (len <= 2) ? near2 : (g_hi - g_lo <= 2) ? wide : INFINITY;
-                if (smin > bound*(1.f + 1e-4f) + 4e-4f) len = 0;
-            }
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
@@ -898,8 +908,7 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
             int xi = -1;
             for (int c0 = 0; c0 < L; c0 += WAVE) {
                 int lo = 0, len = 0;
-                float smin = 0.f;
-                line_setup(c0, lo, len, smin);
+                line_setup(c0, lo, len);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1063,11 +1072,12 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         dt = dtop/(dbot + 1.e-6f);
     }
     const size_t o = ((size_t)n*A + a)*R + r;
+    const float dist = nearest_s*rlen;
     if (r < R) {
-        out.indices[o] = nearest_idx;
-        out.locations[o] = loc;
-        out.dots[o] = dt;
-        out.distances[o] = nearest_s*rlen;
+        if (!OBS || out.indices) out.indices[o] = nearest_idx;
+        if (!OBS || out.locations) out.locations[o] = loc;
+        if (!OBS || out.dots) out.dots[o] = dt;
+        if (!OBS || out.distances) out.distances[o] = dist;
     }
 
     TICK(5)
@@ -1108,17 +1118,19 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         s1 = dn*intensity*(f.lw*tl[1] + f.rw*tr[1]);
         s2 = dn*intensity*(f.lw*tl[2] + f.rw*tr[2]);
     }
-    // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
-    s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nfl = 3*(r_last - g*WAVE + 1);
-    float* __restrict__ scr = out.screen + 3*(((size_t)n*A + a)*R + g*WAVE);
-    #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int j = lane + k*WAVE;
-        if (j < nfl) scr[j] = s_screen_w[j];
+    if (!OBS || out.screen) {
+        // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
+        s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nfl = 3*(r_last - g*WAVE + 1);
+        float* __restrict__ scr = out.screen + 3*(((size_t)n*A + a)*R + g*WAVE);
+        #pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const int j = lane + k*WAVE;
+            if (j < nfl) scr[j] = s_screen_w[j];
+        }
     }
     TICK(7)
     {
@@ -1126,6 +1138,28 @@ __global__ __launch_bounds__(RW*WAVE) void render_kernel(
         #pragma unroll
         for (int k = 0; k < 8; k++) if (lane == k) v = (int)T_[k];
         if (lane < 9) reinterpret_cast<int*>(out.distances)[((size_t)n*A + a)*R + g*WAVE + lane] = v;
+    }
+    // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
+    // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
+    if (OBS && (out.obs_rgb || out.obs_depth)) {
+        const int sub = out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
+        float p0 = s0, p1 = s1, p2 = s2;
+        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/out.obs_max_depth, 0.f), 1.f);
+        for (int o2 = 1; o2 < sub; o2 <<= 1) {
+            p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE);
+            p2 += __shfl_xor(p2, o2, WAVE); pd += __shfl_xor(pd, o2, WAVE);
+        }
+        if (((lane & (sub - 1)) == 0) & (r < R)) {
+            const float fs = (float)sub;
+            const int W = R/sub, px = r/sub;
+            const size_t na = (size_t)n*A + a;
+            if (out.obs_rgb) {
+                out.obs_rgb[(na*3 + 0)*W + px] = p0/fs;
+                out.obs_rgb[(na*3 + 1)*W + px] = p1/fs;
+                out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
+            }
+            if (out.obs_depth) out.obs_depth[na*W + px] = pd/fs;
+        }
     }
 }
 
@@ -1649,21 +1683,21 @@ void ms_host_sincospi(float x, float* s, float* c) { sincospi_f(x, *s, *c); }
 
 int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
-    const int A = sc->n_agents;
-    const int envs_per_wg = A >= WAVES ? 1 : WAVES/A;
-    const int blocks = (sc->n_envs + envs_per_wg - 1)/envs_per_wg;
-    const size_t shmem = (sizeof(float)*4 + sizeof(float) + sizeof(unsigned))*(size_t)envs_per_wg*A;
-    if (shmem > 64*1024) return MS_EUNSUPPORTED;
-    hipLaunchKernelGGL(physics_kernel, dim3(blocks), dim3(WG), shmem, (hipStream_t)stream,
-                       *sc, *ag, progress, cfg->agent_radius, cfg->fps, envs_per_wg);
+    const size_t shmem = (sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
+    if (shmem > 60*1024) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(physics_kernel, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
+                       *sc, *ag, progress, cfg->agent_radius, cfg->fps);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
 
 int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {
-    if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !out->indices || !out->locations ||
-        !out->dots || !out->distances || !out->screen || !sc->textures_vals || !sc->textures_widths ||
+    if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !sc->textures_vals || !sc->textures_widths ||
         !sc->textures_starts || !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
+    if (out->obs_rgb || out->obs_depth) {
+        const int sub = out->obs_subsample;
+        if (sub < 1 || (sub & (sub - 1)) || sub > WAVE || cfg->res % sub || !(out->obs_max_depth > 0.f)) return MS_EINVAL;
+    }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
     const int G = (R + WAVE - 1)/WAVE;
@@ -1684,14 +1718,30 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
     if (!grid) scn.lg_vals = nullptr;
+    // the second kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
+    const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
+    const bool pooled = out->obs_rgb || out->obs_depth;
+    if (!all_planes && !(grid || sc->n_agents == 1)) return MS_EINVAL;
+    if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
+    const bool obs = pooled || !all_planes;
+    RenderConsts rc;
+    rc.x_clip = 0.5f*cfg->agent_radius/sqrtf(1.f + half_screen*half_screen);
+    rc.c_b = 0.5f*(float)R/half_screen;
+    rc.by_f = divisor_of((unsigned)(sc->n_agents*G));
+    rc.by_g = divisor_of((unsigned)G);
+    rc.by_m = divisor_of((unsigned)sc->n_model);
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
-    if (seq)
-        hipLaunchKernelGGL((render_kernel<0, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+    const dim3 rgrid(rblocks), rblock(RW*WAVE);
+    const hipStream_t hs = (hipStream_t)stream;
+    if (seq && obs)
+        hipLaunchKernelGGL((render_kernel<0, RW, 1>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else if (seq)
+        hipLaunchKernelGGL((render_kernel<0, RW, 0>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else if (obs)
+        hipLaunchKernelGGL((render_kernel<1, RW, 1>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else
-        hipLaunchKernelGGL((render_kernel<1, RW>), dim3(rblocks), dim3(RW*WAVE), 0, (hipStream_t)stream,
-                           scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans);
+        hipLaunchKernelGGL((render_kernel<1, RW, 0>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.
     if (!grid && sc->n_agents > 1)

@@ -9,16 +9,24 @@ def rep(old, new):
     src = src.replace(old, new, 1)
 rep("    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w",
     "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int Psum = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w")
-rep("        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            float smin = 0.f;\n            line_setup(c0, lo, len, smin);\n            if (c0 > 0) {",
-    "        TICK(0)\n        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            float smin = 0.f;\n            line_setup(c0, lo, len, smin);\n            TICK(1)\n            if (c0 > 0) {")
+rep("        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            line_setup(c0, lo, len);\n            const int incl = wave_scan_add(len);",
+    "        TICK(0)\n        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            line_setup(c0, lo, len);\n            TICK(1)\n            const int incl = wave_scan_add(len);")
 rep("            s_info_w[lane] = (first << 6) | (lo & 63);\n            int carry = -1;", "            s_info_w[lane] = (first << 6) | (lo & 63);\n            int carry = -1;\n            TICK(2)\n            Psum += P;")
 rep("                __builtin_amdgcn_wave_barrier();\n            }\n            __builtin_amdgcn_wave_barrier();\n        }\n        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        const unsigned long long best",
     "                __builtin_amdgcn_wave_barrier();\n            }\n            __builtin_amdgcn_wave_barrier();\n            TICK(3)\n        }\n        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        const unsigned long long best")
 rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(4)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
 rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(5)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
 rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(6)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
-rep("        if (j < nfl) scr[j] = s_screen_w[j];\n    }\n}\n",
-    "        if (j < nfl) scr[j] = s_screen_w[j];\n    }\n    TICK(7)\n    {\n        int v = Psum;\n        #pragma unroll\n        for (int k = 0; k < 8; k++) if (lane == k) v = (int)T_[k];\n        if (lane < 9) reinterpret_cast<int*>(out.distances)[((size_t)n*A + a)*R + g*WAVE + lane] = v;\n    }\n}\n")
+src = src.rstrip()
+assert src.count("    // ---- pooled observations") == 1
+src = src.replace("    // ---- pooled observations", """    TICK(7)
+    {
+        int v = Psum;
+        #pragma unroll
+        for (int k = 0; k < 8; k++) if (lane == k) v = (int)T_[k];
+        if (lane < 9) reinterpret_cast<int*>(out.distances)[((size_t)n*A + a)*R + g*WAVE + lane] = v;
+    }
+    // ---- pooled observations""", 1)
 os.makedirs(f'{root}/scratch', exist_ok=True)
 open(f'{root}/scratch/probe.hip', 'w').write(src.replace('../../include/megastep_hip.h', 'megastep_hip.h'))
 flags = '--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero'.split()
