@@ -793,22 +793,23 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
             const float dbx = w.z - pp.x, dby = w.w - pp.y;
             s_cand_w[lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
-            // agent-frame coordinates of both endpoints
-            float xa = cs*pqx + sn*pqy, ya = cs*pqy - sn*pqx;
-            float xb = cs*dbx + sn*dby, yb = cs*dby - sn*dbx;
+            // agent-frame coordinates of both endpoints.  From here on everything only feeds the cull, whose margin
+            // is 10^5 roundings wide: fused multiply-adds and approximate reciprocals are fine
+            float xa = __builtin_fmaf(cs, pqx, sn*pqy), ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
+            float xb = __builtin_fmaf(cs, dbx, sn*dby), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
             const bool fa = xa >= x_clip, fb = xb >= x_clip;
             const bool inc = fa | fb | !(xa == xa) | !(xb == xb);       // wholly behind the clip plane: never hit
             if (fa != fb) {                                             // clip the hidden end to x' = x_clip
                 const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
-                const float yc = ya + t*(yb - ya);
+                const float yc = __builtin_fmaf(t, yb - ya, ya);
                 if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
             }
             const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
-            const float ra = c_a - ysa*c_b, rb = c_a - ysb*c_b;
-            const float marg = 0.05f + 1e-4f*(fabsf(ra) + fabsf(rb));
+            const float ra = __builtin_fmaf(-ysa, c_b, c_a), rb = __builtin_fmaf(-ysb, c_b, c_a);
+            const float marg = __builtin_fmaf(1e-4f, fabsf(ra) + fabsf(rb), 0.05f);
             // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
-            const float flo = fminf(fmaxf(fminf(ra, rb) - marg - g0, 0.f), 64.f);
-            const float fhi = fmaxf(fminf(fmaxf(ra, rb) + marg - g0, last_local), -1.f);
+            const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
+            const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
             lo = (int)ceilf(flo);
             len = (live & inc) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
         };
