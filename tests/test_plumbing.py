@@ -134,3 +134,47 @@ def test_shard_scenery_reassembles():
         widths = torch.cat([getattr(s, name).widths for s in shards])
         assert torch.equal(vals, getattr(full, name).vals) and torch.equal(widths, getattr(full, name).widths)
     assert shards[1].lines.starts[0] == 0 and shards[1].textures.starts[0] == 0
+
+
+def test_light_grid_shard_repacks_candidate_lists():
+    """sharding._shard_light_grid: a shard's cells keep their verdicts and candidate lists; the lists move to a
+    pool of the shard's own (the parent's pool is filled in no particular order). Pure tensor logic, so it runs here."""
+    import torch
+    from megastep_amd import sharding
+    rng = np.random.RandomState(0)
+    dims = np.array([[3, 2], [1, 4], [2, 2], [5, 1]])
+    cells = dims.prod(1)
+    starts = torch.tensor(np.concatenate([[0], np.cumsum(cells)[:-1]]), dtype=torch.int32)
+    geom = torch.tensor(np.concatenate([rng.uniform(0, 5, (4, 2)), dims], 1), dtype=torch.float32)
+    total = int(cells.sum())
+    vals = torch.tensor(rng.randint(0, 2**31 - 1, (total, 4)), dtype=torch.int32)
+    counts = rng.randint(0, 6, total)
+    counts[rng.choice(total, 4, replace=False)] = -1                    # cells without a list
+    order = rng.permutation(total)                                       # pool filled in no particular order
+    pool = [0]
+    lists = np.zeros((total, 2), np.int64)
+    wanted = {}
+    for c in order:
+        if counts[c] < 0:
+            continue
+        entries = (0x80000000 | rng.randint(0, 2**24, counts[c])).astype(np.int64)
+        lists[c] = [len(pool), 0x80000000 | counts[c]]
+        pool.extend(entries.tolist())
+        wanted[c] = sorted(entries.tolist())
+    pool[0] = len(pool) - 1
+    to_i32 = lambda a: torch.tensor((np.asarray(a, np.int64) & 0xffffffff).astype(np.uint32).view(np.int32))
+    lg = (vals, starts, geom, .25, int(cells.max()), to_i32(lists), to_i32(pool))
+    for start, stop in [(0, 2), (1, 4), (2, 3), (0, 4)]:
+        v, s, g, cell, mx, l, p = sharding._shard_light_grid(lg, start, stop, 'cpu')
+        c0, c1 = int(starts[start]), int(starts[stop]) if stop < 4 else total
+        assert torch.equal(v, vals[c0:c1]) and torch.equal(g, geom[start:stop]) and cell == .25
+        assert s.tolist() == (starts[start:stop] - c0).tolist() and mx == int(cells[start:stop].max())
+        l64, p64 = l.long() & 0xffffffff, p.long() & 0xffffffff
+        assert int(p64[0]) == len(p) - 1
+        for i, c in enumerate(range(c0, c1)):
+            if counts[c] < 0:
+                assert int(l64[i, 1]) == 0
+            else:
+                first, n = int(l64[i, 0]), int(l64[i, 1]) & 0x7fffffff
+                assert int(l64[i, 1]) >> 31 == 1 and n == counts[c] and first >= 1
+                assert sorted(p64[first:first + n].tolist()) == wanted[c]
