@@ -252,7 +252,7 @@ def main():
             'parallelism': f'env-sharded x{world}, no collectives'},
         'agent_steps_per_sec': value*A,
         'roofline': {
-            'kernel': 'ms_render = render_prep_kernel + render_kernel<1,1>', 'bound': 'hbm', 'achieved': achieved,
+            'kernel': 'ms_render = render_kernel<1,1,0> (headings cached by ms_physics)', 'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS, 'traffic': measured_traffic(args, world),
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
             'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9},

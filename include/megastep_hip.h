@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 5
+#define MS_ABI_VERSION 6
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -93,6 +93,12 @@ typedef struct MsAgents {
     float* positions;     /* (N, A, 2) metres            */
     float* angvelocity;   /* (N, A)    degrees / second  */
     float* velocity;      /* (N, A, 2) metres / second   */
+    /* Optional heading cache (NULL = none; no counterpart in the reference), (N, A, 4): [angle, sin, cos, unused].
+     * ms_physics, which has each agent's new angle in hand, leaves its sine and cosine here; ms_render uses an
+     * entry when its angle equals the agent's current one bit for bit, and works the pair out itself otherwise
+     * (an agent turned by the caller in between).  Same function, same bits either way - it saves ms_render a launch.
+     * Must start as NaNs (or any value no angle takes); pass NULL to ms_render to get its self-contained path. */
+    float* headings;
 } MsAgents;
 
 /* Replaces `Render` (common.h:216-222). Caller-allocated outputs.  With a light grid in the scenery any of the

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -37,7 +37,8 @@ class MsScenery(C.Structure):
 
 
 class MsAgents(C.Structure):
-    _fields_ = [('angles', C.c_void_p), ('positions', C.c_void_p), ('angvelocity', C.c_void_p), ('velocity', C.c_void_p)]
+    _fields_ = [('angles', C.c_void_p), ('positions', C.c_void_p), ('angvelocity', C.c_void_p), ('velocity', C.c_void_p),
+                ('headings', C.c_void_p)]
 
 
 class MsRender(C.Structure):

@@ -336,7 +336,13 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         p.x = p.x + x*v.x/fps;
         p.y = p.y + x*v.y/fps;
         pos2w[i] = p;
-        ag.angles[i] = normalize_degrees(ang + x*w_/fps);
+        const float turned = normalize_degrees(ang + x*w_/fps);
+        ag.angles[i] = turned;
+        if (ag.headings) {                                   // what render_prep_kernel would compute, one launch earlier
+            float hs, hc;
+            sincospi_f(turned/180.f, hs, hc);
+            reinterpret_cast<float4*>(ag.headings)[i] = make_float4(turned, hs, hc, 0.f);
+        }
         if (x < 1) {
             vel2w[i] = make_float2(0.f, 0.f);
             ag.angvelocity[i] = 0.f;
@@ -694,7 +700,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     float ag_s = 0.f, ag_c = 0.f;
     float2 ag_p = make_float2(0.f, 0.f);
     if (lane < A) {
-        if (out.workspace) {
+        if (ag.headings) {                                   // ms_physics' cache, valid while the angle has not changed
+            const float4 h = reinterpret_cast<const float4*>(ag.headings)[n*A + lane];
+            const float angle = ag.angles[n*A + lane];
+            ag_s = h.y; ag_c = h.z;
+            if (f_bits(h.x) != f_bits(angle)) sincospi_f(angle/180.f, ag_s, ag_c);
+        } else if (out.workspace) {
             const float2 sc_ = reinterpret_cast<const float2*>(out.workspace + 16 + ((n_fans + 1) & ~1))[n*A + lane];
             ag_s = sc_.x; ag_c = sc_.y;
         } else {
@@ -1692,16 +1703,27 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
     // (kept for A/B verification); both produce the same bits.
     static const bool seq = [] { const char* e = getenv("MEGASTEP_RENDER_IMPL"); return e && e[0] == 's'; }();
-    if (out->workspace) {
-        if ((uintptr_t)out->workspace % 8) return MS_EINVAL;
-        const int na = sc->n_envs*sc->n_agents;
-        hipLaunchKernelGGL(render_prep_kernel, dim3((na + WG - 1)/WG), dim3(WG), 0, (hipStream_t)stream,
-                           *ag, out->workspace, na, (int)n_fans);
-    }
     // the light grid is all or nothing: render_kernel lights agent-hit rays itself when it is there
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
     if (!grid) scn.lg_vals = nullptr;
+    // Headings: from ms_physics' cache when the agents carry one and a single kernel does the whole job (then the
+    // workspace is not needed at all); otherwise from render_prep_kernel, which also resets the workspace's counters.
+    MsAgents agn = *ag;
+    MsRender outn = *out;
+    const bool one_kernel = grid || sc->n_agents == 1;
+    if (ag->headings && one_kernel) {
+        if ((uintptr_t)ag->headings % 16) return MS_EINVAL;
+        outn.workspace = nullptr;
+    } else {
+        agn.headings = nullptr;
+        if (out->workspace) {
+            if ((uintptr_t)out->workspace % 8) return MS_EINVAL;
+            const int na = sc->n_envs*sc->n_agents;
+            hipLaunchKernelGGL(render_prep_kernel, dim3((na + WG - 1)/WG), dim3(WG), 0, (hipStream_t)stream,
+                               *ag, out->workspace, na, (int)n_fans);
+        }
+    }
     // the second kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
     const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
     const bool pooled = out->obs_rgb || out->obs_depth;
@@ -1719,13 +1741,13 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
     const hipStream_t hs = (hipStream_t)stream;
     if (seq && obs)
-        hipLaunchKernelGGL((render_kernel<0, RW, 1>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+        hipLaunchKernelGGL((render_kernel<0, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else if (seq)
-        hipLaunchKernelGGL((render_kernel<0, RW, 0>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+        hipLaunchKernelGGL((render_kernel<0, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else if (obs)
-        hipLaunchKernelGGL((render_kernel<1, RW, 1>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+        hipLaunchKernelGGL((render_kernel<1, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else
-        hipLaunchKernelGGL((render_kernel<1, RW, 0>), rgrid, rblock, 0, hs, scn, *ag, *out, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+        hipLaunchKernelGGL((render_kernel<1, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.
     if (!grid && sc->n_agents > 1)

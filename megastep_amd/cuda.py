@@ -152,7 +152,13 @@ class Agents:
         n, a = angles.shape
         if positions.shape != (n, a, 2) or velocity.shape != (n, a, 2) or angvelocity.shape != (n, a):
             raise RuntimeError('agent tensors must be (N, A), (N, A, 2), (N, A), (N, A, 2)')
-        self._struct = _lib.MsAgents(angles.data_ptr(), positions.data_ptr(), angvelocity.data_ptr(), velocity.data_ptr())
+        # The heading cache (include/megastep_hip.h, MsAgents.headings): physics leaves each agent's sin/cos there for
+        # the next render. `_struct` carries it; `_plain` does not, for renders before any physics call has filled it.
+        self._headings = torch.full((n, a, 4), float('nan'), dtype=torch.float32, device=angles.device)
+        ptrs = (angles.data_ptr(), positions.data_ptr(), angvelocity.data_ptr(), velocity.data_ptr())
+        self._struct = _lib.MsAgents(*ptrs, self._headings.data_ptr())
+        self._plain = _lib.MsAgents(*ptrs, None)
+        self._cached = False
         devices = {t.device for t in (angles, positions, angvelocity, velocity)}
         self._dev = devices.pop() if len(devices) == 1 else None         # None: tensors on mixed devices
 
@@ -343,20 +349,22 @@ def physics(scenery, agents):
     with _on(dev):
         _lib.check(_lib.lib().ms_physics(C.byref(scenery._as_struct()), C.byref(agents._struct),
                                          C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
+    agents._cached = True
     return Physics(progress)
 
 
 FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
 
 
-def render(scenery, agents, fields=None, pooled=None):
+def render(scenery, agents, fields=None, pooled=None, telemetry=False):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
 
     Two extensions over the reference, both off by default: ``fields`` names the per-ray outputs that are wanted
     (the others are neither written nor allocated), and ``pooled=dict(subsample=s, max_depth=d, rgb=True, depth=True)``
     has the kernel write the mean-pooled observations of ``modules.RGB`` / ``modules.Depth`` itself
-    (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s))."""
+    (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s)). ``telemetry=True`` (tests) takes the
+    self-contained path whose scratch counters end up in ``Render._telemetry``."""
     dev = scenery._device()
     _agents_on(agents, dev)
     n, a = agents.angles.shape
@@ -394,8 +402,9 @@ def render(scenery, agents, fields=None, pooled=None):
     obs_rgb, obs_depth = piece(5, (n, a, 3, w)), piece(6, (n, a, w))
     out = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth)
     with _on(dev):
-        _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct), C.byref(out),
-                                        C.byref(cfg), _stream(dev)))
+        use_cache = agents._cached and not telemetry
+        _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
+                                        C.byref(out), C.byref(cfg), _stream(dev)))
     result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None)
     result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel; read by the tests
     return result

@@ -136,7 +136,7 @@ def test_hysteresis_band_adversarial():
     from megastep_amd import cuda
     ref = util.OracleWorld(c)
     ref.bake(); ref.pull_baked(c); ref.pull_agents(c)
-    r = cuda.render(c.scenery, c.agents)
+    r = cuda.render(c.scenery, c.agents, telemetry=True)
     util.assert_render_matches(c, r, ref.render())
     if not os.environ.get('MEGASTEP_RENDER_IMPL', '').startswith('s'):
         # the scenes are there to drive the sequential-fold fallbacks: make sure they did (render_prep_kernel's telemetry)
@@ -442,3 +442,30 @@ def test_unwanted_outputs_are_skipped_and_wanted_ones_unchanged():
         cuda.render(c.scenery, c.agents, pooled=dict(subsample=3))               # not a power of two
     with pytest.raises(RuntimeError):
         cuda.render(c.scenery, c.agents, pooled=dict(subsample=8))               # does not divide 100
+
+
+def test_heading_cache_is_used_only_while_it_is_true():
+    """ms_physics leaves every agent's sin/cos for the next ms_render (MsAgents.headings); an agent the caller turns in
+    between must be rendered from its new angle. Same bits as the self-contained path in every case."""
+    from megastep_amd import cuda
+    c, _ = _world(10, 4, 64, 130, seed=13)
+    rng = np.random.RandomState(5)
+    util.random_velocities(c, rng, speed=3.)
+    assert not c.agents._cached
+    cuda.physics(c.scenery, c.agents)
+    assert c.agents._cached
+    h = c.agents._headings
+    assert torch.equal(h[..., 0], c.agents.angles)
+    s, co = h[..., 1].double(), h[..., 2].double()
+    assert float((s*s + co*co - 1).abs().max()) < 1e-6
+    def same(a, b):
+        return all(torch.equal(torch.nan_to_num(getattr(a, f).float(), nan=-7.), torch.nan_to_num(getattr(b, f).float(), nan=-7.)) for f in cuda.FIELDS)
+    assert same(cuda.render(c.scenery, c.agents), cuda.render(c.scenery, c.agents, telemetry=True))
+    # turn some agents behind the cache's back (what a respawn does)
+    c.agents.angles[::2, 1] += 33.
+    c.agents.angles[3, :] = torch.tensor([0., -180., 179.99999, 90.], device='cuda')
+    fresh = cuda.render(c.scenery, c.agents)
+    assert same(fresh, cuda.render(c.scenery, c.agents, telemetry=True))
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c); ref.pull_agents(c)
+    util.assert_render_matches(c, fresh, ref.render())
