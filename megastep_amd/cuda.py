@@ -144,6 +144,8 @@ class Agents:
     """Holds the (N, A[, 2]) state tensors of the agents (reference: common.h:157-177, wrappers.cpp:103-120).
     :func:`physics` updates them in place."""
 
+    HEADING_CACHE_MAX_AGENTS = 32768
+
     def __init__(self, angles, positions, angvelocity, velocity):
         self._angles = _check(angles, 'angles', torch.float32, 2)
         self._positions = _check(positions, 'positions', torch.float32, 3)
@@ -159,6 +161,9 @@ class Agents:
         self._struct = _lib.MsAgents(*ptrs, self._headings.data_ptr())
         self._plain = _lib.MsAgents(*ptrs, None)
         self._cached = False
+        # Worth it while the batch is small enough for a launch to cost more than the sin/cos do inside physics
+        # (measured: 16 k agents -2 us per step, 64 k agents +4 us)
+        self._use_cache = n*a <= self.HEADING_CACHE_MAX_AGENTS
         devices = {t.device for t in (angles, positions, angvelocity, velocity)}
         self._dev = devices.pop() if len(devices) == 1 else None         # None: tensors on mixed devices
 
@@ -347,9 +352,9 @@ def physics(scenery, agents):
                            f'{(len(scenery.lines), scenery.n_agents)}, got {tuple(agents.angles.shape)}')
     progress = torch.empty_like(agents.angles)
     with _on(dev):
-        _lib.check(_lib.lib().ms_physics(C.byref(scenery._as_struct()), C.byref(agents._struct),
+        _lib.check(_lib.lib().ms_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
                                          C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
-    agents._cached = True
+    agents._cached = agents._use_cache
     return Physics(progress)
 
 
