@@ -16,10 +16,17 @@
  *   physics : pinned by the reference's one documented known answer
  *             (docs/tutorials/minimal-env/index.rst:140-145 -> x = 5.8649).
  *   ragged  : pinned by ragged.py:77-103 and docs/concepts.rst:205-219.
- *   render / bake / shader : PARITY UNPINNED by the reference (it has no test,
- *             fixture or golden vector for them, and its CUDA extension can be
- *             neither built nor run in the authoring container).  They are
- *             pinned only by analytic closed forms (tests/test_oracle.py).
+ *   render  : hit indices and hues pinned by the one rendered output the
+ *             reference publishes, docs/tutorials/minimal-env/render.png (64
+ *             columns: which wall each ray lands on, each wall's colour
+ *             direction through texture, shading and gamma);
+ *             tests/golden/make_docs_render.py, tests/test_oracle.py.
+ *   render (distances, locations, dots, brightness) / bake : PARITY UNPINNED
+ *             by the reference (it has no test, fixture or golden vector for
+ *             them - the image's textures and light were drawn from an unseeded
+ *             RNG - and its CUDA extension can be neither built nor run in the
+ *             authoring container).  Pinned only by analytic closed forms
+ *             (tests/test_oracle.py).
  *
  * Deliberate, documented definitions where the CUDA source leaves the bits to
  * the toolchain (all within the 1e-5 tolerance of BASELINE.json):

@@ -185,3 +185,36 @@ def test_hysteresis_keeps_first_of_coincident_walls(oracle):
     assert first_hit(np.concatenate([wall(4.), wall(3.99995)]))[0] == 8       # closer by 5e-5: not enough
     assert first_hit(np.concatenate([wall(4.), wall(3.9995)]))[0] == 9        # closer by 5e-4: wins
     assert first_hit(np.concatenate([wall(3.99995), wall(4.)]))[0] == 8
+
+
+def test_render_against_the_reference_docs_image(oracle):
+    """The one rendered output the reference publishes: docs/tutorials/minimal-env/render.png = gamma_encode(r.screen)
+    for toys.box(), agent at (3, 3), heading 0, 64 rays, fov 130 (index.rst:100-120; columns extracted by
+    tests/golden/make_docs_render.py). Its texture pattern and light intensity were random, so brightness is not
+    comparable - but which wall each of the 64 rays lands on is, and so is each wall's hue, which survives any scalar
+    brightness factor through the gamma curve: (k c^2.2)^(1/2.2) = k' c."""
+    import os
+    from megastep_amd import core, scene, toys
+    cols = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'docs_render_columns.npy')).astype(np.float64)
+    assert cols.shape == (64, 3)
+    # the image's own segmentation: purple (R > B > G) | brown (R > G > B) | blue (B > G > R)
+    order = np.argsort(-cols, 1)
+    classes = np.array([{(0, 2, 1): 0, (0, 1, 2): 1, (2, 1, 0): 2}[tuple(o)] for o in order])
+    assert (classes[:17] == 0).all() and (classes[17:42] == 1).all() and (classes[42:] == 2).all()
+
+    g = toys.box()
+    agentlines = scene.agent_model()
+    lines = np.concatenate([agentlines, g.walls])
+    tex, texw = scene.init_textures(agentlines, scene.agent_colors(), g.walls, np.random.RandomState(0))
+    S = oracle.Scene(dict(
+        n_agents=1, model=agentlines, lights_vals=scene.random_lights(g.lights, np.random.RandomState(1)), lights_widths=[len(g.lights)],
+        lines_vals=lines, lines_widths=[len(lines)], textures_vals=tex, textures_widths=texw))
+    cfg = oracle.config(core.AGENT_RADIUS, 64, 130, 10)
+    S.baked_vals[:] = oracle.bake(S, cfg)
+    r = oracle.render(S, agents([[3., 3.]]), cfg)
+    idx = r['indices'][0, 0]
+    # wall 0 (y = 6, on the agent's left) for 17 rays, wall 3 (x = 6, ahead) for 25, wall 2 (y = 1, right) for 22
+    np.testing.assert_array_equal(idx, [8]*17 + [11]*25 + [10]*22)
+    shown = core.gamma_encode(r['screen'][0, 0].astype(np.float64))
+    cos = (shown*cols).sum(1)/np.linalg.norm(shown, axis=1)/np.linalg.norm(cols, axis=1)
+    assert cos.min() > .999, cos.min()                     # hue of every column = the reference's, to 8-bit rounding
