@@ -20,7 +20,7 @@
  *             reference publishes, docs/tutorials/minimal-env/render.png (64
  *             columns: which wall each ray lands on, each wall's colour
  *             direction through texture, shading and gamma);
- *             tests/golden/make_docs_render.py, tests/test_oracle.py.
+ *             tests/golden/make_docs_images.py, tests/test_oracle.py.
  *   render (distances, locations, dots, brightness) / bake : PARITY UNPINNED
  *             by the reference (it has no test, fixture or golden vector for
  *             them - the image's textures and light were drawn from an unseeded

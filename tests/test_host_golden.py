@@ -165,3 +165,20 @@ def test_spawn_tables_reproduce_reference_rng_stream():
     sp = modules.RandomSpawns(geoms, fc, n_spawns=10)
     close(sp._spawns.angles.numpy(), G['spawns_angles'], 1e-5)
     close(sp._spawns.positions.numpy(), G['spawns_positions'], 1e-6)
+
+
+def test_masks_reproduce_the_reference_docs_figure():
+    """geometry.masks on the geometry tutorial's 5 m box against what the reference's own masks() returned for it, read
+    off docs/tutorials/geometry/walls-masks.png cell by cell (tests/golden/make_docs_images.py): the reference uses
+    rasterio + shapely for this, absent here, so this figure is the only pin of our rasteriser's conventions."""
+    import os
+    from megastep_amd import geometry
+    want = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'docs_geometry_masks.npy'))
+    corners = 5*np.array([[0, 0], [0, 1], [1, 1], [1, 0]]) + 1
+    walls = np.stack(geometry.cyclic_pairs(corners))
+    got = geometry.masks(walls, [corners])
+    assert got.shape == want.shape == (36, 36)
+    np.testing.assert_array_equal(got, want)
+    # and toys.box() is that geometry (toys.py:5-16)
+    from megastep_amd import toys
+    np.testing.assert_array_equal(toys.box().masks, want)

@@ -190,7 +190,7 @@ def test_hysteresis_keeps_first_of_coincident_walls(oracle):
 def test_render_against_the_reference_docs_image(oracle):
     """The one rendered output the reference publishes: docs/tutorials/minimal-env/render.png = gamma_encode(r.screen)
     for toys.box(), agent at (3, 3), heading 0, 64 rays, fov 130 (index.rst:100-120; columns extracted by
-    tests/golden/make_docs_render.py). Its texture pattern and light intensity were random, so brightness is not
+    tests/golden/make_docs_images.py). Its texture pattern and light intensity were random, so brightness is not
     comparable - but which wall each of the 64 rays lands on is, and so is each wall's hue, which survives any scalar
     brightness factor through the gamma curve: (k c^2.2)^(1/2.2) = k' c."""
     import os
