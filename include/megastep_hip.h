@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 6
+#define MS_ABI_VERSION 7
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -141,9 +141,23 @@ int         ms_device_count(void);
  * initialize() constants and runs before any Core exists, scene.py:98). */
 int ms_bake(const MsScenery* scenery, const MsConfig* config, void* hip_stream);
 
+/* Optional prologue of the physics step: what the reference's movement modules do with a handful of tensor ops right
+ * before they call physics (modules.py:24-66 SimpleMovement, :68-118 MomentumMovement).  Per agent, with (dx, dy, dw)
+ * the table row of its action and (c, s) = cos, sin of its heading in radians (binary32, as torch evaluates them):
+ *   angvelocity <- keep * angvelocity + dw;  velocity <- keep * velocity + (c dx - s dy, s dx + c dy)
+ * written back to the agents' tensors as the modules do, then the step proceeds.  keep = 1 - decay; keep = 0 assigns. */
+typedef struct MsMovement {
+    const long long* actions;   /* (N, A) row of `table` per agent (clamped to the table) */
+    const float*     table;     /* (n_actions, 3) [dx, dy, dw]: agent-frame velocity and angular velocity deltas */
+    int              n_actions;
+    float            keep;
+} MsMovement;
+
 /* Replaces `physics(scenery, agents) -> Physics` (wrappers.cpp:69, kernels.cu:179-230):
  * collision-limited integration of the agents, in place; `progress` is the (N, A) output that
  * the reference returns as Physics.progress. */
+int ms_move_physics(const MsScenery* scenery, const MsAgents* agents, const MsMovement* movement /* NULL: none */,
+                    float* progress, const MsConfig* config, void* hip_stream);
 int ms_physics(const MsScenery* scenery, const MsAgents* agents, float* progress,
                const MsConfig* config, void* hip_stream);
 

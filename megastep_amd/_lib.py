@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -41,6 +41,10 @@ class MsAgents(C.Structure):
                 ('headings', C.c_void_p)]
 
 
+class MsMovement(C.Structure):
+    _fields_ = [('actions', C.c_void_p), ('table', C.c_void_p), ('n_actions', C.c_int), ('keep', C.c_float)]
+
+
 class MsRender(C.Structure):
     _fields_ = [('indices', C.c_void_p), ('locations', C.c_void_p), ('dots', C.c_void_p), ('distances', C.c_void_p),
                 ('screen', C.c_void_p), ('workspace', C.c_void_p), ('obs_rgb', C.c_void_p), ('obs_depth', C.c_void_p),
@@ -48,7 +52,7 @@ class MsRender(C.Structure):
 
 
 #: every symbol include/megastep_hip.h declares
-SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics',
+SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_render', 'ms_host_sincospi')
 
 
@@ -85,9 +89,11 @@ def lib():
         handle.ms_device_count.restype = C.c_int
         handle.ms_bake.argtypes = [C.POINTER(MsScenery), C.POINTER(MsConfig), C.c_void_p]
         handle.ms_physics.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.c_void_p, C.POINTER(MsConfig), C.c_void_p]
+        handle.ms_move_physics.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsMovement), C.c_void_p,
+                                           C.POINTER(MsConfig), C.c_void_p]
         handle.ms_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]
         handle.ms_host_sincospi.argtypes = [C.c_float, _f32p, _f32p]
-        for name in ('ms_bake', 'ms_physics', 'ms_render'):
+        for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_render'):
             getattr(handle, name).restype = C.c_int
         if handle.ms_abi_version() != ABI_VERSION:
             raise ImportError(f'{LIB_PATH} has ABI {handle.ms_abi_version()}, this package needs {ABI_VERSION}; rebuild it')

@@ -213,9 +213,11 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
 constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
 
+// MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
+template <int MOVE>
 __global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps) {
+        const float agent_radius, const float fps, const MsMovement mv) {
     extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
     __shared__ float4 s_wall[WAVE];              // walls near ...
     __shared__ int s_tag[WAVE];                  // ... this agent
@@ -244,6 +246,26 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     float2 my_p = make_float2(0.f, 0.f), my_v = make_float2(0.f, 0.f);   // agent `lane`, kept for the epilogue
     float my_w = 0.f, my_ang = 0.f;
     if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
+    if constexpr (MOVE == 1) {
+        // modules.py:57-66,106-118: look the action up, turn its velocity delta into the global frame, blend
+        auto moved = [&](const int i, const float ang, float2& v, float& w) {
+            const long long act = min(max(mv.actions[i], 0ll), (long long)mv.n_actions - 1);
+            const float dx = mv.table[3*act], dy = mv.table[3*act + 1], dw = mv.table[3*act + 2];
+            const float a_ = 0.017453292519943295f*ang;                 // np.pi/180*angles, in binary32 like torch
+            const float s_ = sinf(a_), c_ = cosf(a_);
+            const float gx = c_*dx - s_*dy, gy = s_*dx + c_*dy;
+            if (mv.keep == 0.f) { w = dw; v = make_float2(gx, gy); }
+            else { w = mv.keep*w + dw; v = make_float2(mv.keep*v.x + gx, mv.keep*v.y + gy); }
+            ag.angvelocity[i] = w;
+            reinterpret_cast<float2*>(ag.velocity)[i] = v;
+        };
+        if (lane < A) moved(n*A + lane, my_ang, my_v, my_w);
+        for (int t = lane + WAVE; t < A; t += WAVE) {                   // agents beyond the first 64: through memory
+            float2 v = vel2[n*A + t];
+            float w = ag.angvelocity[n*A + t];
+            moved(n*A + t, ag.angles[n*A + t], v, w);
+        }
+    }
     for (int t = lane; t < A; t += WAVE) {
         const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
         const P2 p0 = p2(pp.x, pp.y);
@@ -1676,14 +1698,24 @@ int ms_device_count(void) {
 
 void ms_host_sincospi(float x, float* s, float* c) { sincospi_f(x, *s, *c); }
 
-int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
+int ms_move_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, float* progress, const MsConfig* cfg,
+                    void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
+    if (mv && (!mv->actions || !mv->table || mv->n_actions < 1 || !(mv->keep == mv->keep))) return MS_EINVAL;
     const size_t shmem = (sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
     if (shmem > 60*1024) return MS_EUNSUPPORTED;
-    hipLaunchKernelGGL(physics_kernel, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
-                       *sc, *ag, progress, cfg->agent_radius, cfg->fps);
+    if (mv)
+        hipLaunchKernelGGL(physics_kernel<1>, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
+                           *sc, *ag, progress, cfg->agent_radius, cfg->fps, *mv);
+    else
+        hipLaunchKernelGGL(physics_kernel<0>, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
+                           *sc, *ag, progress, cfg->agent_radius, cfg->fps, MsMovement{nullptr, nullptr, 0, 0.f});
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
+    return ms_move_physics(sc, ag, nullptr, progress, cfg, stream);
 }
 
 int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {

@@ -342,18 +342,31 @@ def bake(scenery):
         _lib.check(_lib.lib().ms_bake(C.byref(scenery._as_struct()), cfg, _stream(dev)))
 
 
-def physics(scenery, agents):
+def physics(scenery, agents, movement=None):
     """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
-    returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230)."""
+    returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230).
+
+    Beyond the reference: ``movement=(actions, table, keep)`` runs the movement modules' velocity update inside the same
+    launch first (include/megastep_hip.h, MsMovement): ``actions`` (N, A) int64 rows of ``table`` (K, 3) = agent-frame
+    [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns)."""
     dev = scenery._device()
     _agents_on(agents, dev)
     if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery: expected (n_envs, n_agents) = '
                            f'{(len(scenery.lines), scenery.n_agents)}, got {tuple(agents.angles.shape)}')
+    mv = None
+    if movement is not None:
+        actions, table, keep = movement
+        _check(table, 'movement table', torch.float32, 2)
+        if actions.dtype != torch.int64 or not actions.is_contiguous() or actions.shape != agents.angles.shape \
+                or table.shape[1:] != (3,) or table.shape[0] < 1:
+            raise RuntimeError('movement must be ((N, A) contiguous int64 actions, (K, 3) float32 table, keep)')
+        _require_gpu(actions, table)
+        mv = C.byref(_lib.MsMovement(actions.data_ptr(), table.data_ptr(), table.shape[0], float(keep)))
     progress = torch.empty_like(agents.angles)
     with _on(dev):
-        _lib.check(_lib.lib().ms_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
-                                         C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
+        _lib.check(_lib.lib().ms_move_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
+                                              mv, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
     agents._cached = agents._use_cache
     return Physics(progress)
 

@@ -33,6 +33,23 @@ def _actionset(core, linear, angular):
     return arrdict.arrdict(velocity=linear/core.fps*velocity, angvelocity=angular/core.fps*angvelocity).to(core.device)
 
 
+def _move(core, actionset, actions, keep):
+    """The velocity update of both movement modules, then physics. On the GPU it is part of the physics launch
+    (cuda.physics' ``movement``); the tensor ops below are the same arithmetic, and what the reference runs."""
+    agents = core.agents
+    if agents.angles.is_cuda:
+        table = torch.cat([actionset.velocity, actionset.angvelocity[:, None]], 1).contiguous()
+        return cuda.physics(core.scenery, agents, movement=(actions.long().contiguous(), table, keep))
+    delta = actionset[actions.long()]
+    if keep == 0:
+        agents.angvelocity[:] = delta.angvelocity
+        agents.velocity[:] = to_global_frame(agents.angles, delta.velocity)
+    else:
+        agents.angvelocity[:] = keep*agents.angvelocity + delta.angvelocity
+        agents.velocity[:] = keep*agents.velocity + to_global_frame(agents.angles, delta.velocity)
+    return cuda.physics(core.scenery, agents)
+
+
 class SimpleMovement:
 
     def __init__(self, core, speed=10, ang_speed=180, n_agents=None):
@@ -44,11 +61,7 @@ class SimpleMovement:
 
     def __call__(self, decision):
         """Sets the agents' velocities from ``decision.actions`` ((n_env, n_agent) ints in 0..6), then steps physics."""
-        core = self.core
-        delta = self._actionset[decision.actions.long()]
-        core.agents.angvelocity[:] = delta.angvelocity
-        core.agents.velocity[:] = to_global_frame(core.agents.angles, delta.velocity)
-        return cuda.physics(core.scenery, core.agents)
+        return _move(self.core, self._actionset, decision.actions, 0.)
 
 
 class MomentumMovement:
@@ -62,11 +75,7 @@ class MomentumMovement:
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
     def __call__(self, decision):
-        core = self.core
-        delta = self._actionset[decision.actions.long()]
-        core.agents.angvelocity[:] = (1 - self.decay)*core.agents.angvelocity + delta.angvelocity
-        core.agents.velocity[:] = (1 - self.decay)*core.agents.velocity + to_global_frame(core.agents.angles, delta.velocity)
-        return cuda.physics(core.scenery, core.agents)
+        return _move(self.core, self._actionset, decision.actions, 1 - self.decay)
 
 
 def unpack(d):

@@ -102,3 +102,45 @@ def test_explorer_reward_equals_the_reference_formula():
             torch.testing.assert_close(world.reward, want)
         prev = potential
     assert world.reset.sum() == 0 and env._potential.min() > 0
+
+
+@pytest.mark.parametrize('cls,kwargs', [('MomentumMovement', dict(accel=5, ang_accel=180, decay=.125)),
+                                        ('SimpleMovement', dict(speed=10, ang_speed=180))])
+def test_movement_inside_the_physics_launch_equals_the_tensor_ops(cls, kwargs):
+    """the movement modules' velocity update, done by the physics kernel's prologue, against the same
+    update done with the reference's tensor ops (modules.py:57-66,106-118) followed by a plain physics call."""
+    from megastep_amd import core, cubicasa, cuda, modules, scene
+    np.random.seed(2); torch.manual_seed(2)
+    gs = cubicasa.sample(16, n_unique=16)
+    c = core.Core(scene.scenery(gs, 3, random=np.random.RandomState(0)), res=64, fov=100)
+    modules.RandomSpawns(gs, c)(c.agent_full(True))
+    mover = getattr(modules, cls)(c, **kwargs)
+    keep = 1 - kwargs['decay'] if 'decay' in kwargs else 0.
+    for step in range(6):
+        actions = torch.randint(0, 7, (16, 3), device='cuda')
+        if step == 3:
+            c.agents.velocity[0, 0] = float('inf')                      # keep = 0 must assign, not blend
+        # the reference's way, on a copy of the state
+        ref = cuda.Agents(*(t.clone() for t in (c.agents.angles, c.agents.positions, c.agents.angvelocity, c.agents.velocity)))
+        delta = mover._actionset[actions]
+        if keep == 0:
+            ref.angvelocity[:] = delta.angvelocity
+            ref.velocity[:] = modules.to_global_frame(ref.angles, delta.velocity)
+        else:
+            ref.angvelocity[:] = keep*ref.angvelocity + delta.angvelocity
+            ref.velocity[:] = keep*ref.velocity + modules.to_global_frame(ref.angles, delta.velocity)
+        moved_v, moved_w = ref.velocity.clone(), ref.angvelocity.clone()
+        p_ref = cuda.physics(c.scenery, ref)
+        # ours: one launch
+        from megastep_amd import arrdict
+        p = mover(arrdict.arrdict(actions=actions))
+        for name in ('angles', 'positions', 'angvelocity', 'velocity'):
+            a, b = getattr(c.agents, name), getattr(ref, name)
+            both = torch.isfinite(a) & torch.isfinite(b)
+            assert torch.equal(torch.isfinite(a), torch.isfinite(b)), name
+            torch.testing.assert_close(a[both], b[both], rtol=0, atol=2e-6, msg=name)
+        both = torch.isfinite(p.progress) & torch.isfinite(p_ref.progress)
+        torch.testing.assert_close(p.progress[both], p_ref.progress[both], rtol=0, atol=2e-6)
+        assert (p.progress < 1).any() or step < 2
+        if keep != 0:
+            c.agents.velocity[0, 0] = 0.
