@@ -1,20 +1,24 @@
 // megastep_hip.hip -- gfx950 (MI355X / CDNA4) simulation core behind include/megastep_hip.h.
 //
-// Three kernels, all written wave64-first:
+// Seven kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
 //
-//   physics_kernel  one wavefront per (env, agent): lanes stride over the env's wall segments
-//                   (16 B / lane, coalesced), each lane folds its own fminf, a 6-step DPP/shuffle
-//                   min-reduce finishes it, then the integration epilogue runs in the same launch
-//                   behind one workgroup barrier.           (reference: kernels.cu:179-230)
-//   render_kernel   one wavefront per (env, agent, 64-ray group), lane = ray.  Pass 1 (lane = line)
-//                   frustum-culls the env's segments against the wave's ray wedge, precomputes the
-//                   ray-independent half of the intersection and compacts the survivors IN ORDER
-//                   into a per-wave LDS list.  Pass 2 (lane = ray) folds over the list with
-//                   broadcast LDS reads and a division-free hit test.  Pass 3 shades.  draw, raycast
-//                   and shader (three launches + five allocations in the reference) are one launch.
+//   physics_kernel<MOVE>   one wavefront per env: wall chunks requested up front, lane = agent for the state and
+//                   the agent-agent tests, lane = wall for a reach-box prefilter, compacted (wall, agent) pairs for
+//                   the exact collision test, atomicMin fold, integration epilogue; leaves each agent's sin/cos for
+//                   the renderer.  MOVE = 1 runs the movement modules' velocity update first.
+//                                                            (reference: kernels.cu:179-230, modules.py:24-118)
+//   render_kernel<IMPL, RW, OBS>   one wavefront per (env, agent, 64-ray group).  Pass 1 (lane = line) turns every
+//                   line into a conservative interval of the wave's rays; pass 2 deals the (line, ray) pairs to the
+//                   lanes, one exact intersection each, merged per ray with 64-bit LDS atomics; the order-dependent
+//                   nearest-hit rule is resolved from the three smallest keys (or a literal fold where it must be);
+//                   rays that landed on an agent are lit through the light grid; shading; optional pooled
+//                   observations.  draw, raycast and shader (three launches + five allocations in the reference)
+//                   are one launch.  IMPL = 0 is the slower literal-order variant kept for A/B runs.
 //                                                            (reference: kernels.cu:297-475)
+//   render_prep_kernel, dynlight_kernel   the renderer's helpers for callers without a heading cache / light grid.
 //   bake_kernel     one workgroup per env, lane = texel, the env's occluders staged once in LDS.
 //                                                            (reference: kernels.cu:238-293)
+//   lightgrid_kernel, lightlist_kernel   per (cell, light) LIT / DARK / UNKNOWN verdicts and candidate walls.
 //
 // Numerics contract: IEEE binary32 evaluated as the reference source is written -- compiled with
 // -ffp-contract=off, correctly rounded divide/sqrt, no fast-math -- so that collision masks and hit
@@ -1756,7 +1760,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
                                *ag, out->workspace, na, (int)n_fans);
         }
     }
-    // the second kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
+    // dynlight_kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
     const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
     const bool pooled = out->obs_rgb || out->obs_depth;
     if (!all_planes && !(grid || sc->n_agents == 1)) return MS_EINVAL;

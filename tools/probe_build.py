@@ -1,4 +1,4 @@
-"""Builds scratch/probe.so: render_kernel<1,1> with cycle counters per section written over out.distances
+"""Builds scratch/probe.so: render_kernel<1,1,*> with cycle counters per section written over out.distances
 (lanes 0-7 of every ray group; lane 8 = (line, ray) pairs) - for tools/probe_run.py. Results are garbage by design."""
 import os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
