@@ -1,99 +1,114 @@
-"""Multi-agent deathmatch: agents score by keeping an opponent in the middle of their view
-(reference: megastep/demo/envs/deathmatch.py:9-115)."""
+"""Deathmatch: several agents per floorplan, each scoring while an opponent sits in its crosshair and bleeding while
+it sits in someone else's. Behaviour follows megastep/demo/envs/deathmatch.py:9-115; the implementation is organised
+around the fused render outputs of this package (pooled RGB-D from the kernel, hit lines only where needed).
+
+The policy sees one row per *agent* - (n_floorplans*n_agents, 1, ...) - while the simulation is laid out per
+floorplan, (n_floorplans, n_agents, ...); :func:`per_agent` and :func:`per_floorplan` convert between the two."""
 import numpy as np
 import torch
-from ... import modules, core, spaces, scene, cubicasa, arrdict, dotdict
 
+from ... import arrdict, core, cubicasa, dotdict, modules, scene, spaces
+
+#: how far outside its floorplan's bounding box an agent may stray before it starts losing health, metres
 CLEARANCE = 1.
+HIT_DAMAGE, TICK_DAMAGE = .05, .001
 
 
-@dotdict.mapping
-def expand(x):
-    B, A = x.shape[:2]
-    return x.reshape(B*A, 1, *x.shape[2:])
+def per_agent(tree):
+    """(n_floorplans, n_agents, ...) leaves -> (n_floorplans*n_agents, 1, ...)."""
+    return dotdict.mapping(lambda x: x.reshape(x.shape[0]*x.shape[1], 1, *x.shape[2:]))(tree)
 
 
-@dotdict.mapping
-def collapse(x, n_agents):
-    B = x.shape[0]
-    return x.reshape(B//n_agents, n_agents, *x.shape[2:])
+def per_floorplan(tree, n_agents):
+    """(n_floorplans*n_agents, 1, ...) leaves -> (n_floorplans, n_agents, ...)."""
+    return dotdict.mapping(lambda x: x.reshape(x.shape[0]//n_agents, n_agents, *x.shape[2:]))(tree)
+
+
+def crosshair_matrix(line_indices, n_model, n_agents, subsample):
+    """Who has whom in the crosshair: (n_floorplans, n_agents, n_agents) bools, [f, a, b] = agent a's two central
+    observation pixels show agent b. ``line_indices`` is the render's (n_floorplans, n_agents, 1, res) hit lines; an
+    observation pixel stands for ``subsample`` rays and shows what its middle ray hit; lines below
+    ``n_agents*n_model`` belong to agent ``line // n_model``."""
+    middle_rays = line_indices[..., 0, subsample//2::subsample]                      # one ray per observation pixel
+    width = middle_rays.shape[-1]
+    centre = middle_rays[..., width//2 - 1:width//2 + 1]                            # (F, A, 2)
+    seen_agent = torch.div(centre, n_model, rounding_mode='floor')
+    seen_agent = torch.where((centre >= 0) & (seen_agent < n_agents), seen_agent, torch.full_like(seen_agent, -1))
+    everyone = torch.arange(n_agents, device=line_indices.device)
+    return (seen_agent[..., None] == everyone).any(-2)
 
 
 class Deathmatch:
 
     def __init__(self, n_envs, n_agents, *args, device='cuda', geometries=None, **kwargs):
-        geometries = cubicasa.sample(max(n_envs//4, 1)) if geometries is None else geometries
-        scenery = scene.scenery(geometries, n_agents, device=device)
-        self.core = core.Core(scenery, *args, res=4*128, fov=70, **kwargs)
-        self._rgb = modules.RGB(self.core, n_agents=1, subsample=4)
-        self._depth = modules.Depth(self.core, n_agents=1, subsample=4)
-        self._imu = modules.IMU(self.core, n_agents=1)
-        self._movement = modules.MomentumMovement(self.core, n_agents=1)
-        self._spawner = modules.RandomSpawns(geometries, self.core)
+        """``n_envs`` counts agent-rows, as the reference's does; without ``geometries`` it samples ``n_envs//4``
+        floorplans (deathmatch.py:24)."""
+        if geometries is None:
+            geometries = cubicasa.sample(max(n_envs//4, 1))
+        self.core = core.Core(scene.scenery(geometries, n_agents, device=device), *args, res=4*128, fov=70, **kwargs)
+        c = self.core
+        self.device, self.n_envs = c.device, c.n_envs*c.n_agents
 
-        self.action_space = self._movement.space
-        self.obs_space = dotdict.dotdict(
-            rgb=self._rgb.space, d=self._depth.space, imu=self._imu.space, health=spaces.MultiVector(1, 1))
+        self._mover = modules.MomentumMovement(c, n_agents=1)
+        self._respawn = modules.RandomSpawns(geometries, c)
+        self._rgb = modules.RGB(c, n_agents=1, subsample=4)
+        self._depth = modules.Depth(c, n_agents=1, subsample=4)
+        self._imu = modules.IMU(c, n_agents=1)
+        self.action_space = self._mover.space
+        self.obs_space = dotdict.dotdict(rgb=self._rgb.space, d=self._depth.space, imu=self._imu.space,
+                                         health=spaces.MultiVector(1, 1))
 
-        bounds = np.stack([np.array(g['masks'].shape)*g['res'] for g in geometries])
-        self._bounds = arrdict.torchify(bounds).to(self.core.device)
-        self._health = self.core.agent_full(np.nan)
-        self._damage = self.core.agent_full(np.nan)
+        extents = np.stack([np.asarray(g['masks'].shape)*g['res'] for g in geometries])
+        self._bounds = arrdict.torchify(extents).to(c.device)
+        self._health = c.agent_full(np.nan)                  # NaN until the first reset
+        self._damage = c.agent_full(np.nan)
+        self.matchings = torch.zeros((c.n_envs, c.n_agents, c.n_agents), dtype=torch.bool, device=c.device)
 
-        self.n_envs = self.core.n_envs*self.core.n_agents
-        self.device = self.core.device
+    # -- pieces of a step ---------------------------------------------------------------------------------------
 
-    def _reset(self, reset=None):
-        reset = (self._health <= 0) if reset is None else reset
-        self._spawner(reset)
-        self._health.masked_fill_(reset, 1.)
-        self._damage.masked_fill_(reset, 0.)
-        return reset.reshape(-1)
+    def _revive(self, who):
+        """Respawns the agents marked in the (n_floorplans, n_agents) mask at full health."""
+        self._respawn(who)
+        self._health.masked_fill_(who, 1.)
+        self._damage.masked_fill_(who, 0.)
+        return who.reshape(-1)
 
-    def _shoot(self, opponents):
-        res = opponents.size(-1)
-        middle = slice(res//2 - 1, res//2 + 1)
-        agents = torch.arange(self.core.n_agents, device=self.core.device)
-        matchings = (opponents[:, :, None] == agents[None, None, :, None, None])[..., middle].any(-1).any(-1)
-        self.matchings = matchings
+    def _exchange_fire(self, line_indices):
+        """Updates health and damage from this frame's crosshairs; returns each agent's hits, the reward."""
+        c = self.core
+        self.matchings = crosshair_matrix(line_indices, len(c.scenery.model), c.n_agents, self._rgb.subsample)
+        dealt = self.matchings.sum(2).float()                # opponents in my crosshair
+        taken = self.matchings.sum(1).float()                # crosshairs I am in
+        where = c.agents.positions
+        strayed = ((where < -CLEARANCE) | (where > self._bounds[:, None] + CLEARANCE)).any(-1)
+        self._damage += HIT_DAMAGE*dealt
+        self._health -= HIT_DAMAGE*(taken + strayed) + TICK_DAMAGE
+        return dealt.reshape(-1)
 
-        hits = matchings.sum(2).float()
-        wounds = matchings.sum(1).float()
-        self._damage[:] += .05*hits
+    def _look(self):
+        # pooled RGB-D straight from the render kernel; the crosshair only needs the line each ray landed on
+        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices',))
+        reward = self._exchange_fire(frame.indices)
+        obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu(),
+                              health=self._health.unsqueeze(-1).clone())
+        return per_agent(obs), reward
 
-        pos = self.core.agents.positions
-        outside = (pos < -CLEARANCE).any(-1) | (pos > (self._bounds[:, None] + CLEARANCE)).any(-1)
-        # 5% damage per hit, .1% damage per timestep
-        self._health[:] += -.05*(wounds + outside) - .001
-        return hits.reshape(-1)
-
-    def _observe(self):
-        # pooled RGB-D straight from the render kernel; shooting only needs the line each ray landed on
-        r = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices',))
-        line_idxs = modules.downsample(r.indices, self._rgb.subsample)[..., self._rgb.subsample//2]
-        obj_idxs = torch.div(line_idxs, len(self.core.scenery.model), rounding_mode='floor')
-        mask = (0 <= line_idxs) & (obj_idxs < self.core.n_agents)
-        opponents = obj_idxs.where(mask, torch.full_like(line_idxs, -1))
-        hits = self._shoot(opponents)
-        obs = arrdict.arrdict(
-            rgb=self._rgb(r), d=self._depth(r), imu=self._imu(), health=self._health.unsqueeze(-1).clone())
-        return obs, hits
+    # -- the env interface --------------------------------------------------------------------------------------
 
     @torch.no_grad()
     def reset(self):
-        reset = self._reset(self.core.agent_full(True))
-        obs, reward = self._observe()
-        return arrdict.arrdict(obs=expand(obs), reward=reward, reset=reset)
+        reset = self._revive(self.core.agent_full(True))
+        obs, reward = self._look()
+        return arrdict.arrdict(obs=obs, reward=reward, reset=reset)
 
     @torch.no_grad()
     def step(self, decision):
-        reset = self._reset()
-        self._movement(collapse(decision, self.core.n_agents))
-        obs, reward = self._observe()
-        return arrdict.arrdict(obs=expand(obs), reward=reward, reset=reset)
+        reset = self._revive(self._health <= 0)              # the dead come back before anyone moves
+        self._mover(per_floorplan(decision, self.core.n_agents))
+        obs, reward = self._look()
+        return arrdict.arrdict(obs=obs, reward=reward, reset=reset)
 
     def state(self, e=0):
-        return arrdict.arrdict(
-            core=self.core.state(e), rgb=self._rgb.state(e), d=self._depth.state(e),
-            health=self._health[e].clone(), damage=self._damage[e].clone(),
-            matchings=self.matchings[e].clone(), bounds=self._bounds[e].clone())
+        return arrdict.arrdict(core=self.core.state(e), rgb=self._rgb.state(e), d=self._depth.state(e),
+                               health=self._health[e].clone(), damage=self._damage[e].clone(),
+                               matchings=self.matchings[e].clone(), bounds=self._bounds[e].clone())

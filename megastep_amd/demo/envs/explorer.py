@@ -1,101 +1,121 @@
-"""Single-agent exploration: reward for every texel seen for the first time
-(reference: megastep/demo/envs/explorer.py:8-115)."""
+"""Exploration: one agent per floorplan, rewarded for every texel of wall it lays eyes on for the first time since its
+last respawn. An episode ends when its length reaches 200 steps plus the number of texels seen, so good explorers
+live longer. Behaviour follows megastep/demo/envs/explorer.py:8-115.
+
+The reference re-counts every texel of every env each step (a ``scatter_add`` over all of them, explorer.py:45-58).
+:class:`SeenTexels` keeps the same tally incrementally and without ever syncing with the host, which is what lets a
+whole ``step`` be captured in a HIP graph."""
 import torch
-from ... import modules, core, scene, cubicasa, arrdict, dotdict
+
+from ... import arrdict, core, cubicasa, dotdict, modules, scene
+
+EPISODE_SLACK = 200     # steps an agent gets on top of one per texel seen
+
+
+class SeenTexels:
+    """Which texels each env has seen since its last respawn, and how many.
+
+    A texel counts as seen while its stamp equals its env's epoch; a respawn bumps the env's epoch, which forgets all
+    of its texels at once without touching them. ``claim`` settles which of several rays on one texel counts it. One
+    extra slot at the end of both arrays takes the rays that hit nothing."""
+
+    def __init__(self, scenery, n_envs):
+        device = scenery.textures.vals.device
+        self.texel_env = scenery.lines.inverse[scenery.textures.inverse.long()].long()       # texel -> env
+        n_texels = len(self.texel_env)
+        self.nowhere = torch.tensor(n_texels, device=device)
+        self.epoch = torch.ones(n_envs, dtype=torch.int32, device=device)
+        self.stamp = torch.zeros(n_texels + 1, dtype=torch.int32, device=device)
+        self.claim = torch.full((n_texels + 1,), -1, dtype=torch.long, device=device)
+        self.count = torch.zeros(n_envs, device=device)
+        self._scenery = scenery
+
+    def texels_hit(self, frame):
+        """(n_envs, n_agents, 1, res) texel under each ray of a render result; ``nowhere`` for the rays that missed."""
+        sc = self._scenery
+        hit = frame.indices >= 0
+        line = (sc.lines.starts[:, None, None, None] + frame.indices.clamp(min=0)).long()
+        width = sc.textures.widths[line].float()
+        along = torch.min(torch.floor(width*frame.locations), width - 1)                 # explorer.py:38-41
+        texel = sc.textures.starts[line].long() + torch.where(hit, along, torch.zeros_like(along)).long()
+        return torch.where(hit, texel, self.nowhere)
+
+    def look(self, frame):
+        """Marks what ``frame`` shows as seen; returns how many texels each env saw for the first time."""
+        texel = self.texels_hit(frame).reshape(-1)
+        ray = torch.arange(len(texel), device=texel.device)
+        epoch = self.epoch.repeat_interleave(len(texel)//len(self.epoch))                 # of each ray's env
+        self.claim[texel] = ray                                                           # one of the rays on a texel wins
+        new = (self.claim[texel] == ray) & (self.stamp[texel] != epoch) & (texel != self.nowhere)
+        self.stamp[texel] = epoch
+        gained = new.view(len(self.epoch), -1).sum(1).float()
+        self.count = self.count + gained
+        return gained
+
+    def forget(self, envs):
+        """Envs marked in the bool mask start over."""
+        self.epoch += envs.int()
+        self.count = self.count.masked_fill(envs, 0)
+
+    def mask(self):
+        """Per texel: has its env seen it since the env's last respawn."""
+        return self.stamp[:-1] == self.epoch[self.texel_env]
 
 
 class Explorer:
 
     def __init__(self, n_envs, *args, device='cuda', geometries=None, **kwargs):
-        geometries = cubicasa.sample(n_envs) if geometries is None else geometries
-        scenery = scene.scenery(geometries, 1, device=device)
-        self.core = core.Core(scenery, *args, res=4*64, fov=130, **kwargs)
-        self._rgb = modules.RGB(self.core, n_agents=1, subsample=4)
-        self._depth = modules.Depth(self.core, n_agents=1, subsample=4)
-        self._mover = modules.MomentumMovement(self.core)
-        self._imu = modules.IMU(self.core)
-        self._respawner = modules.RandomSpawns(geometries, self.core)
+        if geometries is None:
+            geometries = cubicasa.sample(n_envs)
+        self.core = core.Core(scene.scenery(geometries, 1, device=device), *args, res=4*64, fov=130, **kwargs)
+        c = self.core
+        self.device = c.device
 
+        self._mover = modules.MomentumMovement(c)
+        self._respawner = modules.RandomSpawns(geometries, c)
+        self._rgb = modules.RGB(c, n_agents=1, subsample=4)
+        self._depth = modules.Depth(c, n_agents=1, subsample=4)
+        self._imu = modules.IMU(c)
         self.action_space = self._mover.space
         self.obs_space = dotdict.dotdict(rgb=self._rgb.space, d=self._depth.space, imu=self._imu.space)
 
-        sc = self.core.scenery
-        self._tex_to_env = sc.lines.inverse[sc.textures.inverse.long()].long()
-        self._potential = self.core.env_full(0.)
-        self._lengths = torch.zeros(self.core.n_envs, device=self.core.device, dtype=torch.int)
-        self.device = self.core.device
-        # Bookkeeping for the incremental reward, laid out so that a step needs neither a pass over every texel nor
-        # a host sync: a texel counts as seen while its stamp equals its env's epoch (a respawn bumps the epoch and
-        # thereby forgets the env's texels); `_claim` records which ray last landed on a texel. One extra slot at the
-        # end of both arrays takes the rays that hit nothing; it always reads as seen.
-        n_tex = len(self._tex_to_env)
-        self._epoch = torch.ones(self.core.n_envs, device=self.device, dtype=torch.int32)
-        self._stamp = torch.zeros(n_tex + 1, device=self.device, dtype=torch.int32)
-        self._claim = torch.full((n_tex + 1,), -1, device=self.device, dtype=torch.long)
-        self._trash = torch.tensor(n_tex, device=self.device)
+        self._memory = SeenTexels(c.scenery, c.n_envs)
+        self._lengths = torch.zeros(c.n_envs, dtype=torch.int, device=c.device)
 
-    @property
-    def _seen(self):
-        """Per texel: has its env seen it since the env's last respawn."""
-        return self._stamp[:-1] == self._epoch[self._tex_to_env]
+    # what the tests and `state` look at
+    _potential = property(lambda self: self._memory.count)
+    _seen = property(lambda self: self._memory.mask())
+    _tex_to_env = property(lambda self: self._memory.texel_env)
 
-    def _tex_indices(self, aux):
-        """The texel every ray landed on, (n_env, n_agent, 1, res); the trash slot for rays that hit nothing."""
-        sc = self.core.scenery
-        valid = aux.indices >= 0
-        line = (sc.lines.starts[:, None, None, None] + aux.indices.clamp(min=0)).long()
-        tex_w = sc.textures.widths[line].float()
-        tex_i = torch.min(torch.floor(tex_w*aux.locations), tex_w - 1)
-        tex = sc.textures.starts[line].long() + torch.where(valid, tex_i, torch.zeros_like(tex_i)).long()
-        return torch.where(valid, tex, self._trash)
+    def _restart(self, which):
+        self._respawner(which.unsqueeze(-1))
+        self._memory.forget(which)
+        self._lengths.masked_fill_(which, 0)
 
-    def _reward(self, r, reset):
-        """Reward = newly seen texels per env (reference: explorer.py:45-58). The reference re-counts every texel of
-        every env each step (a scatter_add over all of them); here only the texels this step's rays landed on are
-        touched: a texel is counted once, by whichever of the rays on it holds the claim, if it was unseen before."""
-        tex = self._tex_indices(r).reshape(-1)
-        rays = torch.arange(len(tex), device=tex.device)
-        epoch = self._epoch.repeat_interleave(len(tex)//self.core.n_envs)     # of the env each ray belongs to
-        self._claim[tex] = rays                              # duplicates: some single ray wins each texel
-        fresh = (self._claim[tex] == rays) & (self._stamp[tex] != epoch) & (tex != self._trash)
-        self._stamp[tex] = epoch
-        potential = self._potential + fresh.view(self.core.n_envs, -1).sum(1).float()
-        reward = (potential - self._potential)/(self.core.res//self._rgb.subsample)
-        self._potential = potential
-        # Should I render twice so that the last reward is accurate?
-        reward = reward.masked_fill(reset, 0.)
-        return reward
-
-    def _observe(self, reset):
+    def _world(self, reset):
         # pooled RGB-D straight from the render kernel; the reward only needs which texel each ray landed on
-        r = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices', 'locations'))
-        obs = arrdict.arrdict(rgb=self._rgb(r), d=self._depth(r), imu=self._imu())
-        return obs, self._reward(r, reset)
-
-    def _reset(self, reset=None):
-        self._respawner(reset.unsqueeze(-1))
-        self._epoch += reset.int()                           # forget what the respawned envs had seen
-        self._potential = self._potential.masked_fill(reset, 0)
-        self._lengths.masked_fill_(reset, 0)
+        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices', 'locations'))
+        pixels = self.core.res//self._rgb.subsample
+        reward = (self._memory.look(frame)/pixels).masked_fill(reset, 0.)      # nothing for the frame after a respawn
+        obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu())
+        return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
 
     @torch.no_grad()
     def reset(self):
-        reset = self.core.env_full(True)
-        self._reset(reset)
-        obs, reward = self._observe(reset)
-        return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
+        everyone = self.core.env_full(True)
+        self._restart(everyone)
+        return self._world(everyone)
 
     @torch.no_grad()
     def step(self, decision):
         self._mover(decision)
         self._lengths += 1
-        reset = (self._lengths >= self._potential + 200)
-        self._reset(reset)
-        obs, reward = self._observe(reset)
-        return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
+        over = self._lengths >= self._memory.count + EPISODE_SLACK
+        self._restart(over)
+        return self._world(over)
 
     def state(self, e=0):
-        return arrdict.arrdict(
-            core=self.core.state(e), rgb=self._rgb.state(e), d=self._depth.state(e),
-            potential=self._potential[e].clone(), seen=self._seen[self._tex_to_env == e].clone(),
-            length=self._lengths[e].clone(), max_length=self._potential[e].add(200).clone())
+        seen = self._memory.mask()[self._memory.texel_env == e]
+        return arrdict.arrdict(core=self.core.state(e), rgb=self._rgb.state(e), d=self._depth.state(e),
+                               potential=self._memory.count[e].clone(), seen=seen.clone(),
+                               length=self._lengths[e].clone(), max_length=self._memory.count[e].add(EPISODE_SLACK).clone())

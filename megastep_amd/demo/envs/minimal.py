@@ -1,27 +1,38 @@
-"""A minimal environment: a box, RGB observations, simple movement (reference: megastep/demo/envs/minimal.py:7-31)."""
-from ... import modules, core, toys, scene, arrdict, dotdict
+"""The smallest useful environment: every env is the 5 m toy box with one agent in it, the observation is what the
+agent sees (RGB, full resolution), the seven movement actions apply at once (no momentum). It is the skeleton of the
+reference's tutorial (docs/tutorials/minimal-env, megastep/demo/envs/minimal.py:7-31): spawn - observe on reset,
+move - observe on step. The observation comes pooled (subsample 1) straight from the render kernel."""
+import torch
+
+from ... import arrdict, core, dotdict, modules, scene, toys
 
 
 class Minimal:
 
     def __init__(self, n_envs=1, device='cuda'):
-        geometries = n_envs*[toys.box()]
-        scenery = scene.scenery(geometries, n_agents=1, device=device)
-        self.core = core.Core(scenery)
-        self.spawner = modules.RandomSpawns(geometries, self.core)
+        box = toys.box()
+        rooms = [box for _ in range(n_envs)]
+        self.core = core.Core(scene.scenery(rooms, n_agents=1, device=device))
+
         self.rgb = modules.RGB(self.core)
         self.movement = modules.SimpleMovement(self.core)
+        self.spawner = modules.RandomSpawns(rooms, self.core)
+        self.obs_space, self.action_space = self.rgb.space, self.movement.space
 
-        self.obs_space = self.rgb.space
-        self.action_space = self.movement.space
+    def _world(self):
+        frame = modules.render(self.core, observers=(self.rgb,), fields=())
+        return arrdict.arrdict(obs=self.rgb(frame))
 
+    @torch.no_grad()
     def reset(self):
-        self.spawner(self.core.agent_full(True))
-        return arrdict.arrdict(obs=self.rgb())
+        everyone = self.core.agent_full(True)
+        self.spawner(everyone)
+        return self._world()
 
+    @torch.no_grad()
     def step(self, decision):
-        self.movement(decision)
-        return arrdict.arrdict(obs=self.rgb())
+        self.movement(decision)                  # sets the velocities and runs physics, one launch
+        return self._world()
 
     def state(self, e=0):
-        return dotdict.dotdict(core=self.core.state(e), rgb=self.rgb.state(e))
+        return dotdict.dotdict(rgb=self.rgb.state(e), core=self.core.state(e))
