@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 7
+#define MS_ABI_VERSION 8
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -85,6 +85,21 @@ typedef struct MsScenery {
     unsigned*    lg_list;
     unsigned*    lg_pool;
     int          lg_pool_size;
+    /* Optional sharing of static geometry between envs (NULL = every env on its own; no counterpart in the reference,
+     * whose scene.py:75-100 and kernels.cu:270-293 redo identical floorplans env by env): env_geom[n] is the FIRST env
+     * whose walls and light POSITIONS are bit-identical to env n's (itself for a representative).  Light intensities
+     * and textures stay per env.  ms_bake then works out light visibility - the O(texels x lights x walls) part,
+     * which depends on walls and light positions only - once per representative, and members of a group may share one
+     * light grid (equal lg_starts / lg_geom rows); the per-env part (the sum over unblocked lights with the env's
+     * own intensities, kernels.cu:261-267) runs for every env as before, so baked_vals are the reference's bit for bit. */
+    const int*   env_geom;
+    /* Optional scratch for ms_bake (NULL = its self-contained one-pass kernel): one visibility bit per
+     * (texel, light) of every representative env.  The bits of env n's representative start at word
+     * bake_vis_starts[n] and take lights(n) x ceil(texels(n)/64) 64-bit words, row per light.  Contents undefined
+     * before and after the call. */
+    unsigned long long* bake_vis;
+    const long long*    bake_vis_starts;   /* (N,) */
+    long long           bake_vis_words;    /* size of bake_vis, for bounds checking */
 } MsScenery;
 
 /* Replaces `Agents` (common.h:157-177). Updated IN PLACE by ms_physics. */
@@ -168,6 +183,12 @@ int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* 
 
 /* Scalar helper exported for tests: sin(pi x), cos(pi x) exactly as the kernels evaluate them. */
 void ms_host_sincospi(float x, float* s, float* c);
+/* Helpers exported for tests of ms_bake's culling (host instantiations of the device functions): the angular bin
+ * (of MS_BAKE_BINS around a light) a point falls in, and the circular run of bins [first, first + count) a wall can
+ * shadow.  A wall obstructs a point from the light (kernels.cu:238-259) only if the point's bin is in the wall's run. */
+#define MS_BAKE_BINS 64
+int  ms_host_bake_point_bin(float light_x, float light_y, float x, float y);   /* -1: undecidable, test every wall */
+void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, float bx, float by, int* first, int* count);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -33,7 +33,8 @@ class MsScenery(C.Structure):
         ('model', C.c_void_p), ('baked_vals', C.c_void_p),
         ('n_lines_total', C.c_int), ('n_lights_total', C.c_int), ('n_texels_total', C.c_int),
         ('lg_vals', C.c_void_p), ('lg_starts', C.c_void_p), ('lg_geom', C.c_void_p), ('lg_cell', C.c_float),
-        ('lg_max_cells', C.c_int), ('lg_list', C.c_void_p), ('lg_pool', C.c_void_p), ('lg_pool_size', C.c_int)]
+        ('lg_max_cells', C.c_int), ('lg_list', C.c_void_p), ('lg_pool', C.c_void_p), ('lg_pool_size', C.c_int),
+        ('env_geom', C.c_void_p), ('bake_vis', C.c_void_p), ('bake_vis_starts', C.c_void_p), ('bake_vis_words', C.c_longlong)]
 
 
 class MsAgents(C.Structure):
@@ -53,19 +54,39 @@ class MsRender(C.Structure):
 
 #: every symbol include/megastep_hip.h declares
 SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
-           'ms_render', 'ms_host_sincospi')
+           'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins')
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for path in (os.path.join(CSRC, 'megastep_hip.hip'), os.path.join(_HERE, '..', 'include', 'megastep_hip.h'),
+                 os.path.join(CSRC, 'Makefile')):
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def build(force=False):
-    """Compiles csrc/megastep_hip.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    src = os.path.join(CSRC, 'megastep_hip.hip')
-    hdr = os.path.join(_HERE, '..', 'include', 'megastep_hip.h')
-    stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr))
-    if force or stale:
-        proc = subprocess.run(['make', '-C', CSRC, '-B', 'libmegastep_hip.so'], capture_output=True, text=True)
-        if proc.returncode != 0:
-            raise RuntimeError(f'hipcc build of libmegastep_hip.so failed:\n{proc.stdout}\n{proc.stderr}')
+    """Compiles csrc/megastep_hip.hip for gfx950 with hipcc (cross-compiles without a GPU). The library is stale when
+    the hash of its sources differs from the one recorded next to it at build time (mtimes do not survive copies);
+    concurrent callers (one rank per GPU) serialise on a lock file."""
+    import fcntl
+    stamp = LIB_PATH + '.srchash'
+    want = _source_hash()
+
+    def fresh():
+        return os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want
+
+    if force or not fresh():
+        with open(os.path.join(CSRC, '.build.lock'), 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or not fresh():                 # (someone else may have built it while we waited)
+                proc = subprocess.run(['make', '-C', CSRC, '-B', 'libmegastep_hip.so'], capture_output=True, text=True)
+                if proc.returncode != 0:
+                    raise RuntimeError(f'hipcc build of libmegastep_hip.so failed:\n{proc.stdout}\n{proc.stderr}')
+                with open(stamp, 'w') as f:
+                    f.write(want)
     return LIB_PATH
 
 
@@ -73,11 +94,12 @@ _lib = None
 
 
 def lib():
-    """The loaded library. Builds it first if it is missing; raises if that is impossible."""
+    """The loaded library. (Re)builds the in-tree one first if it is missing or older than its sources; raises if that
+    is impossible."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            build()
+        if not os.environ.get('MEGASTEP_HIP_LIB'):
+            build()                     # a no-op while the in-tree library is newer than its sources
         handle = C.CDLL(LIB_PATH)
         missing = [s for s in SYMBOLS if not hasattr(handle, s)]
         if missing:
@@ -93,6 +115,10 @@ def lib():
                                            C.POINTER(MsConfig), C.c_void_p]
         handle.ms_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]
         handle.ms_host_sincospi.argtypes = [C.c_float, _f32p, _f32p]
+        handle.ms_host_bake_point_bin.argtypes = [C.c_float]*4
+        handle.ms_host_bake_point_bin.restype = C.c_int
+        handle.ms_host_bake_wall_bins.argtypes = [C.c_float]*6 + [_i32p, _i32p]
+        handle.ms_host_bake_wall_bins.restype = None
         for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_render'):
             getattr(handle, name).restype = C.c_int
         if handle.ms_abi_version() != ABI_VERSION:

@@ -1455,6 +1455,212 @@ __global__ __launch_bounds__(WG) void bake_kernel(const MsScenery sc) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bake in two phases, for sceneries that share geometry between envs and/or are large          kernels.cu:238-293
+// ------------------------------------------------------------------------------------------------
+// light_intensity() of a texel is  min(1, 0.1 + sum over UNBLOCKED lights of 2 I_i / max(d_i^2, 1)).  Which lights are
+// blocked depends on the walls and the light positions only; the intensities I_i are per env.  So:
+//   visibility_kernel  one workgroup per (representative env, light): the env's walls staged in LDS and sorted into
+//                      ANGULAR BINS around the light, every texel tested against the walls of its own bin only;
+//                      one bit per (texel, light) into the scratch MsScenery.bake_vis.
+//   bake_sum_kernel    one thread per texel of EVERY env: the reference's in-order sum with the env's own
+//                      intensities, visibility read from its representative's bits.
+// Exactness of the bins: the wall a->b obstructs the point C from the light I only if the segment I->C crosses it
+// (0 < t < 1 along the wall, kernels.cu:257), i.e. only if the direction of C as seen from I lies inside the arc the
+// wall subtends - the shorter one between the directions of a and b.  Directions are measured with a pseudo-angle
+// (monotone in the true angle, antipodes exactly 2 apart, so "shorter arc" means a difference below 2), arcs are grown
+// by 2e-3 (~10^4 roundings), and anything doubtful - a light on the wall's line or at one of its ends, NaNs - goes
+// into every bin.  A texel whose own direction is undefined is tested against every wall.
+constexpr int BAKE_BINS = MS_BAKE_BINS;
+constexpr int BAKE_ENTRIES = 6144;           // capacity of the bins' wall lists; beyond it the pass tests every wall
+constexpr float BAKE_BIN_SCALE = BAKE_BINS/4.f;
+
+// direction of (x, y) in [0, 4): 0 along +x, 1 along +y, 2 along -x, 3 along -y; NaN at the origin
+__host__ __device__ inline float pseudo_angle(float x, float y) {
+    const float p = y/(fabsf(x) + fabsf(y));
+    return x < 0.f ? 2.f - p : (p < 0.f ? 4.f + p : p);
+}
+// bin of a point as seen from the light; -1: undecidable
+__host__ __device__ inline int bake_point_bin(P2 I, P2 C) {
+    const float dx = C.x - I.x, dy = C.y - I.y;
+    const float pc = pseudo_angle(dx, dy);
+    if (!(pc == pc) || !(fabsf(dx) + fabsf(dy) > 1e-2f)) return -1;    // on top of the light: directions mean nothing
+    const int b = (int)(pc*BAKE_BIN_SCALE);
+    return b < 0 ? 0 : (b > BAKE_BINS - 1 ? BAKE_BINS - 1 : b);
+}
+// the circular run of bins [first, first + count) wall a->b can shadow from light I; count = BAKE_BINS: all of them
+__host__ __device__ inline void bake_wall_bins(P2 I, float ax, float ay, float bx, float by, int& first, int& count) {
+    constexpr float MARGIN = 2e-3f;
+    const float dax = ax - I.x, day = ay - I.y, dbx = bx - I.x, dby = by - I.y;
+    const float pa = pseudo_angle(dax, day), pb = pseudo_angle(dbx, dby);
+    const float lo = fminf(pa, pb), hi = fmaxf(pa, pb), gap = hi - lo;
+    first = 0; count = BAKE_BINS;
+    // squared distance from the light to the wall
+    const float vx = bx - ax, vy = by - ay;
+    float tc = -(dax*vx + day*vy)/(vx*vx + vy*vy);
+    tc = fminf(fmaxf(tc, 0.f), 1.f);
+    tc = (tc == tc) ? tc : 0.f;
+    const float qx = dax + tc*vx, qy = day + tc*vy;
+    // the wall passes within a centimetre of the light, the light is (almost) on the wall's line between its
+    // ends, NaNs: every bin
+    if (!(pa == pa) || !(pb == pb) || !(qx*qx + qy*qy > 1e-4f) || (fabsf(gap - 2.f) < 2e-2f)) return;
+    float s, e;                                                    // the arc, possibly running through 4 = 0
+    if (gap < 2.f) { s = lo - MARGIN; e = hi + MARGIN; } else { s = hi - MARGIN; e = lo + 4.f + MARGIN; }
+    const int bs = (int)floorf(s*BAKE_BIN_SCALE), be = (int)floorf(e*BAKE_BIN_SCALE);
+    const int c = be - bs + 1;
+    if (c >= BAKE_BINS) return;
+    first = ((bs % BAKE_BINS) + BAKE_BINS) % BAKE_BINS;
+    count = c;
+}
+
+__global__ __launch_bounds__(WG) void visibility_kernel(const MsScenery sc, const int use_bins) {
+    __shared__ float4 s_wall[BAKE_WALLS];        // (ax, ay, vx, vy)
+    __shared__ unsigned short s_entry[BAKE_ENTRIES];
+    __shared__ int s_off[BAKE_BINS + 1];
+    __shared__ int s_cursor[BAKE_BINS];
+    __shared__ int s_total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // which (env, light) is this?  Global light j belongs to the last env whose lights start at or before j and
+    // that has any (a binary search over lights_starts; uniform, so it runs on the scalar unit)
+    const int j = blockIdx.x;
+    int lo_ = 0, hi_ = sc.n_envs - 1;
+    while (lo_ < hi_) {
+        const int mid = (lo_ + hi_ + 1) >> 1;
+        if (sc.lights_starts[mid] <= j) lo_ = mid; else hi_ = mid - 1;
+    }
+    int n = lo_;
+    while (n > 0 && sc.lights_widths[n] == 0) n--;                       // (envs without lights share their successor's start)
+    const int i = j - sc.lights_starts[n];
+    if (i < 0 || i >= sc.lights_widths[n]) return;
+    if (sc.env_geom && sc.env_geom[n] != n) return;                      // a member: its representative does the work
+    const int AF = sc.n_agents*sc.n_model;
+    const int L = sc.lines_widths[n], base = sc.lines_starts[n];
+    if (L == 0) return;
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
+    const int t0 = sc.textures_starts[base];
+    const int t1 = sc.textures_starts[base + L - 1] + sc.textures_widths[base + L - 1];
+    const int T = t1 - t0;
+    const long long TB = (T + 63) >> 6;
+    const long long row = sc.bake_vis_starts[n] + (long long)i*TB;
+    if (row < 0 || row + TB > sc.bake_vis_words) return;                 // (the host checks this too)
+    unsigned long long* __restrict__ vis = sc.bake_vis + row;
+    const float* __restrict__ light = sc.lights_vals + 3*((size_t)sc.lights_starts[n] + i);
+    const P2 I = p2(light[0], light[1]);
+    const int n_walls = max(L - AF, 0);
+
+    for (int w0 = 0, pass = 0; pass == 0 || w0 < n_walls; w0 += BAKE_WALLS, pass++) {   // uniform trip count
+        __syncthreads();
+        const int staged = max(min(BAKE_WALLS, n_walls - w0), 0);
+        if (tid < BAKE_BINS) { s_off[tid] = 0; s_cursor[tid] = 0; }
+        if (tid == 0) { s_off[BAKE_BINS] = 0; s_total = 0; }
+        __syncthreads();
+        // stage the walls; count how many land in each bin
+        for (int k = tid; k < staged; k += WG) {
+            const float4 w = ln[AF + w0 + k];
+            s_wall[k] = make_float4(w.x, w.y, w.z - w.x, w.w - w.y);
+            int first, count;
+            bake_wall_bins(I, w.x, w.y, w.z, w.w, first, count);
+            atomicAdd(&s_total, count);
+            for (int c = 0; c < count; c++) atomicAdd(&s_off[(first + c) & (BAKE_BINS - 1)], 1);
+        }
+        __syncthreads();
+        const bool brute = !use_bins || s_total > BAKE_ENTRIES;         // uniform
+        if (!brute) {
+            if (wave == 0) {                                             // exclusive scan of the 64 counts
+                const int cnt = s_off[lane];
+                const int incl = wave_scan_add(cnt);
+                s_off[lane] = incl - cnt;
+                if (lane == 63) s_off[BAKE_BINS] = incl;
+            }
+            __syncthreads();
+            for (int k = tid; k < staged; k += WG) {
+                const float4 w = ln[AF + w0 + k];                        // (not from s_wall: a + (b - a) is not b)
+                int first, count;
+                bake_wall_bins(I, w.x, w.y, w.z, w.w, first, count);
+                for (int c = 0; c < count; c++) {
+                    const int b = (first + c) & (BAKE_BINS - 1);
+                    s_entry[s_off[b] + atomicAdd(&s_cursor[b], 1)] = (unsigned short)k;
+                }
+            }
+            __syncthreads();
+        }
+        // every texel of the env against the walls of its bin
+        for (int tb = 0; tb < T; tb += WG) {                             // uniform
+            const int tl = tb + tid;
+            const bool live = tl < T;
+            P2 Cp = p2(0.f, 0.f);
+            if (live) {
+                const int l0 = sc.textures_inverse[t0 + tl];
+                const float loc = ((unsigned)(t0 + tl - sc.textures_starts[l0]) + .5f)/sc.textures_widths[l0];
+                const float4 w = reinterpret_cast<const float4*>(sc.lines_vals)[l0];
+                Cp = p2(w.x, w.y)*(1.f - loc) + p2(w.z, w.w)*loc;
+            }
+            const P2 U = Cp - I;
+            const long long word = (tb >> 6) + wave;
+            bool bl = !live;
+            if (pass > 0 && word < TB) bl |= ((vis[word] >> lane) & 1ull) != 0ull;   // blocked by an earlier pass' walls
+            int e0 = 0, e1 = staged;
+            bool listed = false;
+            if (!brute) {
+                const int b = bake_point_bin(I, Cp);
+                if (b >= 0) { listed = true; e0 = s_off[b]; e1 = s_off[b + 1]; }
+            }
+            for (int e = e0; ; e++) {
+                const bool go = !bl & (e < e1);
+                if (!__any(go)) break;
+                if (go) {
+                    const float4 w = s_wall[listed ? (int)s_entry[e] : e];
+                    bl = light_blocked(I, U, w.x, w.y, w.z, w.w);
+                }
+            }
+            const unsigned long long m = __ballot(bl & live);
+            if (lane == 0 && word < TB) vis[word] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void bake_sum_kernel(const MsScenery sc) {
+    const long long t = (long long)blockIdx.x*WG + threadIdx.x;
+    if (t >= sc.n_texels_total) return;
+    const int l0 = sc.textures_inverse[t];
+    const int n = sc.lines_inverse[l0];
+    const int AF = sc.n_agents*sc.n_model;
+    const int L = sc.lines_widths[n], base = sc.lines_starts[n];
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + base;
+    const int num_i = sc.lights_widths[n];
+    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const int t0 = sc.textures_starts[base];
+    const int t1 = sc.textures_starts[base + L - 1] + sc.textures_widths[base + L - 1];
+    const long long TB = (t1 - t0 + 63) >> 6;
+    const int tl = (int)(t - t0);
+    const float loc = ((unsigned)(t - sc.textures_starts[l0]) + .5f)/sc.textures_widths[l0];
+    const float4 w = reinterpret_cast<const float4*>(sc.lines_vals)[l0];
+    const P2 Cp = p2(w.x, w.y)*(1.f - loc) + p2(w.z, w.w)*loc;
+    // The texels of the agents' own lines are never looked up by ms_render (agent hits are lit dynamically,
+    // kernels.cu:434) but the reference bakes them where the agents happen to stand, so they are worked out here,
+    // per env, against every wall - the agents of a group's envs need not stand in the same place.
+    const bool agent_line = l0 - base < AF;
+    const unsigned long long* __restrict__ vis = sc.bake_vis + sc.bake_vis_starts[n];
+    float acc = AMBIENT;
+    for (int i = 0; i < num_i; i++) {                                    // kernels.cu:261-264, in light order
+        const P2 I = p2(lights[3*i], lights[3*i + 1]);
+        bool bl;
+        if (agent_line) {
+            bl = false;
+            const P2 U = Cp - I;
+            for (int k = AF; (k < L) & !bl; k++) {
+                const float4 o = ln[k];
+                bl = light_blocked(I, U, o.x, o.y, o.z - o.x, o.w - o.y);
+            }
+        } else {
+            bl = ((vis[(long long)i*TB + (tl >> 6)] >> (tl & 63)) & 1ull) != 0ull;
+        }
+        const float d2 = len2(I - Cp);
+        if (!bl) acc += LUMINANCE*lights[3*i + 2]/ms_max(d2, 1.f);
+    }
+    sc.baked_vals[t] = ms_min(acc, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------
 // light grid: which lights reach which cells                   (accelerates kernels.cu:238-268 at run time)
 // ------------------------------------------------------------------------------------------------
 // One thread per cell of the env's grid, the env's walls staged in LDS.  For a cell (grown by LG_SLACK so a
@@ -1539,6 +1745,7 @@ __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
     const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
     const int ncell = (int)geom.z*(int)geom.w;
     if ((int)blockIdx.x*WG >= ncell) return;     // uniform: whole workgroups leave together
+    if (sc.env_geom && sc.env_geom[n] != n) return;   // shares its representative's grid
     const int c = blockIdx.x*WG + tid;
     const bool live = c < ncell;
     const int AF = sc.n_agents*sc.n_model;
@@ -1602,6 +1809,7 @@ __global__ __launch_bounds__(WG) void lightlist_kernel(const MsScenery sc) {
     const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
     const int ncell = (int)geom.z*(int)geom.w;
     if ((int)blockIdx.x*WG >= ncell) return;
+    if (sc.env_geom && sc.env_geom[n] != n) return;
     const int c = blockIdx.x*WG + tid;
     const bool live = c < ncell;
     const int AF = sc.n_agents*sc.n_model;
@@ -1702,6 +1910,11 @@ int ms_device_count(void) {
 
 void ms_host_sincospi(float x, float* s, float* c) { sincospi_f(x, *s, *c); }
 
+int ms_host_bake_point_bin(float light_x, float light_y, float x, float y) { return bake_point_bin(p2(light_x, light_y), p2(x, y)); }
+void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, float bx, float by, int* first, int* count) {
+    bake_wall_bins(p2(light_x, light_y), ax, ay, bx, by, *first, *count);
+}
+
 int ms_move_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, float* progress, const MsConfig* cfg,
                     void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
@@ -1763,7 +1976,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // dynlight_kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
     const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
     const bool pooled = out->obs_rgb || out->obs_depth;
-    if (!all_planes && !(grid || sc->n_agents == 1)) return MS_EINVAL;
+    if ((!all_planes || pooled) && !(grid || sc->n_agents == 1)) return MS_EUNSUPPORTED;   // dynlight_kernel patches `screen` afterwards
     if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
     const bool obs = pooled || !all_planes;
     RenderConsts rc;
@@ -1797,8 +2010,17 @@ int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !sc->textures_widths || !sc->textures_starts || !sc->textures_inverse ||
         !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
-    if (sc->n_texels_total > 0)
+    if (sc->n_texels_total > 0 && sc->bake_vis) {
+        // two phases: visibility once per representative env and light, then the per-env sums
+        if (!sc->bake_vis_starts || sc->bake_vis_words < 0 || !sc->lines_inverse || ((uintptr_t)sc->bake_vis % 8)) return MS_EINVAL;
+        static const bool bins = [] { const char* e = getenv("MEGASTEP_BAKE_BINS"); return !(e && e[0] == '0'); }();
+        if (sc->n_lights_total > 0)
+            hipLaunchKernelGGL(visibility_kernel, dim3(sc->n_lights_total), dim3(WG), 0, (hipStream_t)stream, *sc, bins ? 1 : 0);
+        const long long blocks = ((long long)sc->n_texels_total + WG - 1)/WG;
+        hipLaunchKernelGGL(bake_sum_kernel, dim3((unsigned)blocks), dim3(WG), 0, (hipStream_t)stream, *sc);
+    } else if (sc->n_texels_total > 0) {
         hipLaunchKernelGGL(bake_kernel, dim3(sc->n_envs), dim3(WG), 0, (hipStream_t)stream, *sc);
+    }
     if (sc->lg_vals) {
         if (!sc->lg_starts || !sc->lg_geom || !(sc->lg_cell > 0.f) || sc->lg_max_cells <= 0 || ((uintptr_t)sc->lg_vals % 16) ||
             ((uintptr_t)sc->lg_geom % 16)) return MS_EINVAL;

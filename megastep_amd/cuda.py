@@ -184,7 +184,7 @@ class Scenery:
     ``lines`` is ragged per env with the ``n_agents*len(model)`` agent lines first; ``textures`` and ``baked`` are
     ragged per *line*. ``baked`` starts as ones and is filled in by :func:`bake`."""
 
-    def __init__(self, n_agents, lights, lines, textures, model):
+    def __init__(self, n_agents, lights, lines, textures, model, geom=None):
         if not isinstance(lights, Ragged2D) or not isinstance(lines, Ragged3D) or not isinstance(textures, Ragged2D):
             raise RuntimeError('lights, lines, textures must be Ragged2D, Ragged3D, Ragged2D')
         _check(model, 'model', torch.float32, 3)
@@ -198,6 +198,14 @@ class Scenery:
         self._n_agents = int(n_agents)
         self._lights, self._lines, self._textures, self._model = lights, lines, textures, model
         self._baked = Ragged1D(torch.ones_like(textures.vals[:, 0]).contiguous(), textures.widths)
+        # Beyond the reference: `geom` (n_envs,) int32 names, for every env, the first env with bit-identical walls
+        # and light positions (see MsScenery.env_geom). bake() then does the expensive part once per distinct
+        # floorplan, and such envs share one light grid. None: every env stands alone.
+        if geom is not None:
+            _check(geom, 'geom', torch.int32, 1)
+            if len(geom) != len(lines) or geom.device != lines.vals.device:
+                raise RuntimeError('geom must have one entry per env, on the same device as the lines')
+        self._geom = geom
         self._struct = None
         self._lg = None             # the light grid's tensors; made by _as_struct unless sharding carried one over
         self._dev = None
@@ -208,6 +216,7 @@ class Scenery:
     textures = property(lambda self: self._textures)
     model = property(lambda self: self._model)
     baked = property(lambda self: self._baked)
+    geom = property(lambda self: self._geom)
 
     def state(self, e):
         from . import dotdict
@@ -221,7 +230,10 @@ class Scenery:
     def _light_grid(self):
         """Storage and geometry of the light grid (see include/megastep_hip.h): a uniform grid over each env's walls,
         half a metre of slack around them: per cell the lights' verdicts and a candidate list drawn from a shared pool.
-        `bake` fills it in; zeros mean 'unknown, test every wall', which is always safe."""
+        `bake` fills it in; zeros mean 'unknown, test every wall', which is always safe. Envs that share their
+        geometry (`geom`) share their representative's cells. 72 bytes per cell (16 verdicts + 8 list header + 48 pool):
+        about 1.2 KB per square metre of floorplan, i.e. tens of times the floorplan's own lines - hence the sharing,
+        and no grid at all for single-agent sceneries, whose rays never land on an agent."""
         ln = self._lines
         dev = ln.vals.device
         n_envs, cell = len(ln), self.LIGHT_GRID_CELL
@@ -237,9 +249,11 @@ class Scenery:
         origin = torch.floor(lo) - .5
         dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
         cells = (dims[:, 0]*dims[:, 1]).long()
-        starts = (cells.cumsum(0) - cells).to(torch.int32)
-        geom = torch.cat([origin, dims], 1).float().contiguous()
-        total = int(cells.sum())
+        rep = torch.arange(n_envs, device=dev) if self._geom is None else self._geom.long()
+        own = cells*(rep == torch.arange(n_envs, device=dev))          # members own no cells
+        starts = (own.cumsum(0) - own)[rep].to(torch.int32)
+        geom = torch.cat([origin, dims], 1).float()[rep].contiguous()
+        total = int(own.sum())
         vals = torch.zeros((total, 4), dtype=torch.int32, device=dev)
         lists = torch.zeros((total, 2), dtype=torch.int32, device=dev)
         pool = torch.zeros(min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1), dtype=torch.int32, device=dev)
@@ -251,7 +265,9 @@ class Scenery:
             # the grid holds 64 lights per env; sceneries beyond that go without
             few_lights = len(li.widths) == 0 or int(li.widths.max()) <= 64
             if self._lg is None:
-                self._lg = self._light_grid() if few_lights else (None, None, None, 0., 0, None, None)
+                # (one agent per env: no ray ever lands on an agent line, so nothing would consult the grid)
+                wanted = few_lights and self._n_agents > 1
+                self._lg = self._light_grid() if wanted else (None, None, None, 0., 0, None, None)
             lg = self._lg
             self._struct = _lib.MsScenery(
                 len(ln), self._n_agents, self._model.shape[0],
@@ -261,8 +277,23 @@ class Scenery:
                 self._model.data_ptr(), self._baked.vals.data_ptr(),
                 ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0],
                 *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4],
-                *(t.data_ptr() if t is not None else None for t in lg[5:7]), lg[6].shape[0] if lg[6] is not None else 0)
+                *(t.data_ptr() if t is not None else None for t in lg[5:7]), lg[6].shape[0] if lg[6] is not None else 0,
+                self._geom.data_ptr() if self._geom is not None else None, None, None, 0)
         return self._struct
+
+    def _bake_plan(self):
+        """Scratch for the two-phase bake (MsScenery.bake_vis): for each representative env, lights x ceil(texels/64)
+        words. Returns (vis, starts) - torch tensors that must outlive the launch."""
+        li, ln, tx = self._lights, self._lines, self._textures
+        dev = ln.vals.device
+        n_envs = len(ln)
+        first, last = ln.starts.long(), (ln.ends - 1).long().clamp(min=0)
+        texels = torch.where(ln.widths > 0, tx.ends.long()[last] - tx.starts.long()[first], torch.zeros_like(first))
+        words = li.widths.long()*((texels + 63)//64)
+        rep = torch.arange(n_envs, device=dev) if self._geom is None else self._geom.long()
+        own = words*(rep == torch.arange(n_envs, device=dev))
+        starts = (own.cumsum(0) - own)[rep].contiguous()
+        return torch.empty(max(int(own.sum()), 1), dtype=torch.int64, device=dev), starts
 
     def _device(self):
         """The GPU all of this scenery's tensors live on (checked once; the tensors cannot be swapped out)."""
@@ -331,15 +362,21 @@ def _agents_on(agents, dev):
         raise RuntimeError(f'all tensors must live on one device; got {agents._dev} and {dev}')
 
 
-def bake(scenery):
+def bake(scenery, scratch=True):
     """Pre-computes the static lighting of every texel into ``scenery.baked`` (reference: wrappers.cpp:61,
-    kernels.cu:270-293)."""
+    kernels.cu:270-293). ``scratch=False`` selects the library's self-contained one-pass kernel (no temporary
+    allocation, no sharing between envs; same result)."""
     dev = scenery._device()
     # bake uses none of the initialize() constants (kernels.cu:238-293), and scene.scenery() calls it before any Core
     # exists, so the config is optional here
     cfg = C.byref(_config) if _config is not None else None
+    struct = scenery._as_struct()
+    if scratch:
+        vis, starts = scenery._bake_plan()
+        struct = _lib.MsScenery.from_buffer_copy(struct)
+        struct.bake_vis, struct.bake_vis_starts, struct.bake_vis_words = vis.data_ptr(), starts.data_ptr(), vis.shape[0]
     with _on(dev):
-        _lib.check(_lib.lib().ms_bake(C.byref(scenery._as_struct()), cfg, _stream(dev)))
+        _lib.check(_lib.lib().ms_bake(C.byref(struct), cfg, _stream(dev)))
 
 
 def physics(scenery, agents, movement=None):
@@ -393,6 +430,11 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False):
     want = FIELDS if fields is None else tuple(fields)
     if any(f not in FIELDS for f in want):
         raise RuntimeError(f'fields must be among {FIELDS}')
+    scenery._as_struct()
+    if a > 1 and scenery._lg[0] is None:
+        # no light grid (an env with more than 64 lights): agent hits are lit by a second launch that reads all five
+        # planes back and patches `screen` - after any pooling. All planes then, and the caller pools.
+        want, pooled = FIELDS, None
     sub, max_depth, w = 1, 1., r
     n_rgb = n_depth = 0
     if pooled is not None:

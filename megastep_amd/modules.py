@@ -182,23 +182,53 @@ class IMU:
 
 def random_empty_positions(geometries, n_agents, n_points):
     """(n_geometries, n_agents, n_points, 2) randomly chosen free-cell centres, precomputed so respawns are cheap
-    (reference: modules.py:272-296; consumes the global ``np.random`` in the same order)."""
-    points = []
-    for g in geometries:
-        free = np.stack((g['masks'] > 0).nonzero(), -1)
+    (reference: modules.py:272-296; consumes the global ``np.random`` in the same order, env by env). The free cells of
+    a geometry that turns up many times are looked up once."""
+    free_cells = {}
+    points = np.empty((len(geometries), n_agents, n_points, 2))
+    for e, g in enumerate(geometries):
+        free = free_cells.get(id(g))
+        if free is None:
+            free = free_cells[id(g)] = np.stack((g['masks'] > 0).nonzero(), -1)
         n_possible = min(len(free)//n_agents, n_points)
         sample = free[np.random.choice(np.arange(len(free)), (n_possible, n_agents), replace=True)]
         sample = np.concatenate([sample]*int(n_points/len(sample) + 1))[-n_points:]
         sample = np.random.permutation(sample)
-        points.append(geometry.centers(sample, g['masks'].shape, g['res']).transpose(1, 0, 2))
-    return arrdict.stack(points)
+        points[e] = geometry.centers(sample, g['masks'].shape, g['res']).transpose(1, 0, 2)
+    return points
+
+
+def _device_empty_positions(geometries, n_agents, n_points, device):
+    """:func:`random_empty_positions` drawn on the device: every spawn point an independent uniform pick among its
+    geometry's free cells (what the reference's choice-then-permute amounts to whenever a geometry has at least
+    ``n_agents*n_points`` free cells), from torch's generator instead of ``np.random``."""
+    tables, which = {}, np.empty(len(geometries), np.int64)
+    for e, g in enumerate(geometries):
+        if id(g) not in tables:
+            free = np.stack((g['masks'] > 0).nonzero(), -1)
+            tables[id(g)] = (len(tables), geometry.centers(free, g['masks'].shape, g['res']))
+        which[e] = tables[id(g)][0]
+    centres = [c for _, c in tables.values()]
+    counts = torch.as_tensor([len(c) for c in centres], device=device)
+    starts = (counts.cumsum(0) - counts)[torch.as_tensor(which, device=device)]
+    counts = counts[torch.as_tensor(which, device=device)]
+    pick = (torch.rand((len(geometries), n_agents, n_points), device=device, dtype=torch.float64)*counts[:, None, None]).long()
+    pick = torch.minimum(pick, counts[:, None, None] - 1) + starts[:, None, None]
+    return torch.as_tensor(np.concatenate(centres), device=device).float()[pick]
 
 
 class RandomSpawns:
 
-    def __init__(self, geometries, core, n_spawns=100):
-        """Respawns agents at random free points of their geometry (reference: modules.py:298-326)."""
+    def __init__(self, geometries, core, n_spawns=100, fast=False):
+        """Respawns agents at random free points of their geometry (reference: modules.py:298-326). ``fast=True``
+        draws the spawn tables on the device (same distribution, torch's random stream instead of numpy's) - for
+        worlds of 10^4 envs and up, where the reference's per-env loop takes seconds."""
         self.core = core
+        if fast:
+            positions = _device_empty_positions(geometries, core.n_agents, n_spawns, core.device)
+            angles = torch.empty(positions.shape[:3], device=core.device).uniform_(-180, 180)
+            self._spawns = arrdict.arrdict(positions=positions, angles=angles)
+            return
         positions = random_empty_positions(geometries, core.n_agents, n_spawns)
         angles = core.random.uniform(-180, +180, (len(geometries), core.n_agents, n_spawns))
         self._spawns = arrdict.torchify(arrdict.arrdict(positions=positions, angles=angles)).to(core.device)

@@ -29,38 +29,53 @@ def shard_scenery(scenery, rank, world_size, device=None):
         raise ValueError(f'rank {rank} of {world_size} would own no envs out of {len(scenery.lines)}')
     l0, l1 = int(scenery.lines.starts[start]), int(scenery.lines.ends[stop - 1])
     move = lambda r: type(r)(r.vals.to(device).contiguous().clone(), r.widths.to(device).contiguous().clone())
+    geom = None
+    if getattr(scenery, 'geom', None) is not None:
+        # representatives are re-elected inside the shard: the first env of the slice with the same floorplan
+        parent_rep = scenery.geom[start:stop].long()
+        _, group = torch.unique(parent_rep, return_inverse=True)
+        here = torch.arange(stop - start, device=group.device)
+        first = torch.full((int(group.max()) + 1,), stop - start, device=group.device).scatter_reduce_(0, group, here, 'amin')
+        geom = first[group].to(torch.int32).to(device).contiguous()
     out = cuda.Scenery(
         n_agents=scenery.n_agents,
         lights=move(scenery.lights[start:stop]),
         lines=move(scenery.lines[start:stop]),
         textures=move(scenery.textures[l0:l1]),
-        model=scenery.model.to(device).clone())
+        model=scenery.model.to(device).clone(), geom=geom)
     out.baked.vals.copy_(scenery.baked[l0:l1].vals)
-    # the light grid (what ms_bake caches about which lights reach which cells) is per env too: carry its slice over
+    # the light grid (what ms_bake caches about which lights reach which cells) is per floorplan: carry the slice's over
     parent = getattr(scenery, '_lg', None)
     if parent is not None and parent[0] is not None and out.model.is_cuda:
-        out._lg = _shard_light_grid(parent, start, stop, device)
+        out._lg = _shard_light_grid(parent, start, stop, device, geom)
     return out
 
 
-def _shard_light_grid(lg, start, stop, device):
-    """Envs [start, stop) of a baked light grid (cuda.Scenery._light_grid's tuple): the verdict rows as they are, the
-    candidate lists repacked into a pool of their own (the parent's pool is filled in no particular order)."""
-    vals, starts, geom, cell, _, lists, pool = lg
-    c0 = int(starts[start])
-    c1 = int(starts[stop]) if stop < len(starts) else vals.shape[0]
-    sub_starts = (starts[start:stop] - c0).to(device).contiguous()
-    sub_geom = geom[start:stop].to(device).contiguous().clone()
+def _shard_light_grid(lg, start, stop, device, geom=None):
+    """Envs [start, stop) of a baked light grid (cuda.Scenery._light_grid's tuple): the cells of the slice's
+    representative envs (`geom`, slice-local; None = every env its own) back to back, the candidate lists repacked into
+    a pool of their own (the parent's pool is filled in no particular order)."""
+    vals, starts, grid, cell, _, lists, pool = lg
+    dev = vals.device
+    n = stop - start
+    rep = torch.arange(n, device=dev) if geom is None else geom.long().to(dev)
+    sub_geom = grid[start:stop]
     cells = (sub_geom[:, 2]*sub_geom[:, 3]).long()
-    rows = lists[c0:c1].long() & 0xffffffff
+    own = cells*(rep == torch.arange(n, device=dev))
+    new_starts = (own.cumsum(0) - own)
+    total = int(own.sum())
+    # for every cell of the shard, the parent's row it copies
+    src = torch.arange(total, device=dev) + torch.repeat_interleave(starts[start:stop].long() - new_starts, own, output_size=total)
+    rows = lists[src].long() & 0xffffffff
     count = torch.where(rows[:, 1] != 0, rows[:, 1] & 0x7fffffff, torch.zeros_like(rows[:, 1]))
     first = count.cumsum(0) - count                                   # 0-based position in the new pool's payload
-    cell_of = torch.repeat_interleave(torch.arange(len(count), device=count.device), count)
-    src = rows[cell_of, 0] + (torch.arange(int(count.sum()), device=count.device) - first[cell_of])
-    sub_pool = torch.cat([count.sum()[None].to(pool.dtype), pool[src]])
+    cell_of = torch.repeat_interleave(torch.arange(len(count), device=dev), count)
+    take = rows[cell_of, 0] + (torch.arange(int(count.sum()), device=dev) - first[cell_of])
+    sub_pool = torch.cat([count.sum()[None].to(pool.dtype), pool[take]])
     sub_lists = torch.stack([torch.where(rows[:, 1] != 0, first + 1, torch.zeros_like(first)), rows[:, 1]], 1).to(torch.int32)
-    return (vals[c0:c1].to(device).contiguous().clone(), sub_starts.to(torch.int32), sub_geom, cell, int(cells.max()),
-            sub_lists.to(device).contiguous(), sub_pool.to(device).contiguous())
+    return (vals[src].to(device).contiguous().clone(), new_starts[rep].to(torch.int32).to(device).contiguous(),
+            sub_geom.to(device).contiguous().clone(), cell, int(cells.max()), sub_lists.to(device).contiguous(),
+            sub_pool.to(device).contiguous())
 
 
 def max_over_ranks(seconds, device=None):

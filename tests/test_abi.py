@@ -1,6 +1,7 @@
 """The C-ABI library: loads, exports every symbol include/megastep_hip.h declares, validates arguments, and fails loudly.
 No kernel is launched here (no GPU in the authoring container)."""
 import ctypes as C
+C_int = C.c_int
 import os
 import re
 import numpy as np
@@ -86,3 +87,47 @@ def test_product_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for pat in banned:
                     assert not re.search(pat, text, flags=re.M), (os.path.join(dirpath, f), pat)
+
+
+def test_bake_bins_never_hide_an_obstructing_wall():
+    """ms_bake's angular bins (host instantiations of the device functions): whenever the reference's obstructed()
+    test (kernels.cu:238-259, evaluated in binary32) says a wall blocks a point from a light, the point's bin lies
+    in the wall's run of bins - over random scenes salted with the degenerate cases (points and walls next to the
+    light, lights on a wall's line, tiny and huge walls)."""
+    from megastep_amd import _lib
+    h = _lib.lib()
+    rng = np.random.RandomState(0)
+    n = 60000
+    f = np.float32
+    I = rng.uniform(1, 20, (n, 2)).astype(f)
+    a = rng.uniform(0, 21, (n, 2)).astype(f)
+    v = (rng.normal(size=(n, 2))*rng.choice([.01, .3, 3., 15.], (n, 1))).astype(f)
+    pt = rng.uniform(0, 21, (n, 2)).astype(f)
+    k = n//6
+    pt[:k] = I[:k] + (rng.normal(size=(k, 2))*rng.choice([1e-4, 1e-2, .1], (k, 1))).astype(f)         # points by the light
+    a[k:2*k] = I[k:2*k] + (rng.normal(size=(k, 2))*rng.choice([1e-4, 1e-2, .1], (k, 1))).astype(f)  # walls by the light
+    t = rng.uniform(-.2, 1.2, (k, 1)).astype(f)                                                      # lights on the wall's line
+    I[2*k:3*k] = (a[2*k:3*k] + t*v[2*k:3*k] + (rng.normal(size=(k, 2))*rng.choice([0, 1e-5, 1e-3], (k, 1)))).astype(f)
+    pt[3*k:4*k] = (a[3*k:4*k] + rng.uniform(0, 1, (k, 1)).astype(f)*v[3*k:4*k]                         # points just behind walls
+                  + (rng.normal(size=(k, 2))*1e-2)).astype(f)
+    b = (a + v).astype(f)
+    V = (b - a).astype(f)
+    # obstructed(): intersect(I, C - I, a, b - a), binary32 as the reference writes it
+    U = (pt - I).astype(f)
+    cross = lambda p, q: (p[:, 0]*q[:, 1] - p[:, 1]*q[:, 0]).astype(f)
+    UxV = cross(U, V)
+    PQ = (a - I).astype(f)
+    with np.errstate(all='ignore'):
+        s = (cross(PQ, V)/UxV).astype(f)
+        tt = (cross(PQ, U)/UxV).astype(f)
+    blocked = (np.abs(UxV) >= f(1e-3)) & (tt > 0) & (tt < 1) & (s > 0) & (s < f(.999))
+    assert blocked.sum() > 2000
+    first, count = C_int(), C_int()
+    narrow = 0
+    for i in np.flatnonzero(blocked):
+        pb = h.ms_host_bake_point_bin(I[i, 0], I[i, 1], pt[i, 0], pt[i, 1])
+        h.ms_host_bake_wall_bins(I[i, 0], I[i, 1], a[i, 0], a[i, 1], b[i, 0], b[i, 1], C.byref(first), C.byref(count))
+        assert 0 <= first.value < 64 and 1 <= count.value <= 64
+        narrow += count.value < 64
+        assert pb == -1 or (pb - first.value) % 64 < count.value, (i, pb, first.value, count.value)
+    assert narrow > 1000        # the bins do cull

@@ -178,3 +178,80 @@ def test_light_grid_shard_repacks_candidate_lists():
                 first, n = int(l64[i, 0]), int(l64[i, 1]) & 0x7fffffff
                 assert int(l64[i, 1]) >> 31 == 1 and n == counts[c] and first >= 1
                 assert sorted(p64[first:first + n].tolist()) == wanted[c]
+
+
+@pytest.mark.parametrize('shared_stream', [False, True])
+def test_vectorised_scenery_equals_the_reference_assembly_loop(shared_stream):
+    """scene.scenery works per distinct floorplan and gathers; the result must be what the reference's per-env loop
+    (scene.py:75-100) produces, value for value, random streams included - also when geometries repeat and when the
+    wall patterns come from the same global stream as the light intensities."""
+    from megastep_amd import scene, cubicasa, toys
+    from tests import util
+    pool = cubicasa.sample(3, n_unique=16)
+    box = toys.box()
+    geoms = [pool[0], box, pool[1], pool[0], pool[2], box, box, pool[1]]
+    np.random.seed(11)
+    want = util.scenery_by_the_book(geoms, 3, np.random if shared_stream else np.random.RandomState(4))
+    np.random.seed(11)
+    got = scene.scenery(geoms, 3, device='cpu', bake=False, random=np.random if shared_stream else np.random.RandomState(4))
+    for k, t in [('lights_vals', got.lights.vals), ('lights_widths', got.lights.widths), ('lines_vals', got.lines.vals),
+                 ('lines_widths', got.lines.widths), ('textures_vals', got.textures.vals), ('textures_widths', got.textures.widths)]:
+        np.testing.assert_array_equal(t.numpy(), want[k], err_msg=k)
+    # envs built from one geometry object name the first of them as their representative
+    assert got.geom.tolist() == [0, 1, 2, 0, 4, 1, 1, 2]
+    assert scene.scenery(pool, 1, device='cpu', bake=False).geom is None
+
+
+def test_fast_scenery_has_the_same_layout_and_statistics():
+    """fast=True draws intensities and wall patterns on the device: everything deterministic (lines, texel counts,
+    which colour a texel has) is unchanged; brightness levels follow the same law (in [.5, 1), agent texels 1, level
+    changes about every 10th texel); intensities are U(.5, 2)."""
+    from megastep_amd import scene, cubicasa
+    pool = cubicasa.sample(4, n_unique=16)
+    geoms = [pool[i % 4] for i in range(12)]
+    np.random.seed(0)
+    ref = scene.scenery(geoms, 2, device='cpu', bake=False)
+    torch.manual_seed(0)
+    got = scene.scenery(geoms, 2, device='cpu', bake=False, fast=True)
+    np.testing.assert_array_equal(got.lines.vals.numpy(), ref.lines.vals.numpy())
+    np.testing.assert_array_equal(got.textures.widths.numpy(), ref.textures.widths.numpy())
+    np.testing.assert_array_equal(got.lights.vals[:, :2].numpy(), ref.lights.vals[:, :2].numpy())
+    inten = got.lights.vals[:, 2].numpy()
+    assert inten.min() >= .5 and inten.max() <= 2. and abs(inten.mean() - 1.25) < .1
+    agent_texels = 2*2*8
+    for e in range(len(geoms)):
+        t0 = int(ref.textures.starts[int(ref.lines.starts[e])])
+        t1 = int(ref.textures.ends[int(ref.lines.ends[e]) - 1])
+        tex_got, tex_ref = got.textures.vals[t0:t1].numpy(), ref.textures.vals[t0:t1].numpy()
+        np.testing.assert_array_equal(tex_got[:agent_texels], tex_ref[:agent_texels])       # agents are drawn flat
+        # same hue, texel by texel: got = colour*b1, ref = colour*b2 with b in [.5, 1)
+        b = tex_got[agent_texels:].max(1)/np.maximum(tex_ref[agent_texels:].max(1), 1e-9)
+        assert (b > .5/1.).all() and (b < 1./.5).all()
+    # the pattern's statistics, read off one wall colour channel: jumps in ~10% of the steps within a long wall
+    w = ref.textures.widths.numpy()
+    longest = int(np.argmax(w))
+    t0 = int(ref.textures.starts[longest])
+    seg = got.textures.vals[t0:t0 + w[longest]].numpy().max(1)
+    assert len(seg) > 50 and .02 < (np.diff(seg) != 0).mean() < .3
+
+
+def test_shards_of_sceneries_with_shared_floorplans():
+    """Envs that share a floorplan share a light grid; a shard re-elects representatives among its own envs and takes
+    exactly their cells along."""
+    from megastep_amd import sharding, scene
+    pool = cubicasa.sample(3, n_unique=16)
+    geoms = [pool[0], pool[1], pool[0], pool[2], pool[1], pool[1], pool[0]]
+    full = scene.scenery(geoms, 2, device='cpu', random=np.random.RandomState(0), bake=False)
+    assert full.geom.tolist() == [0, 1, 0, 3, 1, 1, 0]
+    shard = sharding.shard_scenery(full, 1, 2)                # envs 4, 5, 6: floorplans 1, 1, 0
+    assert shard.geom.tolist() == [0, 0, 2]
+    assert sharding.shard_scenery(full, 0, 7).geom.tolist() == [0]
+    # a light grid with shared cells: envs 0, 2, 6 -> cells [0, 6), envs 1, 4, 5 -> [6, 10), env 3 -> [10, 14)
+    dims = torch.tensor([[3., 2.], [1., 4.], [3., 2.], [2., 2.], [1., 4.], [1., 4.], [3., 2.]])
+    grid = torch.cat([torch.zeros(7, 2), dims], 1)
+    starts = torch.tensor([0, 6, 0, 10, 6, 6, 0], dtype=torch.int32)
+    vals = torch.arange(14*4, dtype=torch.int32).view(14, 4)
+    lists = torch.zeros((14, 2), dtype=torch.int32)
+    pool_ = torch.zeros(1, dtype=torch.int32)
+    v, s, g, cell, mx, l, p = sharding._shard_light_grid((vals, starts, grid, .25, 6, lists, pool_), 4, 7, 'cpu', shard.geom)
+    assert s.tolist() == [0, 0, 4] and torch.equal(v, torch.cat([vals[6:10], vals[0:6]])) and torch.equal(g, grid[4:7])
