@@ -5,14 +5,27 @@
 Workload (BASELINE.json `metric`): 4096 envs x 4 agents x 64-ray RGBD per GPU, seeded synthetic cubicasa-like
 floorplans, random momentum actions. One *step* = one pass of the hot path over the whole batch: `ms_physics` then
 `ms_render`, both through the C-ABI; the step's inputs (velocities produced beforehand by the momentum-movement glue
-from random actions) are resident in HBM and read in place. With --gpus N>1 the driver launches this file under torch.distributed.run; every rank owns its
-own 4096-env slice (weak scaling, no data-path collective - envs are independent) and rank 0 prints one JSON line.
+from random actions) are resident in HBM and read in place.
+
+The K timed steps are enqueued as ONE HIP graph (2K kernel nodes, recorded once, replayed inside the timed region):
+`value` is that replay's rate - what the kernels can do with the host out of the way. The same K steps launched one by
+one from Python (`eager`) are timed beside it, with HIP events around every step and every render for the per-step
+spread and the roofline.
+
+With --gpus N>1 the driver launches this file under torch.distributed.run, one rank per GPU. The world holds N x
+--envs envs; every rank cuts its slice out of it with `sharding.shard_scenery` (contiguous env slices balanced by
+lines x agents x rays - weak scaling, no collective on the data path: envs are independent); the ranks meet only in a
+gloo barrier around the timed region and a MAX over their times, so RCCL is never initialised. Rank 0 prints one JSON
+line.
 
 Besides the contract fields the line carries
   roofline      render kernel (the dominant one): algorithmic bytes per launch / its mean launch time (HIP events
-                around every render launch of the timed region) against the 8 TB/s HBM peak;
-  cpu_baseline  the CPU oracle (oracle/, a plain-C port of the reference's kernels) on this box's host cores, on a
-                bounded sample of the same workload - reported only, never the target.
+                around every render launch of the eager timed region) against the 8 TB/s HBM peak;
+  cpu_baseline  a pure-PyTorch CPU step (oracle/torch_step.py, the restatement of the reference's kernels as tensor
+                ops) on this box's host cores, on a bounded sample of the same workload - reported only, never the
+                target; `cpu_baseline_c` is the plain-C port with OpenMP over envs on the same sample;
+  env_step      whole `env.step()` rates of the reference-shaped Explorer and Deathmatch envs (what the reference's
+                docs quote), eager and replayed as a HIP graph.
 """
 import argparse
 import json
@@ -29,15 +42,21 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False):
-    from megastep_amd import core, cubicasa, modules, scene
+def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False):
+    """The benchmark's world. With world > 1 the whole N x n_envs world is assembled and this rank keeps its slice."""
+    from megastep_amd import core, cubicasa, modules, scene, sharding
     np.random.seed(seed)
     pool = cubicasa.sample(min(n_unique, n_envs), seed=seed + 1, n_unique=max(n_unique, 16), large=large)
-    geometries = [pool[i % len(pool)] for i in range(n_envs)]
-    scenery = scene.scenery(geometries, n_agents, device=device, random=np.random.RandomState(seed))
+    geometries = [pool[i % len(pool)] for i in range(world*n_envs)]
+    scenery = scene.scenery(geometries, n_agents, device=device, random=np.random.RandomState(seed), bake=bake, fast=fast)
+    if world > 1:
+        cost = sharding.render_cost(scenery, res)
+        start, stop = sharding.env_slice(len(geometries), rank, world, cost)
+        scenery = sharding.shard_scenery(scenery, rank, world, cost=cost)
+        geometries = geometries[start:stop]
     c = core.Core(scenery, res=res, fov=fov, fps=10)
-    spawner = modules.RandomSpawns(geometries, c)
-    torch.manual_seed(seed)
+    spawner = modules.RandomSpawns(geometries, c, fast=fast)
+    torch.manual_seed(seed + rank)
     spawner(c.agent_full(True))
     return c, geometries
 
@@ -59,7 +78,7 @@ def algorithmic_bytes(core):
     return render, physics
 
 
-def env_step_fps(device, n_core_envs=4096, steps=60, warmup=10):
+def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     """Whole env.step() rates - kernels plus the torch glue of megastep_amd.demo.envs - with random actions, the
     quantity the reference's docs quote (docs/index.rst:13-25: Explorer 180k FPS, Deathmatch 1.2m FPS on a 2080 Ti).
     Explorer renders 256 rays -> 64 px, Deathmatch 512 -> 128 px, as in the reference; FPS counts agent-envs."""
@@ -104,38 +123,70 @@ def env_step_fps(device, n_core_envs=4096, steps=60, warmup=10):
     return out
 
 
-def measured_traffic(args, world):
+def measured_traffic(args):
     """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact command (profiles/rNN_traffic.json,
     written by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950). None when the workload differs from the profiled one."""
+    MI355X_MICROARCH.md prescribes for gfx950) and the file it was read from. (None, None) when the workload differs
+    from the profiled one: PMC counters cannot be collected from inside the benchmark process."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
         t = json.load(open(path))
         w = t.get('workload', {})
         if (w.get('envs'), w.get('agents'), w.get('res'), w.get('large', False)) == (args.envs, args.agents, args.res, args.large):
-            return t['render_bytes_per_launch']
-    return None
+            return t['render_bytes_per_launch'], os.path.relpath(path, ROOT)
+    return None, None
 
 
-def cpu_baseline(core, budget_s=4., max_envs=4096):
-    """The CPU oracle on a bounded sample: the first `max_envs` envs of this workload, all host cores (OpenMP over
-    envs), for about `budget_s` seconds of wall time (a few tens of seconds of CPU work per 8 cores)."""
-    from oracle import oracle as O
+def _oracle_sample(core, max_envs):
+    """The first `max_envs` envs of the workload as an oracle scene dict + agents (numpy)."""
     from tests import util
     n = min(max_envs, core.n_envs)
     sc = core.scenery
     e_l, e_i = int(sc.lines.ends[n - 1]), int(sc.lights.ends[n - 1])
     e_t = int(sc.textures.ends[e_l - 1])
     g = lambda t: t.detach().cpu().numpy()
-    scene = O.Scene(dict(
+    scene = dict(
         n_agents=sc.n_agents, model=g(sc.model),
         lights_vals=g(sc.lights.vals[:e_i]), lights_widths=g(sc.lights.widths[:n]),
         lines_vals=g(sc.lines.vals[:e_l]), lines_widths=g(sc.lines.widths[:n]),
         textures_vals=g(sc.textures.vals[:e_t]), textures_widths=g(sc.textures.widths[:e_l]),
-        baked_vals=g(sc.baked.vals[:e_t])))
-    cfg = O.config(core.agent_radius, core.res, core.fov, core.fps)
-    agents = {k: v[:n] for k, v in util.agents_dict(core.agents).items()}
+        baked_vals=g(sc.baked.vals[:e_t]))
+    agents = {k: v[:n].copy() for k, v in util.agents_dict(core.agents).items()}
+    return n, scene, agents
+
+
+def cpu_baselines(core, budget_s=8.):
+    """The reported-only CPU baselines on a bounded sample of the workload, on this box's host cores.
+
+    `cpu_baseline`: the pure-PyTorch step (north_star; oracle/torch_step.py) on the first 256 envs, all cores through
+    torch's intra-op threads. `cpu_baseline_c`: the plain-C oracle on the first 4096 envs, OpenMP over envs. Each runs
+    for about `budget_s` seconds of wall time; both draw fresh random velocities every step, as the GPU legs' inputs do."""
+    from oracle import oracle as O
+    from oracle import torch_step
+    cores = os.cpu_count()
+    out = {}
     rng = np.random.RandomState(0)
+
+    n, scene, agents = _oracle_sample(core, 256)
+    torch.set_num_threads(cores)
+    world = torch_step.World(scene, core.agent_radius, core.res, core.fov, core.fps)
+    ag = {k: torch.as_tensor(v) for k, v in agents.items()}
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        ag['velocity'] = torch.as_tensor(rng.uniform(-3, 3, agents['velocity'].shape).astype(np.float32))
+        ag['angvelocity'] = torch.as_tensor(rng.uniform(-180, 180, agents['angvelocity'].shape).astype(np.float32))
+        torch_step.step(world, ag)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or steps >= 50:
+            break
+    out['cpu_baseline'] = {
+        'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'implementation': 'pure PyTorch (CPU tensors)',
+        'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/torch_step.py, torch.set_num_threads({cores})'}
+
+    n, scene, agents = _oracle_sample(core, 4096)
+    scene = O.Scene(scene)
+    cfg = O.config(core.agent_radius, core.res, core.fov, core.fps)
     steps, t0 = 0, time.perf_counter()
     while True:
         agents['velocity'] = rng.uniform(-3, 3, agents['velocity'].shape).astype(np.float32)
@@ -144,13 +195,82 @@ def cpu_baseline(core, budget_s=4., max_envs=4096):
         O.render(scene, agents, cfg)
         steps += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or steps >= 100:
+        if dt > budget_s/2 or steps >= 100:
             break
-    return {'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': f'first {n} envs of the workload x {steps} steps (physics+render), C oracle with OpenMP over envs'}
+    out['cpu_baseline_c'] = {
+        'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'implementation': 'plain C + OpenMP over envs',
+        'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/megastep_oracle.c'}
+    return out
 
 
-def main():
+class _Gpu:
+    """What the timing harness needs from the device; `_Stub` below stands in for it in the CPU dry run."""
+
+    def __init__(self, local_rank):
+        assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device('cuda', local_rank)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def hot_path(self, scenery):
+        from megastep_amd import cuda
+        state = {}
+
+        def step(view, ev=None):
+            state['p'] = cuda.physics(scenery, view, out=state.get('p'))
+            if ev is not None:
+                ev[1].record()
+            state['r'] = cuda.render(scenery, view, out=state.get('r'))
+            if ev is not None:
+                ev[2].record()
+        return step
+
+    def graph(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g.replay
+
+
+class _Stub:
+    """CPU stand-in for the device (python bench.py --dry-run-cpu, used by tests/test_bench_gloo.py): the world is built
+    and sharded for real on CPU tensors, the two kernel calls are replaced by a token tensor op, events by wall-clock
+    stamps. Exercises everything around the kernels - arguments, rendezvous, slices, timing, the JSON line."""
+
+    device = torch.device('cpu')
+
+    def sync(self):
+        pass
+
+    def event(self):
+        class E:
+            def record(self):
+                self.t = time.perf_counter()
+
+            def elapsed_time(self, other):
+                return 1e3*(other.t - self.t)
+        return E()
+
+    def hot_path(self, scenery):
+        def step(view, ev=None):
+            view.positions.add_(view.velocity, alpha=.1)
+            if ev is not None:
+                ev[1].record()
+            view.angles.add_(view.angvelocity, alpha=.1)
+            if ev is not None:
+                ev[2].record()
+        return step
+
+    def graph(self, fn):
+        return fn
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -160,24 +280,32 @@ def main():
     ap.add_argument('--res', type=int, default=64)
     ap.add_argument('--fov', type=float, default=130.)
     ap.add_argument('--large', action='store_true', help='800-1200 wall segments per env')
+    ap.add_argument('--unique', type=int, default=512, help='distinct floorplans in the world (tiled)')
+    ap.add_argument('--fast-build', action='store_true', help="draw textures, lights and spawns on the device (10^4+ envs)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--env-fps', action='store_true',
-                    help="also time full env.step() of the reference-shaped Explorer and Deathmatch envs (reported only)")
-    args = ap.parse_args()
+    ap.add_argument('--no-env-fps', action='store_true', help="skip the whole-env.step() rates of Explorer and Deathmatch")
+    ap.add_argument('--env-fps', action='store_true', help='(default now; kept for old command lines)')
+    ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
+    ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
+    args = ap.parse_args(argv)
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     distributed = world > 1
-    assert torch.cuda.is_available(), 'bench.py needs a GPU: the product has no CPU path'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank)
+    device = dev.device
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        # gloo: the ranks only meet in a barrier and a MAX of one float - envs are independent, RCCL stays out of it
+        dist.init_process_group('gloo')
+        barrier = dist.barrier
+    else:
+        barrier = lambda: None
 
-    from megastep_amd import cuda, modules
-    core, _ = build_world(args.envs, args.agents, args.res, args.fov, device, seed=1 + rank, large=args.large)
+    from megastep_amd import cuda, modules, sharding
+    core, _ = build_world(args.envs, args.agents, args.res, args.fov, device, seed=1, n_unique=args.unique, large=args.large,
+                          rank=rank, world=world, bake=not args.dry_run_cpu, fast=args.fast_build)
     N, A = core.n_envs, core.n_agents
     total = args.steps + args.warmup
 
@@ -186,87 +314,98 @@ def main():
     mover = modules.MomentumMovement(core)
     actions = torch.randint(0, 7, (total, N, A), device=device)
     scenery, agents = core.scenery, core.agents
+    hot = dev.hot_path(scenery)
 
-    def step(i):
+    # velocities per step are produced by the (untimed) torch movement glue ahead of time: a dry run of the env loop
+    vel = torch.empty((total, N, A, 2), device=device)
+    angvel = torch.empty((total, N, A), device=device)
+    for i in range(total):
         delta = mover._actionset[actions[i]]
         agents.angvelocity[:] = (1 - mover.decay)*agents.angvelocity + delta.angvelocity
         agents.velocity[:] = (1 - mover.decay)*agents.velocity + modules.to_global_frame(agents.angles, delta.velocity)
-        cuda.physics(scenery, agents)
-        return cuda.render(scenery, agents)
-
-    # velocities per step are produced by the (untimed) torch movement glue ahead of time
-    vel = torch.empty((total, N, A, 2), device=device)
-    angvel = torch.empty((total, N, A), device=device)
-    for i in range(total):       # a dry run of the env loop records the velocity targets
-        step(i)
+        hot(agents)
         vel[i], angvel[i] = agents.velocity, agents.angvelocity
-    torch.cuda.synchronize()
+    dev.sync()
 
     # One Agents view per step: positions/angles are the persistent state, velocity/angvelocity point at that
     # step's pre-generated inputs, already resident in HBM - the hot path reads its inputs in place, no copies.
     views = [cuda.Agents(agents.angles, agents.positions, angvel[i], vel[i]) for i in range(total)]
 
-    def timed_step(i, ev=None):
-        cuda.physics(scenery, views[i])
-        if ev is not None:
-            ev[0].record()
-        r = cuda.render(scenery, views[i])
-        if ev is not None:
-            ev[1].record()
-        return r
+    def timed(run):
+        barrier()
+        dev.sync()
+        t0 = time.perf_counter()
+        run()
+        dev.sync()
+        barrier()
+        return sharding.max_over_ranks(time.perf_counter() - t0)       # the slowest rank sets the step rate
 
+    # ---- eager: K steps launched one by one, events around every step and every render
     for i in range(args.warmup):
-        timed_step(i)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        hot(views[i])
+    events = [(dev.event(), dev.event(), dev.event()) for _ in range(args.steps)]
 
+    def eager():
+        for i in range(args.steps):
+            events[i][0].record()
+            hot(views[args.warmup + i], events[i])
+    eager_s = timed(eager)
+    step_ms = np.array([e[0].elapsed_time(e[2]) for e in events])
+    render_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+
+    # ---- graph: the same K steps as one HIP graph, replayed
+    graph_s = None
+    if not args.no_graph:
+        replay = dev.graph(lambda: [hot(views[args.warmup + i]) for i in range(args.steps)])
+        replay()                                                       # (instantiation / first-launch costs stay outside)
+        graph_s = timed(replay)
+
+    elapsed = graph_s if graph_s is not None else eager_s
+    n_total = N
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timed_step(args.warmup + i, events[i])
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    from megastep_amd import sharding
-    elapsed = sharding.max_over_ranks(elapsed, device)      # the slowest rank sets the step rate
-
-    render_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        t = torch.tensor([N], dtype=torch.int64)
+        dist.all_reduce(t)
+        n_total = int(t)
     rb, pb = algorithmic_bytes(core)
     achieved = rb/(render_ms*1e-3)/1e9
     ms_per_step = 1e3*elapsed/args.steps
-    value = world*N*args.steps/elapsed
+    value = n_total*args.steps/elapsed
+    traffic, traffic_source = measured_traffic(args)
 
     out = {
         'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {
-            'workload': f'{N} envs x {A} agents x {args.res}-ray RGBD per GPU, fov {args.fov:g}, synthetic cubicasa floorplans'
+            'workload': f'{args.envs} envs x {A} agents x {args.res}-ray RGBD per GPU, fov {args.fov:g}, synthetic cubicasa floorplans'
                         + (' (large maps)' if args.large else ''),
             'step': 'ms_physics + ms_render (C-ABI), per-step velocities from random momentum actions resident in HBM',
-            'envs_per_gpu': N, 'agents': A, 'res': args.res,
+            'launch': 'the K timed steps replayed as one HIP graph' if graph_s is not None else 'one Python call per kernel (eager)',
+            'envs_per_gpu': args.envs, 'envs_this_rank': N, 'envs_total': n_total, 'agents': A, 'res': args.res,
             'lines_per_env': scenery.lines.vals.shape[0]/N, 'lights_per_env': scenery.lights.vals.shape[0]/N,
-            'parallelism': f'env-sharded x{world}, no collectives'},
+            'parallelism': f'env-sharded x{world} (contiguous slices balanced by lines x agents x rays), no collectives'},
         'agent_steps_per_sec': value*A,
+        'eager': {'value': n_total*args.steps/eager_s, 'ms_per_step': 1e3*eager_s/args.steps,
+                  'step_ms_hip_events': {'min': float(step_ms.min()), 'median': float(np.median(step_ms)), 'max': float(step_ms.max())}},
         'roofline': {
             'kernel': 'ms_render = render_kernel<1,1,0> (headings cached by ms_physics)', 'bound': 'hbm', 'achieved': achieved,
-            'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS, 'traffic': measured_traffic(args, world),
+            'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
+            'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
             'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(core)
-    if rank == 0 and world == 1 and args.env_fps:
-        del core, scenery, agents
-        torch.cuda.empty_cache()
-        out['env_step'] = env_step_fps(device)
+    if rank == 0 and world == 1 and not args.dry_run_cpu:
+        if not args.no_cpu_baseline:
+            out.update(cpu_baselines(core))
+        if not args.no_env_fps:
+            del core, scenery, agents, views, hot
+            torch.cuda.empty_cache()
+            out['env_step'] = env_step_fps(device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+    return out
 
 
 if __name__ == '__main__':

@@ -211,7 +211,8 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 //
 // Reach cull (exact): all four sub-tests of collision_cs leave x = 1 for a wall farther from the agent than
 // 1.02|v| + 2r - the crossing and side tests need the wall within |v| + r of p, and an endpoint that far ahead
-// clamps to 1 (0.99 (a.s - backoff) >= 1).  The margin dwarfs rounding.  Lanes test one wall each with cheap
+// clamps to 1 (0.99 (a.s - backoff) >= 1).  The margin dwarfs rounding - for |v| >= 1e-3; slower agents (but not
+// stationary ones) are exempt from the cull, because project()'s |v| + 1e-6 distorts their distances.  Lanes test one wall each with cheap
 // arithmetic; the few (agent, wall) pairs in reach are compacted into LDS and only those pay for the ten
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     float4* s_box = s_task + A;
     float* s_reach2 = reinterpret_cast<float*>(s_box + A);
     unsigned* s_prog = reinterpret_cast<unsigned*>(s_reach2 + A);
-    const float2* __restrict__ pos2 = reinterpret_cast<const float2*>(ag.positions);
-    const float2* __restrict__ vel2 = reinterpret_cast<const float2*>(ag.velocity);
+    // (no __restrict__: the movement prologue and the epilogue write the same arrays through other pointers)
+    const float2* pos2 = reinterpret_cast<const float2*>(ag.positions);
+    const float2* vel2 = reinterpret_cast<const float2*>(ag.velocity);
 
     // the first wall chunks are requested before anything else: nothing below depends on them until the sweep
     const int L = sc.lines_widths[n];
@@ -274,7 +276,12 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
         const P2 p0 = p2(pp.x, pp.y);
         const P2 v0 = p2(mm.x, mm.y)/fps;
-        const float reach = 1.02f*len(v0) + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+        const float vl = len(v0);
+        float reach = 1.02f*vl + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+        // A crawling agent sees every wall: project() divides by (|v| + 1e-6), so below |v| ~ 1e-6 the reference's
+        // distances shrink until far-away endpoints pass `d < r` and stop the agent (x = 0).  Rare (a velocity that
+        // has decayed for a hundred steps), so those agents simply meet all the walls.
+        if ((vl > 0.f) & (vl < 1e-3f)) reach = INFINITY;
         s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
         s_box[t] = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
         s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
@@ -351,8 +358,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     if (cnt) flush();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // epilogue, kernels.cu:224-227
-    float2* __restrict__ pos2w = reinterpret_cast<float2*>(ag.positions);
-    float2* __restrict__ vel2w = reinterpret_cast<float2*>(ag.velocity);
+    float2* pos2w = reinterpret_cast<float2*>(ag.positions);
+    float2* vel2w = reinterpret_cast<float2*>(ag.velocity);
     for (int t = lane; t < A; t += WAVE) {
         const int i = n*A + t;
         const float x = bits_f(s_prog[t]);
@@ -2013,7 +2020,8 @@ int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
     if (sc->n_texels_total > 0 && sc->bake_vis) {
         // two phases: visibility once per representative env and light, then the per-env sums
         if (!sc->bake_vis_starts || sc->bake_vis_words < 0 || !sc->lines_inverse || ((uintptr_t)sc->bake_vis % 8)) return MS_EINVAL;
-        static const bool bins = [] { const char* e = getenv("MEGASTEP_BAKE_BINS"); return !(e && e[0] == '0'); }();
+        const char* be = getenv("MEGASTEP_BAKE_BINS");                 // =0: every texel meets every wall (A/B runs)
+        const bool bins = !(be && be[0] == '0');
         if (sc->n_lights_total > 0)
             hipLaunchKernelGGL(visibility_kernel, dim3(sc->n_lights_total), dim3(WG), 0, (hipStream_t)stream, *sc, bins ? 1 : 0);
         const long long blocks = ((long long)sc->n_texels_total + WG - 1)/WG;

@@ -379,13 +379,14 @@ def bake(scenery, scratch=True):
         _lib.check(_lib.lib().ms_bake(C.byref(struct), cfg, _stream(dev)))
 
 
-def physics(scenery, agents, movement=None):
+def physics(scenery, agents, movement=None, out=None):
     """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
     returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230).
 
     Beyond the reference: ``movement=(actions, table, keep)`` runs the movement modules' velocity update inside the same
     launch first (include/megastep_hip.h, MsMovement): ``actions`` (N, A) int64 rows of ``table`` (K, 3) = agent-frame
-    [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns)."""
+    [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns). ``out``: the
+    :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating."""
     dev = scenery._device()
     _agents_on(agents, dev)
     if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
@@ -400,33 +401,52 @@ def physics(scenery, agents, movement=None):
             raise RuntimeError('movement must be ((N, A) contiguous int64 actions, (K, 3) float32 table, keep)')
         _require_gpu(actions, table)
         mv = C.byref(_lib.MsMovement(actions.data_ptr(), table.data_ptr(), table.shape[0], float(keep)))
-    progress = torch.empty_like(agents.angles)
+    progress = torch.empty_like(agents.angles) if out is None else out.progress      # `out`: an earlier call's Physics
     with _on(dev):
         _lib.check(_lib.lib().ms_move_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
                                               mv, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
     agents._cached = agents._use_cache
-    return Physics(progress)
+    return Physics(progress) if out is None else out
 
 
 FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
 
 
-def render(scenery, agents, fields=None, pooled=None, telemetry=False):
+def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
 
-    Two extensions over the reference, both off by default: ``fields`` names the per-ray outputs that are wanted
+    Extensions over the reference, all off by default: ``fields`` names the per-ray outputs that are wanted
     (the others are neither written nor allocated), and ``pooled=dict(subsample=s, max_depth=d, rgb=True, depth=True)``
     has the kernel write the mean-pooled observations of ``modules.RGB`` / ``modules.Depth`` itself
-    (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s)). ``telemetry=True`` (tests) takes the
-    self-contained path whose scratch counters end up in ``Render._telemetry``."""
+    (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s)). ``out`` takes the :class:`Render` of an
+    earlier call with the same arguments and writes into its tensors instead of allocating (the reference allocates
+    five tensors per call, kernels.cu:461-469; a caller that consumes a frame before asking for the next need not).
+    ``telemetry=True`` (tests) takes the self-contained path whose scratch counters end up in ``Render._telemetry``."""
     dev = scenery._device()
     _agents_on(agents, dev)
     n, a = agents.angles.shape
     if (n, a) != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery')
     cfg = _cfg()
-    r = cfg.res
+    key = (n, a, cfg.res, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), dev)
+    if out is not None:
+        if getattr(out, '_key', None) != key:
+            raise RuntimeError('`out` must come from a render call with the same shapes, fields and pooling')
+        result = out
+    else:
+        result = _render_buffers(scenery, n, a, cfg.res, fields, pooled, dev)
+        result._key = key
+    with _on(dev):
+        use_cache = agents._cached and not telemetry
+        _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
+                                        C.byref(result._struct), C.byref(cfg), _stream(dev)))
+    return result
+
+
+def _render_buffers(scenery, n, a, r, fields, pooled, dev):
+    """One allocation for the wanted outputs (reference: five at::empty calls, kernels.cu:461-469), the pooled
+    observations and the kernels' scratch (MS_RENDER_WORKSPACE_INTS), and the MsRender that points into it."""
     want = FIELDS if fields is None else tuple(fields)
     if any(f not in FIELDS for f in want):
         raise RuntimeError(f'fields must be among {FIELDS}')
@@ -444,8 +464,6 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False):
         w = r//sub
         n_rgb = 3*n*a*w if pooled.get('rgb', True) else 0
         n_depth = n*a*w if pooled.get('depth', True) else 0
-    # One allocation for the wanted outputs (reference: five at::empty calls, kernels.cu:461-469), the pooled
-    # observations and the kernels' scratch (MS_RENDER_WORKSPACE_INTS), in words of 4 bytes.
     plane = n*a*r
     sizes = [plane*(3 if f == 'screen' else 1) if f in want else 0 for f in FIELDS] + [n_rgb, n_depth]
     sizes = [(x + 3) & ~3 for x in sizes]                                # keep every piece 16-byte aligned
@@ -460,11 +478,7 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False):
     if outs[0] is not None:
         outs[0] = outs[0].view(torch.int32)
     obs_rgb, obs_depth = piece(5, (n, a, 3, w)), piece(6, (n, a, w))
-    out = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth)
-    with _on(dev):
-        use_cache = agents._cached and not telemetry
-        _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
-                                        C.byref(out), C.byref(cfg), _stream(dev)))
     result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None)
+    result._struct = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth)
     result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel; read by the tests
     return result

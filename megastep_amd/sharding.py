@@ -8,22 +8,43 @@ import torch
 from . import cuda
 
 
-def env_slice(n_envs, rank, world_size):
-    """The contiguous ``[start, stop)`` slice of envs owned by ``rank``; sizes differ by at most one."""
+def env_slice(n_envs, rank, world_size, cost=None):
+    """The contiguous ``[start, stop)`` slice of envs owned by ``rank``.
+
+    Without ``cost`` sizes differ by at most one. With ``cost`` - a per-env weight, e.g. :func:`render_cost` - the cuts
+    sit where the running total crosses ``rank/world_size`` of the whole, so every rank carries the same share of the
+    work rather than of the envs (floorplans differ several-fold in wall count); every rank still gets at least one env."""
     if not (0 <= rank < world_size):
         raise ValueError(f'rank {rank} outside world of {world_size}')
-    base, extra = divmod(n_envs, world_size)
-    start = rank*base + min(rank, extra)
-    return start, start + base + (1 if rank < extra else 0)
+    if cost is None:
+        base, extra = divmod(n_envs, world_size)
+        start = rank*base + min(rank, extra)
+        return start, start + base + (1 if rank < extra else 0)
+    cost = torch.as_tensor(cost, dtype=torch.float64).reshape(-1).cpu()
+    if len(cost) != n_envs or n_envs < world_size or not bool((cost >= 0).all()):
+        raise ValueError('cost must hold one non-negative weight per env, and there must be an env per rank')
+    total = cost.cumsum(0)
+    # cut r: after the first env at which the running total reaches r/world_size of the whole
+    targets = total[-1]*torch.arange(1, world_size, dtype=torch.float64)/world_size
+    cuts = torch.searchsorted(total, targets).clamp(max=n_envs - 1) + 1
+    bounds = [0] + cuts.tolist() + [n_envs]
+    for r in range(1, world_size + 1):                      # at least one env each, in order
+        bounds[r] = min(max(bounds[r], bounds[r - 1] + 1), n_envs - (world_size - r))
+    return bounds[rank], bounds[rank + 1]
 
 
-def shard_scenery(scenery, rank, world_size, device=None):
+def render_cost(scenery, res):
+    """Per-env weight lines x agents x rays - what the raycast's work scales with."""
+    return scenery.lines.widths.double()*scenery.n_agents*res
+
+
+def shard_scenery(scenery, rank, world_size, device=None, cost=None):
     """The part of ``scenery`` that ``rank`` owns, as an independent :class:`~megastep_amd.cuda.Scenery` on ``device``.
 
     ``lights`` and ``lines`` are ragged per env and sliced by env; ``textures`` and ``baked`` are ragged per line and
     sliced by the env slice's line range (as ``Scenery.state`` does, reference: common.h:203-211). Baked lighting is
-    carried over, so a shard never needs re-baking."""
-    start, stop = env_slice(len(scenery.lines), rank, world_size)
+    carried over, so a shard never needs re-baking. ``cost``: see :func:`env_slice`."""
+    start, stop = env_slice(len(scenery.lines), rank, world_size, cost)
     device = scenery.model.device if device is None else device
     if stop == start:
         raise ValueError(f'rank {rank} of {world_size} would own no envs out of {len(scenery.lines)}')

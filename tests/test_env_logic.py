@@ -1,0 +1,164 @@
+"""The envs' own logic - who shoots whom, respawns, lifespans - against numpy restatements of the reference's formulas
+on synthetic inputs. Pure tensor logic over the hot path's outputs, so it runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+
+# ---- reference restatements (numpy) ---------------------------------------------------------------------------------
+
+def ref_observe_opponents(indices, n_model, n_agents, subsample):
+    """demo/envs/deathmatch.py:74-80 `_observe`: indices (F, A, 1, res) -> opponents (F, A, 1, res/subsample)."""
+    F, A, _, res = indices.shape
+    line_idxs = indices.reshape(F, A, 1, res//subsample, subsample)[..., subsample//2]
+    obj_idxs = line_idxs//n_model
+    mask = (0 <= line_idxs) & (obj_idxs < n_agents)
+    return np.where(mask, obj_idxs, -1)
+
+
+def ref_shoot(opponents, n_agents, positions, bounds, health, damage, clearance=1.):
+    """demo/envs/deathmatch.py:54-72 `_shoot`. Returns (matchings, hits, new health, new damage)."""
+    res = opponents.shape[-1]
+    middle = slice(res//2 - 1, res//2 + 1)
+    agents = np.arange(n_agents)
+    matchings = (opponents[:, :, None] == agents[None, None, :, None, None])[..., middle].any(-1).any(-1)
+    hits = matchings.sum(2).astype(np.float32)
+    wounds = matchings.sum(1).astype(np.float32)
+    damage = damage + np.float32(.05)*hits
+    outside = (positions < -clearance).any(-1) | (positions > (bounds[:, None] + clearance)).any(-1)
+    health = health + np.float32(-.05)*(wounds + outside) - np.float32(.001)
+    return matchings, hits.reshape(-1), health, damage
+
+
+# ---- Deathmatch -----------------------------------------------------------------------------------------------------
+
+def _synthetic_indices(rng, F, A, M, res):
+    idx = rng.randint(A*M, A*M + 300, (F, A, 1, res))                    # walls
+    idx[rng.uniform(size=idx.shape) < .1] = -1                           # misses
+    agent_hit = rng.uniform(size=idx.shape) < .35
+    idx[agent_hit] = rng.randint(0, A*M, agent_hit.sum())                # agent lines, own included
+    return idx.astype(np.int32)
+
+
+@pytest.mark.parametrize('A,res,sub', [(4, 512, 4), (2, 64, 1), (3, 128, 8), (6, 32, 2)])
+def test_crosshair_matrix_is_the_reference_matching(A, res, sub):
+    from megastep_amd.demo.envs import deathmatch
+    rng = np.random.RandomState(A*res + sub)
+    M, F = 8, 50
+    idx = _synthetic_indices(rng, F, A, M, res)
+    got = deathmatch.crosshair_matrix(torch.as_tensor(idx), M, A, sub).numpy()
+    opp = ref_observe_opponents(idx, M, A, sub)
+    want = ref_shoot(opp, A, np.zeros((F, A, 2), np.float32), np.ones((F, 2), np.float32),
+                     np.ones((F, A), np.float32), np.zeros((F, A), np.float32))[0]
+    np.testing.assert_array_equal(got, want)
+    assert want.any() and not want.all()
+
+
+def test_exchange_fire_is_the_reference_shoot():
+    """health, damage and reward after a frame: `_exchange_fire` against deathmatch.py:54-72 on synthetic hit lines,
+    with some agents strayed outside their floorplan."""
+    from megastep_amd import core, scene, toys, modules
+    from megastep_amd.demo.envs import deathmatch
+    rng = np.random.RandomState(0)
+    F, A, res, sub = 20, 4, 512, 4
+    sc = scene.scenery(F*[toys.box()], A, device='cpu', bake=False)
+    env = deathmatch.Deathmatch.__new__(deathmatch.Deathmatch)          # the pieces _exchange_fire touches, no GPU
+    env.core = core.Core(sc, res=res, fov=70)
+    env._rgb = modules.RGB(env.core, n_agents=1, subsample=sub)
+    bounds = rng.uniform(5, 10, (F, 2)).astype(np.float32)
+    env._bounds = torch.as_tensor(bounds)
+    pos = rng.uniform(-2, 12, (F, A, 2)).astype(np.float32)
+    env.core.agents.positions[:] = torch.as_tensor(pos)
+    health, damage = rng.uniform(0, 1, (F, A)).astype(np.float32), rng.uniform(0, 1, (F, A)).astype(np.float32)
+    env._health, env._damage = torch.as_tensor(health.copy()), torch.as_tensor(damage.copy())
+    idx = _synthetic_indices(rng, F, A, 8, res)
+    reward = env._exchange_fire(torch.as_tensor(idx)[..., :])
+    opp = ref_observe_opponents(idx, 8, A, sub)
+    matchings, hits, want_health, want_damage = ref_shoot(opp, A, pos, bounds, health, damage)
+    np.testing.assert_array_equal(env.matchings.numpy(), matchings)
+    np.testing.assert_array_equal(reward.numpy(), hits)
+    np.testing.assert_allclose(env._health.numpy(), want_health, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(env._damage.numpy(), want_damage, rtol=0, atol=1e-6)
+    assert ((pos < -1).any(-1) | (pos > bounds[:, None] + 1).any(-1)).any()
+
+
+# ---- RandomSpawns ---------------------------------------------------------------------------------------------------
+
+def test_random_spawns_touch_only_the_reset_agents():
+    """modules.py:312-326: reset agents get a pose from THEIR row of the spawn table and zero velocities; everyone else
+    is left exactly as they were. The reference draws the spawn index below ``spawns.angles.shape[1]`` (modules.py:321)
+    - which is the number of AGENTS, not of spawn points - so the choice is uniform over the first ``n_agents`` entries
+    of the table; a drop-in keeps that."""
+    from megastep_amd import core, scene, cubicasa, modules
+    np.random.seed(0); torch.manual_seed(0)
+    geoms = cubicasa.sample(6, n_unique=16)
+    c = core.Core(scene.scenery(geoms, 3, device='cpu', bake=False))
+    spawner = modules.RandomSpawns(geoms, c, n_spawns=20)
+    table_p, table_a = spawner._spawns.positions.numpy(), spawner._spawns.angles.numpy()
+    rng = np.random.RandomState(1)
+    counts = np.zeros(20)
+    for trial in range(200):
+        before = {k: torch.as_tensor(rng.normal(size=getattr(c.agents, k).shape).astype(np.float32)) for k in
+                  ('angles', 'positions', 'velocity', 'angvelocity')}
+        for k, v in before.items():
+            getattr(c.agents, k)[:] = v
+        reset = torch.as_tensor(rng.uniform(size=(6, 3)) < .4)
+        spawner(reset)
+        m = reset.numpy()
+        for k, v in before.items():
+            np.testing.assert_array_equal(getattr(c.agents, k).numpy()[~m], v.numpy()[~m], err_msg=k)   # untouched
+        assert (c.agents.velocity.numpy()[m] == 0).all() and (c.agents.angvelocity.numpy()[m] == 0).all()
+        for e, a in zip(*np.nonzero(m)):
+            which = np.flatnonzero((table_p[e, a] == c.agents.positions.numpy()[e, a]).all(-1)
+                                   & (table_a[e, a] == c.agents.angles.numpy()[e, a]))
+            assert len(which) >= 1, 'pose is not from this agent\'s spawn table'
+            counts[which[0]] += 1
+    assert (counts[3:] == 0).all() and counts[:3].min() > .8*counts[:3].mean()      # uniform over the first n_agents = 3
+
+
+def test_random_spawn_tables_hold_free_cells_of_their_own_geometry():
+    from megastep_amd import core, scene, cubicasa, modules, geometry
+    np.random.seed(0); torch.manual_seed(0)
+    geoms = cubicasa.sample(4, n_unique=16)
+    geoms = [geoms[0], geoms[1], geoms[0], geoms[2], geoms[3]]
+    c = core.Core(scene.scenery(geoms, 2, device='cpu', bake=False))
+    for fast in (False, True):
+        spawner = modules.RandomSpawns(geoms, c, n_spawns=50, fast=fast)
+        assert spawner._spawns.positions.shape == (5, 2, 50, 2) and spawner._spawns.angles.shape == (5, 2, 50)
+        assert spawner._spawns.angles.abs().max() <= 180
+        for e, g in enumerate(geoms):
+            pts = spawner._spawns.positions[e].reshape(-1, 2).numpy().astype(float)
+            ij = geometry.indices(pts, g['masks'].shape, g['res'])
+            assert (g['masks'][ij[:, 0], ij[:, 1]] > 0).all(), (fast, e)
+
+
+# ---- RandomLifespans ------------------------------------------------------------------------------------------------
+
+def test_random_lifespans_follow_the_reference_rules():
+    """modules.py:361-366: every call ages everyone by one step; those that reached their maximum - or are reset from
+    outside - are flagged, start again at zero and get a fresh maximum in [min, max)."""
+    from megastep_amd import core, scene, toys, modules
+    torch.manual_seed(0)
+    c = core.Core(scene.scenery(32*[toys.box()], 3, device='cpu', bake=False))
+    life = modules.RandomLifespans(c, max_lifespan=12)                   # min defaults to 6
+    assert life.min_lifespan == 6 and life.max_lifespan == 12
+    age, limit = np.zeros((32, 3), np.int64), life._max_lifespans.numpy().copy()
+    assert ((limit >= 6) & (limit < 12)).all() and len(np.unique(limit)) > 3
+    rng = np.random.RandomState(0)
+    flagged = 0
+    for step in range(60):
+        outside = torch.as_tensor(rng.uniform(size=(32, 3)) < .05) if step % 3 == 0 else None
+        got = life(outside).numpy()
+        age += 1
+        want = (age >= limit) | (outside.numpy() if outside is not None else False)
+        np.testing.assert_array_equal(got, want)
+        age[want] = 0
+        np.testing.assert_array_equal(life._lifespans.numpy(), age)
+        fresh = life._max_lifespans.numpy()
+        np.testing.assert_array_equal(fresh[~want], limit[~want])       # maxima only change on a reset
+        assert ((fresh >= 6) & (fresh < 12)).all()
+        limit = fresh.copy()
+        flagged += want.sum()
+    assert flagged > 100
+    st = life.state(3)
+    assert st.lifespan.shape == (3,) and st.max_lifespans.shape == (3,)

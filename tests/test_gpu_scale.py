@@ -1,0 +1,148 @@
+"""GPU parity at the benchmark's full sizes (BASELINE.json configs C2, C3 and the per-GPU shape of C5) and of the world
+build / bake that get a GPU there: the HIP path runs the whole batch, the oracle a sample of its envs."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _big_world(n_envs, n_agents, res, fov, n_distinct, large=False, fast=True, seed=0):
+    from megastep_amd import core, cubicasa, modules, scene
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    pool = cubicasa.sample(n_distinct, n_unique=max(n_distinct, 16), seed=seed + 1, large=large)
+    geometries = [pool[i % len(pool)] for i in range(n_envs)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scenery = scene.scenery(geometries, n_agents, device='cuda', random=np.random.RandomState(seed), fast=fast, bake=False)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    from megastep_amd import cuda
+    t0 = time.perf_counter()
+    cuda.bake(scenery)
+    torch.cuda.synchronize()
+    t_bake = time.perf_counter() - t0
+    c = core.Core(scenery, res=res, fov=fov, fps=10)
+    t0 = time.perf_counter()
+    spawner = modules.RandomSpawns(geometries, c, fast=fast)
+    spawner(c.agent_full(True))
+    torch.cuda.synchronize()
+    t_spawn = time.perf_counter() - t0
+    return c, geometries, dict(build=t_build, bake=t_bake, spawn=t_spawn)
+
+
+def _check_sample(c, envs, steps=2, seed=3):
+    from megastep_amd import cuda
+    sub = util.OracleSubset(c, envs)
+    want = sub.bake()
+    got = c.scenery.baked.vals[sub.texel_rows].cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5, err_msg='baked')
+    rng = np.random.RandomState(seed)
+    for step in range(steps):
+        util.random_velocities(c, rng, speed=4. if step % 2 else 30.)
+        sub.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        util.assert_subset_matches(c, sub, p, r)
+    return float((got == want).mean())
+
+
+def test_c2_explorer_shape_full_size():
+    """C2: 4096 envs x 1 agent x 64 rays (512 distinct floorplans: generating them is what takes time here)."""
+    c, _, t = _big_world(4096, 1, 64, 130, n_distinct=512, fast=True)
+    exact = _check_sample(c, [0, 1, 1023, 1024, 2500, 4095])
+    print('C2 timings (s):', t, 'baked bitwise-equal fraction:', exact)
+
+
+def test_c3_deathmatch_shape_full_size():
+    """C3: 4096 envs x 4 agents x 128 rays, floorplans tiled n/4 as Deathmatch does (deathmatch.py:24)."""
+    c, _, t = _big_world(4096, 4, 128, 70, n_distinct=512, fast=True)
+    assert c.scenery.geom is not None and int((c.scenery.geom == torch.arange(4096, device='cuda')).sum()) == 512
+    exact = _check_sample(c, [0, 5, 512, 3000, 4095])
+    print('C3 timings (s):', t, 'baked bitwise-equal fraction:', exact)
+
+
+def test_c5_per_gpu_shape_full_size():
+    """C5's per-GPU share: 32768 envs x 1 agent x 256 rays on large (800-1200 wall) maps. The world has to build in
+    seconds and bake in under a second for this point to be usable at all."""
+    c, _, t = _big_world(32768, 1, 256, 130, n_distinct=64, large=True, fast=True)
+    print('C5 timings (s):', t, 'lines', c.scenery.lines.vals.shape[0], 'texels', c.scenery.textures.vals.shape[0])
+    assert t['build'] < 10 and t['bake'] < 1 and t['spawn'] < 5, t
+    exact = _check_sample(c, [0, 63, 64, 20000, 32767], steps=2)
+    print('C5 baked bitwise-equal fraction:', exact)
+
+
+@pytest.mark.parametrize('n_agents', [1, 3])
+def test_bake_paths_agree(n_agents, monkeypatch):
+    """The two-phase bake (with and without the angular bins) and the one-pass kernel against the oracle and each
+    other - on a scenery whose envs share floorplans but not light intensities, with agents parked in different
+    places (the agent lines' own texels are baked where the agents stand, kernels.cu:277-281)."""
+    from megastep_amd import core, cubicasa, cuda, scene, toys
+    np.random.seed(5)
+    pool = cubicasa.sample(3, n_unique=16, seed=2) + [toys.box(), toys.column()]
+    geoms = [pool[i] for i in (0, 1, 0, 3, 2, 1, 4, 0, 3)]
+    sc = scene.scenery(geoms, n_agents, device='cuda', random=np.random.RandomState(5), bake=False)
+    assert sc.geom.tolist() == [0, 1, 0, 3, 4, 1, 6, 0, 3]
+    c = core.Core(sc, res=32, fov=110)
+    util.spawn(c, geoms, seed=1)
+    cuda.render(sc, c.agents)                     # moves the agent lines to where the agents are
+    ref = util.OracleWorld(c)
+    want = ref.bake()
+    results = {}
+    for name, kwargs, bins in [('two-phase', {}, '1'), ('two-phase, no bins', {}, '0'), ('one-pass', dict(scratch=False), '1')]:
+        monkeypatch.setenv('MEGASTEP_BAKE_BINS', bins)
+        sc.baked.vals.fill_(-1.)
+        cuda.bake(sc, **kwargs)
+        results[name] = sc.baked.vals.cpu().numpy()
+        np.testing.assert_allclose(results[name], want, rtol=0, atol=1e-5, err_msg=name)
+    for name, got in results.items():
+        np.testing.assert_array_equal(got, results['one-pass'], err_msg=f'{name} vs one-pass')
+    # envs of one floorplan are lit differently (their own intensities), so the sharing is not a copy
+    t = sc.textures
+    env_texels = lambda e: slice(int(t.starts[int(sc.lines.starts[e])]), int(t.ends[int(sc.lines.ends[e]) - 1]))
+    assert not np.array_equal(want[env_texels(0)], want[env_texels(2)])
+
+
+def test_bake_more_walls_than_fit_in_lds_and_many_lights():
+    """> 2048 walls (the visibility kernel's staging passes accumulate) and > 64 lights (more than one mask word)."""
+    from megastep_amd import arrdict, core, cuda, scene
+    rng = np.random.RandomState(0)
+    n = 2300
+    a = rng.uniform(1, 30, (n, 2))
+    walls = np.stack([a, a + rng.normal(size=(n, 2))*.4], 1)
+    lights = rng.uniform(1, 30, (70, 2))
+    g = arrdict.arrdict(walls=walls, lights=lights, masks=np.ones((4, 4), np.int16), res=.2)
+    np.random.seed(0)
+    sc = scene.scenery([g, g], 1, device='cuda', random=np.random.RandomState(0), bake=True)
+    c = core.Core(sc, res=16)
+    want = util.OracleWorld(c).bake()
+    np.testing.assert_allclose(sc.baked.vals.cpu().numpy(), want, rtol=0, atol=1e-5)
+
+
+def test_crawling_agents_meet_far_walls_like_the_reference():
+    """project() divides by (|v| + 1e-6) (kernels.cu:91-107): for |v| below ~1e-6 per step its distances shrink until
+    endpoints metres away pass `d < r` and the reference stops the agent. The reach cull must not hide those walls."""
+    from megastep_amd import core, cuda, scene, toys
+    sc = scene.scenery(64*[toys.box()], 1, device='cuda')
+    c = core.Core(sc, res=8, fps=10)
+    rng = np.random.RandomState(0)
+    pos = rng.uniform(1.5, 5.5, (64, 1, 2)).astype(np.float32)
+    pos[0] = [5., 5.]
+    speed = 10.**rng.uniform(-9, -2, (64, 1, 1))
+    ang = rng.uniform(0, 2*np.pi, (64, 1, 1))
+    vel = (10*speed*np.concatenate([np.cos(ang), np.sin(ang)], -1)).astype(np.float32)      # v/fps = speed
+    vel[0] = [1e-6, 0.]
+    c.agents.positions[:] = torch.as_tensor(pos, device='cuda')
+    c.agents.velocity[:] = torch.as_tensor(vel, device='cuda')
+    ref = util.OracleWorld(c)
+    p = cuda.physics(c.scenery, c.agents)
+    prog_ref, agents_ref = ref.physics()
+    assert prog_ref[0, 0] == 0., 'the reference stops this one (ADVICE r1)'
+    assert (prog_ref < 1).sum() > 5
+    util.assert_physics_matches(c, p, prog_ref, agents_ref)
+    np.testing.assert_array_equal(p.progress.cpu().numpy(), prog_ref)

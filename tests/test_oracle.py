@@ -218,3 +218,49 @@ def test_render_against_the_reference_docs_image(oracle):
     shown = core.gamma_encode(r['screen'][0, 0].astype(np.float64))
     cos = (shown*cols).sum(1)/np.linalg.norm(shown, axis=1)/np.linalg.norm(cols, axis=1)
     assert cos.min() > .999, cos.min()                     # hue of every column = the reference's, to 8-bit rounding
+
+
+@pytest.mark.parametrize('n_agents,res,fov', [(1, 32, 130), (3, 64, 70)])
+def test_pure_pytorch_step_matches_the_c_oracle(oracle, n_agents, res, fov):
+    """oracle/torch_step.py (bench.py's pure-PyTorch CPU baseline) against the C restatement: same collision masks and
+    hit indices, floats within 1e-5, over a few steps with agents meeting walls and each other."""
+    import torch
+    from oracle import torch_step
+    from megastep_amd import core, cubicasa, scene
+    from tests import util
+    np.random.seed(0)
+    geoms = cubicasa.sample(5, n_unique=16)
+    sc = scene.scenery(geoms, n_agents, device='cpu', random=np.random.RandomState(0), bake=False)
+    c = core.Core(sc, res=res, fov=fov)
+    util.spawn(c, geoms, seed=2)
+    if n_agents > 1:                                       # two agents face to face so that rays land on an agent
+        c.agents.positions[0, 1] = c.agents.positions[0, 0] + torch.tensor([.6, 0.])
+        c.agents.angles[0, 0], c.agents.angles[0, 1] = 0., 180.
+    ref = util.OracleWorld(c)
+    ref.bake()
+    world = torch_step.World({k: getattr(ref.scene, k) for k in
+                              ('n_agents', 'model', 'lines_vals', 'lines_widths', 'lights_vals', 'lights_widths',
+                               'textures_vals', 'textures_widths', 'baked_vals')}, c.agent_radius, res, fov, c.fps)
+    rng = np.random.RandomState(1)
+    dyn = 0
+    for step in range(3):
+        util.random_velocities(c, rng, speed=3. if step else 0.)
+        ref.pull_agents(c)
+        agents = {k: torch.as_tensor(v.copy()) for k, v in ref.agents.items()}
+        progress, frame = torch_step.step(world, agents)
+        want_p, want_agents = ref.physics()
+        want = ref.render()
+        np.testing.assert_array_equal(progress.numpy() < 1, want_p < 1)
+        np.testing.assert_allclose(progress.numpy(), want_p, rtol=0, atol=1e-5)
+        for k in ('positions', 'velocity', 'angvelocity'):
+            np.testing.assert_allclose(agents[k].numpy(), want_agents[k], rtol=0, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(agents['angles'].numpy(), want_agents['angles'], rtol=0, atol=2e-5)
+        np.testing.assert_array_equal(frame['indices'].numpy(), want['indices'])
+        hit = want['indices'] >= 0
+        for k in ('locations', 'dots', 'distances'):
+            np.testing.assert_allclose(frame[k].numpy()[hit], want[k][hit], rtol=0, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(frame['screen'].numpy(), want['screen'], rtol=0, atol=1e-5)
+        dyn += int(((want['indices'] >= 0) & (want['indices'] < 8*n_agents)).sum())
+        for k in ('angles', 'positions', 'velocity', 'angvelocity'):           # carry on from the oracle's state
+            getattr(c.agents, k)[:] = torch.as_tensor(want_agents[k])
+    assert n_agents == 1 or dyn > 0

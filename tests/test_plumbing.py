@@ -255,3 +255,28 @@ def test_shards_of_sceneries_with_shared_floorplans():
     pool_ = torch.zeros(1, dtype=torch.int32)
     v, s, g, cell, mx, l, p = sharding._shard_light_grid((vals, starts, grid, .25, 6, lists, pool_), 4, 7, 'cpu', shard.geom)
     assert s.tolist() == [0, 0, 4] and torch.equal(v, torch.cat([vals[6:10], vals[0:6]])) and torch.equal(g, grid[4:7])
+
+
+def test_cost_balanced_env_slices():
+    """Slices balanced by work (lines x agents x rays) instead of env count: contiguous, complete, non-empty, and no
+    rank carries much more than its share."""
+    rng = np.random.RandomState(0)
+    for world in (2, 3, 8):
+        cost = rng.randint(150, 1200, 4096).astype(float)
+        slices = [sharding.env_slice(4096, r, world, cost) for r in range(world)]
+        assert slices[0][0] == 0 and slices[-1][1] == 4096
+        assert all(a[1] == b[0] for a, b in zip(slices, slices[1:])) and all(b > a for a, b in slices)
+        loads = np.array([cost[a:b].sum() for a, b in slices])
+        assert loads.max() <= cost.sum()/world + cost.max()
+        by_count = np.array([cost[a:b].sum() for a, b in (sharding.env_slice(4096, r, world) for r in range(world))])
+        assert loads.max() <= by_count.max() + cost.max()
+    # degenerate weights still give every rank an env
+    assert [sharding.env_slice(4, r, 4, [0, 0, 0, 9]) for r in range(4)] == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    assert [sharding.env_slice(5, r, 2, [9, 0, 0, 0, 0]) for r in range(2)] == [(0, 1), (1, 5)]
+    with pytest.raises(ValueError):
+        sharding.env_slice(3, 0, 4, [1, 1, 1])
+    sc = scene.scenery(cubicasa.sample(6, n_unique=16), 2, device='cpu', bake=False)
+    cost = sharding.render_cost(sc, 64)
+    assert cost.tolist() == (sc.lines.widths.double()*2*64).tolist()
+    parts = [sharding.shard_scenery(sc, r, 2, cost=cost) for r in range(2)]
+    assert sum(len(p.lines) for p in parts) == 6

@@ -116,3 +116,70 @@ def scenery_by_the_book(geometries, n_agents, random=np.random):
         lights_vals=np.concatenate(lights).astype(np.float32), lights_widths=np.array([len(x) for x in lights], np.int32),
         lines_vals=np.concatenate(lines).astype(np.float32), lines_widths=np.array([len(x) for x in lines], np.int32),
         textures_vals=np.concatenate(texels).astype(np.float32), textures_widths=np.concatenate(counts).astype(np.int32))
+
+
+class OracleSubset:
+    """The oracle's copy of a few envs of a (large) Core: what the full-size tests compare a sample against."""
+
+    def __init__(self, core, envs):
+        sc = core.scenery
+        self.envs = np.asarray(envs)
+        e = torch.as_tensor(self.envs, device=core.device)
+        ln, li, tx = sc.lines, sc.lights, sc.textures
+        rows = lambda r, which: torch.cat([torch.arange(int(r.starts[i]), int(r.ends[i]), device=core.device) for i in which]) \
+            if len(which) else torch.zeros(0, dtype=torch.long, device=core.device)
+        self.line_rows = rows(ln, self.envs)
+        light_rows = rows(li, self.envs)
+        tstart, tend = tx.starts.long()[self.line_rows], tx.ends.long()[self.line_rows]
+        self.texel_rows = torch.cat([torch.arange(int(a), int(b), device=core.device) for a, b in
+                                     zip(tx.starts.long()[ln.starts.long()[e]].tolist(), tx.ends.long()[ln.ends.long()[e] - 1].tolist())])
+        assert int((tend - tstart).sum()) == len(self.texel_rows)
+        n = lambda t: t.detach().cpu().numpy().copy()
+        self.scene = O.Scene(dict(
+            n_agents=sc.n_agents, model=n(sc.model),
+            lights_vals=n(li.vals[light_rows]), lights_widths=n(li.widths[e]),
+            lines_vals=n(ln.vals[self.line_rows]), lines_widths=n(ln.widths[e]),
+            textures_vals=n(tx.vals[self.texel_rows]), textures_widths=n(tx.widths[self.line_rows]),
+            baked_vals=n(sc.baked.vals[self.texel_rows])))
+        self.cfg = O.config(core.agent_radius, core.res, core.fov, core.fps)
+        self.pull_agents(core)
+
+    def pull_agents(self, core):
+        self.agents = {k: v[self.envs] for k, v in agents_dict(core.agents).items()}
+
+    def bake(self):
+        return O.bake(self.scene, self.cfg).copy()
+
+    def physics(self):
+        progress, self.agents = O.physics(self.scene, self.agents, self.cfg)
+        return progress, self.agents
+
+    def render(self):
+        return O.render(self.scene, self.agents, self.cfg)
+
+
+class _Rows:
+    """A Core-like view of a few envs of a step's results, for the assert_* helpers above."""
+
+    def __init__(self, core, envs):
+        class A:
+            pass
+        self.agents = A()
+        for k in ('angles', 'positions', 'angvelocity', 'velocity'):
+            setattr(self.agents, k, getattr(core.agents, k)[envs])
+
+
+def assert_subset_matches(core, sub, p, r):
+    """Physics and render results of the full batch, at the sampled envs, against the oracle."""
+    e = torch.as_tensor(sub.envs, device=core.device)
+    prog_ref, agents_ref = sub.physics()
+
+    class P:
+        progress = p.progress[e]
+    assert_physics_matches(_Rows(core, e), P, prog_ref, agents_ref)
+
+    class R:
+        pass
+    for k in ('indices', 'locations', 'dots', 'distances', 'screen'):
+        setattr(R, k, getattr(r, k)[e])
+    assert_render_matches(None, R, sub.render())

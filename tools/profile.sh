@@ -1,19 +1,22 @@
 #!/bin/bash
-# Collects the round's rocprofv3 evidence into gpurun_out/prof_$1/: kernel-trace stats of the default bench command,
-# then HBM traffic counters in separate PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
+# Collects the round's rocprofv3 evidence into gpurun_out/prof_$1/: kernel-trace stats of the default bench command
+# (eager + graph legs), then HBM traffic counters in separate PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass
+# on gfx950) and an SQ counter set, each on the eager leg only.
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline > $out/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $out/sq -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_sq.log 2>&1
+lean="--no-cpu-baseline --no-env-fps"
+rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python bench.py --steps 100 --warmup 10 $lean > $out/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $out/sq -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_sq.log 2>&1
 python - <<PY
 import pandas as pd, json
 out='$out'
 st = pd.read_csv(f'{out}/stats/bench_kernel_stats.csv')
-st = st[st.Name.str.contains('render_kernel|render_prep|physics_kernel|dynlight|bake_kernel|lightgrid|lightlist')]
+st = st[st.Name.str.contains('render_kernel|render_prep|physics_kernel|dynlight|bake_kernel|bake_sum|visibility|lightgrid|lightlist')]
 print(st[['Name','Calls','AverageNs','MinNs','MaxNs']].to_string())
+st.to_csv(f'{out}/kernel_stats.csv', index=False)
 res = {}
 for c, f in [('FETCH_SIZE','fetch'),('WRITE_SIZE','write')]:
     d = pd.read_csv(f'{out}/{f}/bench_counter_collection.csv')
@@ -22,17 +25,18 @@ for c, f in [('FETCH_SIZE','fetch'),('WRITE_SIZE','write')]:
     res[c] = g.to_dict(); print(c, '(KB per launch, raw counter)', g.round(0).to_dict())
 json.dump(res, open(f'{out}/traffic_raw.json','w'))
 # HBM bytes per ms_render launch: FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide
-# coalesced read; calibrated on physics_kernel's 16 B/lane wall stream), WRITE_SIZE (KB) as reported.
+# coalesced read; calibrated here on physics_kernel's 16 B/lane wall stream), WRITE_SIZE (KB) as reported.
 rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) for k in ('render_kernel', 'render_prep_kernel', 'dynlight_kernel'))
 pb = 2*1024*res['FETCH_SIZE'].get('physics_kernel', 0) + 1024*res['WRITE_SIZE'].get('physics_kernel', 0)
 json.dump({'workload': {'envs': 4096, 'agents': 4, 'res': 64, 'large': False},
            'render_bytes_per_launch': rb, 'physics_bytes_per_launch': pb, 'raw_counters_KB': res,
-           'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'},
+           'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'},
           open(f'{out}/traffic.json','w'), indent=1)
 sq = pd.read_csv(f'{out}/sq/bench_counter_collection.csv')
 sq['k'] = sq.Kernel_Name.str.extract(r'(render_kernel|render_prep_kernel|physics_kernel|dynlight_kernel)')
 g = sq[sq.k.notna()].groupby(['k','Counter_Name']).Counter_Value.mean().unstack()
+g['VALU_per_wave'] = g.SQ_INSTS_VALU/g.SQ_WAVES; g['SALU_per_wave'] = g.SQ_INSTS_SALU/g.SQ_WAVES; g['LDS_per_wave'] = g.SQ_INSTS_LDS/g.SQ_WAVES
 g.to_csv(f'{out}/sq_counters_mean_per_launch.csv')
 print(g.round(0).to_string())
 PY
-tail -1 $out/bench_stats.log | cut -c1-400
+tail -1 $out/bench_stats.log | cut -c1-600
