@@ -40,6 +40,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (stdout carries the one JSON line)."""
+    if int(os.environ.get('RANK', 0)) == 0:
+        print(f'[bench {time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
 def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False):
@@ -113,11 +120,17 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
 
     out = {}
     np.random.seed(0); torch.manual_seed(0)
-    eager, graphed = rate(Explorer(n_core_envs, device=device, geometries=geometries), n_core_envs)
+    env = Explorer(n_core_envs, device=device, geometries=geometries)
+    log('Explorer built')
+    eager, graphed = rate(env, n_core_envs)
+    log('Explorer timed')
+    del env
     out['explorer'] = {'fps': eager, 'fps_hip_graph': graphed,
                        'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU'}
     torch.cuda.empty_cache()
-    eager, graphed = rate(Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries), 4*n_core_envs)
+    env = Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries)
+    log('Deathmatch built')
+    eager, graphed = rate(env, 4*n_core_envs)
     out['deathmatch'] = {'fps': eager, 'fps_hip_graph': graphed,
                          'env': f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU'}
     return out
@@ -180,6 +193,7 @@ def cpu_baselines(core, budget_s=8.):
         dt = time.perf_counter() - t0
         if dt > budget_s or steps >= 50:
             break
+    log(f'pure-PyTorch CPU step: {steps} steps of {n} envs in {dt:.1f}s')
     out['cpu_baseline'] = {
         'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'implementation': 'pure PyTorch (CPU tensors)',
         'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/torch_step.py, torch.set_num_threads({cores})'}
@@ -292,6 +306,10 @@ def main(argv=None):
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     distributed = world > 1
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get('BENCH_WATCHDOG_S'):       # where is it, if it is still running by then?
+        faulthandler.dump_traceback_later(float(os.environ['BENCH_WATCHDOG_S']), repeat=True)
     dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank)
     device = dev.device
     if distributed:
@@ -308,6 +326,7 @@ def main(argv=None):
                           rank=rank, world=world, bake=not args.dry_run_cpu, fast=args.fast_build)
     N, A = core.n_envs, core.n_agents
     total = args.steps + args.warmup
+    log(f'world built: {N} envs on this rank')
 
     # pre-generated random momentum actions -> per-step velocity targets, resident in HBM
     torch.manual_seed(rank)
@@ -350,6 +369,7 @@ def main(argv=None):
             events[i][0].record()
             hot(views[args.warmup + i], events[i])
     eager_s = timed(eager)
+    log(f'eager leg: {1e3*eager_s/args.steps:.4f} ms/step')
     step_ms = np.array([e[0].elapsed_time(e[2]) for e in events])
     render_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
 
@@ -359,6 +379,7 @@ def main(argv=None):
         replay = dev.graph(lambda: [hot(views[args.warmup + i]) for i in range(args.steps)])
         replay()                                                       # (instantiation / first-launch costs stay outside)
         graph_s = timed(replay)
+        log(f'graph leg: {1e3*graph_s/args.steps:.4f} ms/step')
 
     elapsed = graph_s if graph_s is not None else eager_s
     n_total = N
@@ -397,10 +418,12 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.dry_run_cpu:
         if not args.no_cpu_baseline:
             out.update(cpu_baselines(core))
+            log('cpu baselines done')
         if not args.no_env_fps:
             del core, scenery, agents, views, hot
             torch.cuda.empty_cache()
             out['env_step'] = env_step_fps(device)
+            log('env-step rates done')
     if rank == 0:
         print(json.dumps(out), flush=True)
     if distributed:

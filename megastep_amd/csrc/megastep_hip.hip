@@ -703,12 +703,13 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     //   3584 info   (64 x 4 B)   per line: (first pair << 6) | first ray
     //   3840 mark   (64 x 4 B)   pair window: which line starts here
     //   4096 screen (192 x 4 B)  RGB staging
-    constexpr int LDS_PER_WAVE = 4864;
+    // IMPL 2 lays its block out differently (see there): 5376 B
+    constexpr int LDS_PER_WAVE = IMPL == 2 ? 5376 : 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);
-    float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][4096]);
+    float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][IMPL == 2 ? 0 : 4096]);   // (IMPL 2: the raycast is over by then)
 
     // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
     // logical blocks so the fans of one env (and its lines) stay behind one L2.
@@ -968,6 +969,227 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+            }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+        } else if (amb) {
+            float x = INFINITY;
+            int xi = -1;
+            for (int c0 = 0; c0 < L; c0 += WAVE) {
+                const int l = c0 + lane;
+                float pqx = 0.f, pqy = 0.f, vx = 0.f, vy = 0.f;
+                float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c0 < AF) aw = agent_line(l);
+                if (l < L) {
+                    const float4 w = (l < AF) ? aw : ln[l];
+                    pqx = w.x - pp.x; pqy = w.y - pp.y; vx = w.z - w.x; vy = w.w - w.y;
+                }
+                for (unsigned long long todo = amb; todo; todo &= todo - 1) {
+                    const int jr = __ffsll((long long)todo) - 1;
+                    const float jrx = readlane_f(rx, jr), jry = readlane_f(ry, jr), jnear = readlane_f(near, jr);
+                    const float d = jrx*vy - jry*vx;
+                    const float nt = pqx*jry - pqy*jrx;
+                    const float ad = fabsf(d);
+                    const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                    bool valid = false;
+                    float sv = 0.f;
+                    if ((l < L) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                        sv = (pqx*vy - pqy*vx)/d;
+                        valid = jnear < sv;
+                    }
+                    unsigned long long m = __ballot(valid);
+                    if (m) {
+                        float xs = readlane_f(x, jr);
+                        int xis = __builtin_amdgcn_readlane(xi, jr);
+                        for (; m; m &= m - 1) {
+                            const int j = __ffsll((long long)m) - 1;
+                            const float sj = readlane_f(sv, j);
+                            if (sj < xs - 1.e-4f) { xs = sj; xis = c0 + j; }
+                        }
+                        if (lane == jr) { x = xs; xi = xis; }
+                    }
+                }
+            }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+        }
+    } else if constexpr (IMPL == 2) {
+        // ------------------------------------------------------------------------------------------
+        // (line, ray) pairs, second edition.  Same idea as IMPL 1 - pass 1 (lane = line) gives every line a
+        // conservative integer interval of this wave's rays, pass 2 deals the (line, ray) pairs to the lanes - but
+        //  * the lines that can be seen at all (about a third) are COMPACTED into an LDS list as the chunks go by,
+        //    and pass 2 runs over the list when it fills up or the lines run out: full 64-pair windows instead of
+        //    a ragged last window per chunk;
+        //  * a line marks the bit of its first pair in an LDS bit vector; a window's 64 mark bits M are one
+        //    broadcast read, and the line that owns pair q of the window is (#marks before the window) +
+        //    popcount(M & bits 0..q) - 1: two mbcnt instructions instead of a marks array and a DPP max-scan;
+        //  * ONE 64-bit LDS atomicMin per hit.  Its return value is the ray's previous best, so the lane sees the
+        //    loser of that merge; if the loser is not clearly behind the winner (not `winner < loser - 1e-4f`, the
+        //    reference's comparison) the ray is flagged.  For an unflagged ray every hit k other than the final
+        //    minimum b met, at the moment the later of the two arrived, either b itself or something no farther
+        //    than k as the other party, so s_b < s_k - 1e-4f for all k: the fold takes b when it reaches it (its
+        //    state is inf or some s_k) and nothing after b can pass `s < s_b - 1e-4f`.  Flagged rays (a ray
+        //    through a shared wall corner, coincident walls) take the literal sequential fold below.
+        //  * a line with an end behind the near clip plane is not clipped: its interval runs from the visible
+        //    end's ray to the edge of the fan on the side it leaves by - the sign of cross(a, b).  (Clipping would
+        //    only give less when the crossing is within centimetres of the agent.)
+        // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first pair << 6 | first ray, line)
+        //               3072 ray (64 x 16 B)    | 4096 best (64 x 8 B) | 4608 marks (4096 bits) | 5120 flags (64 x 4 B)
+        // ------------------------------------------------------------------------------------------
+        constexpr int V_CAP = 128, P_CAP = 4096;
+        int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][2048]);
+        float4* const s_ray_w = reinterpret_cast<float4*>(&s_raw[wave][3072]);
+        unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4096]);
+        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][4608]);
+        unsigned* const s_flag_w = reinterpret_cast<unsigned*>(&s_raw[wave][5120]);
+        s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
+        s_best_w[lane] = ~0ull;
+        s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
+        s_flag_w[lane] = 0u;
+        const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
+        // pass 1 for one line (lane = line): the ray-independent half of the intersection, and the conservative
+        // interval [lo, lo + len) of this wave's rays that can hit it
+        auto line_setup2 = [&](const int c0, Cand& cd, int& lo, int& len) {   // every lane comes in; dead ones leave with len 0
+            const int l = c0 + lane;
+            const bool live = l < L;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live & (l >= AF)) w = ln[l];
+            if (c0 < AF) {                                              // chunk with agent lines in it
+                const float4 aw = agent_line(l);
+                if (l < AF) w = aw;
+            }
+            const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
+            const float dbx = w.z - pp.x, dby = w.w - pp.y;
+            cd = Cand{pqx, pqy, w.z - w.x, w.w - w.y};                 // v = b - a
+            // agent-frame coordinates of both endpoints.  From here on everything only feeds the cull, whose margin
+            // is 10^5 roundings wide: fused multiply-adds and approximate reciprocals are fine
+            const float xa = __builtin_fmaf(cs, pqx, sn*pqy), ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
+            const float xb = __builtin_fmaf(cs, dbx, sn*dby), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
+            const bool fa = xa >= x_clip, fb = xb >= x_clip;            // (a NaN coordinate: the reference never hits such a line)
+            // continuous ray index of a visible end; a hidden end is replaced by the edge of the fan its line leaves by
+            const float ia = fa ? ya*__builtin_amdgcn_rcpf(xa) : 0.f, ib = fb ? yb*__builtin_amdgcn_rcpf(xb) : 0.f;
+            const float fra = __builtin_fmaf(-ia, c_b, c_a), frb = __builtin_fmaf(-ib, c_b, c_a);
+            const float marg = __builtin_fmaf(1e-4f, fabsf(fra) + fabsf(frb), 0.05f);
+            const float edge = (xa*yb - ya*xb > 0.f) ? -INFINITY : INFINITY;   // from a towards b the ray index falls / rises
+            const float ra = fa ? fra : -edge, rb = fb ? frb : edge;
+            const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
+            const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
+            lo = (int)ceilf(flo);
+            len = (live & (fa | fb)) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+        };
+
+        int n_list = 0, n_pairs = 0;             // lines and pairs in the list (wave-uniform)
+        // pass 2 over the list: windows of 64 pairs
+        auto drain = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int before = 0;                      // marks in earlier windows = lines that start before this one
+            for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {
+                const unsigned mlo = __builtin_amdgcn_readfirstlane(s_mark_w[p0 >> 5]);
+                const unsigned mhi = __builtin_amdgcn_readfirstlane(s_mark_w[(p0 >> 5) + 1]);
+                const unsigned long long M = ((unsigned long long)mhi << 32) | mlo;
+                // marks at positions 0..lane of this window, via the bits of M >> 1 below the lane
+                const unsigned long long Ms = M >> 1;
+                const int upto = (int)(mlo & 1u) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(Ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Ms, 0u));
+                const int p = p0 + lane;
+                const bool valid = p < n_pairs;
+                const int k = valid ? before + upto - 1 : 0;
+                before += __popcll(M);
+                const int2 info = s_info_w[k];
+                const int rr = valid ? (info.x & 63) + (p - (info.x >> 6)) : 0;   // ray of this pair, wave-local
+                const Cand cd = s_cand_w[k];
+                const float4 ray = s_ray_w[rr];
+                const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
+                const float nt = cd.pqx*ray.y - cd.pqy*ray.x;                // cross(PQ, ru)
+                const float ad = fabsf(d);
+                const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked)
+                const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+                if (hit) {
+                    const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
+                    if (ray.z < sv) {                                        // beyond the near plane, kernels.cu:369
+                        const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)info.y;
+                        const unsigned long long old = atomicMin(&s_best_w[rr], key);
+                        const unsigned oh = (unsigned)(old >> 32);
+                        if (oh != 0xffffffffu) {                             // there was a hit before: is the loser clearly behind?
+                            const bool won = key < old;
+                            const float so = bits_f(oh);
+                            const float front = won ? sv : so, back = won ? so : sv;
+                            if (!(front < back - 1.e-4f)) s_flag_w[rr] = 1u;
+                        }
+                    }
+                }
+            }
+            // the list starts over
+            __builtin_amdgcn_wave_barrier();
+            s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
+            n_list = 0; n_pairs = 0;
+        };
+
+        for (int c0 = 0; c0 < L; c0 += WAVE) {
+            Cand cd;
+            int lo = 0, len = 0;
+            line_setup2(c0, cd, lo, len);
+            const bool seen = len > 0;
+            const unsigned long long vm = __ballot(seen);
+            if (!vm) continue;                                               // uniform
+            const int incl = wave_scan_add(len);
+            const int chunk_pairs = __builtin_amdgcn_readlane(incl, 63);
+            const int chunk_lines = __popcll(vm);
+            if ((n_list + chunk_lines > V_CAP) | (n_pairs + chunk_pairs > P_CAP)) drain();
+            if (seen) {
+                const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                const int first = n_pairs + incl - len;                      // this line's first pair
+                s_cand_w[k] = cd;
+                s_info_w[k] = make_int2((first << 6) | (lo & 63), c0 + lane);
+                atomicOr(&s_mark_w[first >> 5], 1u << (first & 31));
+            }
+            n_list += chunk_lines; n_pairs += chunk_pairs;
+        }
+        if (n_pairs) drain();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long best = s_best_w[lane];
+        const bool ambiguous = s_flag_w[lane] != 0u;
+        if (best != ~0ull) {
+            nearest_s = bits_f((uint32_t)(best >> 32));
+            nearest_idx = (int)(uint32_t)best;
+        }
+        // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1
+        const unsigned long long amb = __ballot(ambiguous);
+        if (amb && out.workspace && lane == 0) {
+            atomicAdd(&out.workspace[1], __popcll(amb));
+            if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
+        }
+        if (__popcll(amb) > 6) {
+            // many such rays (a view full of coincident walls): every one of them walks the lines itself, lines
+            // broadcast from LDS - but only the lines whose interval reaches one of these rays are looked at
+            float x = INFINITY;
+            int xi = -1;
+            for (int c0 = 0; c0 < L; c0 += WAVE) {
+                Cand mine;
+                int lo = 0, len = 0;
+                line_setup2(c0, mine, lo, len);
+                __builtin_amdgcn_wave_barrier();
+                s_cand_w[lane] = mine;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (unsigned long long todo = __ballot(len > 0); todo; todo &= todo - 1) {
+                    const int j = __ffsll((long long)todo) - 1;
+                    const int jlo = __builtin_amdgcn_readlane(lo, j), jhi = jlo + __builtin_amdgcn_readlane(len, j) - 1;
+                    const unsigned long long span = ((jhi >= 63) ? ~0ull : ((2ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull);
+                    if (!(span & amb)) continue;
+                    if (ambiguous & (lane >= jlo) & (lane <= jhi)) {
+                        const Cand cd = s_cand_w[j];
+                        const float d = rx*cd.vy - ry*cd.vx;
+                        const float nt = cd.pqx*ry - cd.pqy*rx;
+                        const float ad = fabsf(d);
+                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                        if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                            if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = c0 + j; }
+                        }
+                    }
+                }
             }
             if (ambiguous) { nearest_s = x; nearest_idx = xi; }
         } else if (amb) {
@@ -1958,7 +2180,11 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
     // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
     // (kept for A/B verification); both produce the same bits.
-    static const bool seq = [] { const char* e = getenv("MEGASTEP_RENDER_IMPL"); return e && e[0] == 's'; }();
+    // MEGASTEP_RENDER_IMPL: "seq" (literal order, slowest), "pairs" (round 1's pair raycast), "v2" (compacted pairs);
+    // all three produce the same bits.  Read per call: tests switch it.
+    const char* impl_env = getenv("MEGASTEP_RENDER_IMPL");
+    const bool seq = impl_env && impl_env[0] == 's';
+    const bool pairs1 = !(impl_env && impl_env[0] == 'v');                     // (the default until v2 has been through the GPU suite)
     // the light grid is all or nothing: render_kernel lights agent-hit rays itself when it is there
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
@@ -2000,6 +2226,10 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
         hipLaunchKernelGGL((render_kernel<0, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else if (seq)
         hipLaunchKernelGGL((render_kernel<0, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else if (!pairs1 && obs)
+        hipLaunchKernelGGL((render_kernel<2, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else if (!pairs1)
+        hipLaunchKernelGGL((render_kernel<2, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else if (obs)
         hipLaunchKernelGGL((render_kernel<1, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
     else
