@@ -177,13 +177,27 @@ def cpu_baselines(core, budget_s=8.):
     from oracle import oracle as O
     from oracle import torch_step
     cores = os.cpu_count()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else cores
     out = {}
     rng = np.random.RandomState(0)
 
-    n, scene, agents = _oracle_sample(core, 256)
-    torch.set_num_threads(cores)
-    world = torch_step.World(scene, core.agent_radius, core.res, core.fov, core.fps)
-    ag = {k: torch.as_tensor(v) for k, v in agents.items()}
+    # the pure-PyTorch step is thousands of small tensor ops: past a few dozen threads each op spends its time waking
+    # threads up (256 of them turned one step into minutes), so the pool is capped; the sample is sized from a probe
+    # step so that the leg stays within its budget whatever the box
+    threads = max(1, min(usable, 32))
+    torch.set_num_threads(threads)
+    n = 16
+    while True:
+        n, scene, agents = _oracle_sample(core, n)
+        world = torch_step.World(scene, core.agent_radius, core.res, core.fov, core.fps)
+        ag = {k: torch.as_tensor(v) for k, v in agents.items()}
+        t0 = time.perf_counter()
+        torch_step.step(world, ag)
+        probe = time.perf_counter() - t0
+        log(f'pure-PyTorch CPU step: probe of {n} envs took {probe:.2f}s on {threads} threads')
+        if n >= min(256, core.n_envs) or probe*4 > budget_s/4:
+            break
+        n *= 4
     steps, t0 = 0, time.perf_counter()
     while True:
         ag['velocity'] = torch.as_tensor(rng.uniform(-3, 3, agents['velocity'].shape).astype(np.float32))
@@ -195,8 +209,9 @@ def cpu_baselines(core, budget_s=8.):
             break
     log(f'pure-PyTorch CPU step: {steps} steps of {n} envs in {dt:.1f}s')
     out['cpu_baseline'] = {
-        'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'implementation': 'pure PyTorch (CPU tensors)',
-        'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/torch_step.py, torch.set_num_threads({cores})'}
+        'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port', 'implementation': 'pure PyTorch (CPU tensors)',
+        'host_cores': cores, 'usable_cores': usable,
+        'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/torch_step.py, torch.set_num_threads({threads})'}
 
     n, scene, agents = _oracle_sample(core, 4096)
     scene = O.Scene(scene)
@@ -212,7 +227,8 @@ def cpu_baselines(core, budget_s=8.):
         if dt > budget_s/2 or steps >= 100:
             break
     out['cpu_baseline_c'] = {
-        'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port', 'implementation': 'plain C + OpenMP over envs',
+        'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': usable, 'kind': 'port', 'implementation': 'plain C + OpenMP over envs',
+        'host_cores': cores,
         'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/megastep_oracle.c'}
     return out
 

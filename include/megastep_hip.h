@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 8
+#define MS_ABI_VERSION 9
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -139,6 +139,18 @@ typedef struct MsRender {
     float* obs_depth;
     int    obs_subsample;
     float  obs_max_depth;
+    /* Optional, with obs_subsample set: what the two central observation pixels of each agent show - the index of
+     * the agent whose outline the pixel's middle ray (ray pixel*obs_subsample + obs_subsample/2) landed on, else -1.
+     * It is all Deathmatch reads from `indices` (demo/envs/deathmatch.py:54-58,74-80).  (N, A, 2) */
+    int*   obs_centre;
+    /* Optional first-sight bookkeeping (replaces demo/envs/explorer.py:34-58, a scatter over every texel of every env
+     * per step): each ray that hits marks the texel under it - textures_starts[line] + min(floor(width*location),
+     * width - 1), explorer.py:38-41 - by writing its env's epoch into seen_stamp, and texels whose stamp was not the
+     * epoch yet are counted into seen_count.  Bumping an env's epoch forgets all its texels at once.
+     *   seen_stamp (sum T,) int, seen_epoch (N,) int, seen_count (N,) int (added to, atomically) */
+    int*       seen_stamp;
+    const int* seen_epoch;
+    int*       seen_count;
 } MsRender;
 
 /* 4-byte words of MsRender.workspace needed for N envs, A agents, R rays */
@@ -168,6 +180,31 @@ typedef struct MsMovement {
     float            keep;
 } MsMovement;
 
+/* Optional bookkeeping around the physics step: what the reference's environments do with a few dozen tensor ops
+ * right before and after it - lifespans (modules.py:328-381), respawns (modules.py:298-326) and the IMU observation
+ * (modules.py:240-270).  Every part is optional (NULL pointer = skipped).  Per agent, in this order:
+ *   tick     lifespans += 1;  respawn_mask |= lifespans >= max_lifespans;  where the mask is set, lifespans = 0 and
+ *            max_lifespans = fresh_max (drawn by the caller, as `actions` are)
+ *   respawn  where respawn_mask is set: pose = spawn table row `respawn_choice` (clamped to the table) of this agent,
+ *            velocities = 0.  respawn_after = 0: before the movement prologue and the step, so the new pose is what
+ *            moves and collides (Deathmatch's order, demo/envs/deathmatch.py:96-99); respawn_after = 1: after the
+ *            step's integration (Explorer's order, demo/envs/explorer.py:83-90)
+ *   imu      of the state the call leaves behind: [angvelocity/imu_ang_scale, (c vx + s vy)/imu_speed_scale,
+ *            (-s vx + c vy)/imu_speed_scale] with (c, s) = cos, sin of the heading in radians, binary32 as torch does */
+typedef struct MsStepExtras {
+    unsigned char*   respawn_mask;      /* (N, A) bytes, non-zero = respawn; written back when lifespans tick  */
+    const long long* respawn_choice;    /* (N, A) */
+    const float*     spawn_positions;   /* (N, A, n_spawns, 2) */
+    const float*     spawn_angles;      /* (N, A, n_spawns)    */
+    int              n_spawns;
+    int              respawn_after;
+    int*             lifespans;         /* (N, A) */
+    int*             max_lifespans;     /* (N, A) */
+    const int*       fresh_max;         /* (N, A) */
+    float*           imu;               /* (N, A, 3) */
+    float            imu_ang_scale, imu_speed_scale;
+} MsStepExtras;
+
 /* Replaces `physics(scenery, agents) -> Physics` (wrappers.cpp:69, kernels.cu:179-230):
  * collision-limited integration of the agents, in place; `progress` is the (N, A) output that
  * the reference returns as Physics.progress. */
@@ -175,6 +212,9 @@ int ms_move_physics(const MsScenery* scenery, const MsAgents* agents, const MsMo
                     float* progress, const MsConfig* config, void* hip_stream);
 int ms_physics(const MsScenery* scenery, const MsAgents* agents, float* progress,
                const MsConfig* config, void* hip_stream);
+/* The same step with the environment's bookkeeping around it in the same launch (movement and extras may be NULL). */
+int ms_step_physics(const MsScenery* scenery, const MsAgents* agents, const MsMovement* movement, const MsStepExtras* extras,
+                    float* progress, const MsConfig* config, void* hip_stream);
 
 /* Replaces `render(scenery, agents) -> Render` (wrappers.cpp:82, kernels.cu:297-475):
  * draw (rewrites the agent rows of lines_vals) -> raycast -> shade, one fused launch. */

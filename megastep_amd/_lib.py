@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -46,14 +46,23 @@ class MsMovement(C.Structure):
     _fields_ = [('actions', C.c_void_p), ('table', C.c_void_p), ('n_actions', C.c_int), ('keep', C.c_float)]
 
 
+class MsStepExtras(C.Structure):
+    _fields_ = [('respawn_mask', C.c_void_p), ('respawn_choice', C.c_void_p), ('spawn_positions', C.c_void_p),
+                ('spawn_angles', C.c_void_p), ('n_spawns', C.c_int), ('respawn_after', C.c_int),
+                ('lifespans', C.c_void_p), ('max_lifespans', C.c_void_p), ('fresh_max', C.c_void_p),
+                ('imu', C.c_void_p), ('imu_ang_scale', C.c_float), ('imu_speed_scale', C.c_float)]
+
+
 class MsRender(C.Structure):
     _fields_ = [('indices', C.c_void_p), ('locations', C.c_void_p), ('dots', C.c_void_p), ('distances', C.c_void_p),
                 ('screen', C.c_void_p), ('workspace', C.c_void_p), ('obs_rgb', C.c_void_p), ('obs_depth', C.c_void_p),
-                ('obs_subsample', C.c_int), ('obs_max_depth', C.c_float)]
+                ('obs_subsample', C.c_int), ('obs_max_depth', C.c_float), ('obs_centre', C.c_void_p),
+                ('seen_stamp', C.c_void_p), ('seen_epoch', C.c_void_p), ('seen_count', C.c_void_p)]
 
 
 #: every symbol include/megastep_hip.h declares
 SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
+           'ms_step_physics',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins')
 
 
@@ -113,13 +122,15 @@ def lib():
         handle.ms_physics.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.c_void_p, C.POINTER(MsConfig), C.c_void_p]
         handle.ms_move_physics.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsMovement), C.c_void_p,
                                            C.POINTER(MsConfig), C.c_void_p]
+        handle.ms_step_physics.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsMovement), C.POINTER(MsStepExtras),
+                                           C.c_void_p, C.POINTER(MsConfig), C.c_void_p]
         handle.ms_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]
         handle.ms_host_sincospi.argtypes = [C.c_float, _f32p, _f32p]
         handle.ms_host_bake_point_bin.argtypes = [C.c_float]*4
         handle.ms_host_bake_point_bin.restype = C.c_int
         handle.ms_host_bake_wall_bins.argtypes = [C.c_float]*6 + [_i32p, _i32p]
         handle.ms_host_bake_wall_bins.restype = None
-        for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_render'):
+        for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_step_physics', 'ms_render'):
             getattr(handle, name).restype = C.c_int
         if handle.ms_abi_version() != ABI_VERSION:
             raise ImportError(f'{LIB_PATH} has ABI {handle.ms_abi_version()}, this package needs {ABI_VERSION}; rebuild it')

@@ -219,10 +219,11 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
-template <int MOVE>
+// EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
+template <int MOVE, int EXTRA>
 __global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps, const MsMovement mv) {
+        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex) {
     extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
     __shared__ float4 s_wall[WAVE];              // walls near ...
     __shared__ int s_tag[WAVE];                  // ... this agent
@@ -252,6 +253,36 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     float2 my_p = make_float2(0.f, 0.f), my_v = make_float2(0.f, 0.f);   // agent `lane`, kept for the epilogue
     float my_w = 0.f, my_ang = 0.f;
     if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
+    // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)
+    auto spawn_pose = [&](const int i, float2& p, float& ang) {
+        const long long c = min(max(ex.respawn_choice[i], 0ll), (long long)ex.n_spawns - 1);
+        p = reinterpret_cast<const float2*>(ex.spawn_positions)[(size_t)i*ex.n_spawns + c];
+        ang = ex.spawn_angles[(size_t)i*ex.n_spawns + c];
+    };
+    if constexpr (EXTRA == 1) {
+        for (int t = lane; t < A; t += WAVE) {
+            const int i = n*A + t;
+            bool reset = ex.respawn_mask && ex.respawn_mask[i];
+            if (ex.lifespans) {                                          // modules.py:361-366
+                int life = ex.lifespans[i] + 1;
+                reset = reset | (life >= ex.max_lifespans[i]);
+                if (reset) { life = 0; ex.max_lifespans[i] = ex.fresh_max[i]; }
+                ex.lifespans[i] = life;
+                if (ex.respawn_mask) ex.respawn_mask[i] = reset ? 1 : 0;
+            }
+            if (reset && ex.spawn_positions && !ex.respawn_after) {
+                float2 p; float ang;
+                spawn_pose(i, p, ang);
+                if (t == lane) { my_p = p; my_ang = ang; my_v = make_float2(0.f, 0.f); my_w = 0.f; }
+                // through memory as well: agents beyond the first 64 live there, and the movement prologue and the
+                // epilogue's "velocity only changes on a collision" rule read it back
+                reinterpret_cast<float2*>(ag.positions)[i] = p;
+                ag.angles[i] = ang;
+                reinterpret_cast<float2*>(ag.velocity)[i] = make_float2(0.f, 0.f);
+                ag.angvelocity[i] = 0.f;
+            }
+        }
+    }
     if constexpr (MOVE == 1) {
         // modules.py:57-66,106-118: look the action up, turn its velocity delta into the global frame, blend
         auto moved = [&](const int i, const float ang, float2& v, float& w) {
@@ -368,19 +399,37 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         if (t != lane) { p = pos2w[i]; v = vel2w[i]; w_ = ag.angvelocity[i]; ang = ag.angles[i]; }
         p.x = p.x + x*v.x/fps;
         p.y = p.y + x*v.y/fps;
+        float turned = normalize_degrees(ang + x*w_/fps);
+        bool stopped = x < 1;
+        if (stopped) { v = make_float2(0.f, 0.f); w_ = 0.f; }
+        if constexpr (EXTRA == 1) {
+            if (ex.spawn_positions && ex.respawn_after && ex.respawn_mask && ex.respawn_mask[i]) {
+                spawn_pose(i, p, turned);
+                v = make_float2(0.f, 0.f); w_ = 0.f;
+                stopped = true;
+            }
+        }
         pos2w[i] = p;
-        const float turned = normalize_degrees(ang + x*w_/fps);
         ag.angles[i] = turned;
         if (ag.headings) {                                   // what render_prep_kernel would compute, one launch earlier
             float hs, hc;
             sincospi_f(turned/180.f, hs, hc);
             reinterpret_cast<float4*>(ag.headings)[i] = make_float4(turned, hs, hc, 0.f);
         }
-        if (x < 1) {
-            vel2w[i] = make_float2(0.f, 0.f);
-            ag.angvelocity[i] = 0.f;
+        if (stopped) {
+            vel2w[i] = v;
+            ag.angvelocity[i] = w_;
         }
         progress[i] = x;
+        if constexpr (EXTRA == 1) {
+            if (ex.imu) {                                    // modules.py:263-270, to_local_frame :24-31
+                const float a_ = 0.017453292519943295f*turned;
+                const float s_ = sinf(a_), c_ = cosf(a_);
+                ex.imu[3*i] = w_/ex.imu_ang_scale;
+                ex.imu[3*i + 1] = (c_*v.x + s_*v.y)/ex.imu_speed_scale;
+                ex.imu[3*i + 2] = (-s_*v.x + c_*v.y)/ex.imu_speed_scale;
+            }
+        }
     }
 }
 
@@ -616,6 +665,16 @@ __device__ inline float grid_light_intensity(
 #ifndef MS_GROUPS
 #define MS_GROUPS 8
 #endif
+// A/B knobs of the pair raycasts (tools/ab_variants.sh builds one library per setting; the defaults are the product):
+//   MS_V1_OPTS  bit 0: IMPL 1 takes IMPL 2's interval arithmetic (no clipping); bit 1: IMPL 1 takes IMPL 2's single
+//               atomic + hysteresis flag instead of the three-slot cascade
+//   MS_V2_OPTS  bit 0: IMPL 2 drains its list after every chunk; bit 1: IMPL 2 clips like IMPL 1
+#ifndef MS_V1_OPTS
+#define MS_V1_OPTS 0
+#endif
+#ifndef MS_V2_OPTS
+#define MS_V2_OPTS 0
+#endif
 constexpr int GROUPS = MS_GROUPS;     // ray groups (sub-wedges) per wave
 constexpr int GSIZE = WAVE/GROUPS;    // rays per group
 constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair list in the dynamic-light pass
@@ -676,12 +735,49 @@ __device__ inline int div_by(int n, const Divisor d) {     // n >= 0
 __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
                                                          const int n_agents_total, const int n_fans) {
     const int i = blockIdx.x*WG + threadIdx.x;
-    if (i == 0) { workspace[0] = 0; workspace[1] = 0; workspace[2] = 0; }
+    if (i == 0) { workspace[0] = 0; workspace[1] = 0; workspace[2] = 0; workspace[3] = 0; workspace[4] = 0; }
     if (i < n_agents_total) {
         float s, c;
         sincospi_f(ag.angles[i]/180.f, s, c);
         reinterpret_cast<float2*>(workspace + 16 + ((n_fans + 1) & ~1))[i] = make_float2(s, c);
     }
+}
+
+// Conservative interval [lo, lo + len) of a wave's rays that can hit a line, from the agent-frame coordinates of its
+// ends (x forward, y left; c_a - (y/x) c_b is the continuous ray index).  Everything here only feeds the cull, whose
+// margin is 10^5 roundings wide: fused multiply-adds and approximate reciprocals are fine.
+//   CLIP = 1: an end behind the near clip plane is clipped to it;
+//   CLIP = 0: it is replaced by the edge of the fan on the side the line leaves by (the sign of cross(a, b)) - the same
+//             interval unless the line crosses the clip plane within centimetres of the agent, for fewer instructions.
+template <int CLIP>
+__device__ inline void ray_interval(float xa, float ya, float xb, float yb, const bool live, const float x_clip,
+                                    const float c_a, const float c_b, const float g0, const float last_local, int& lo, int& len) {
+    const bool fa = xa >= x_clip, fb = xb >= x_clip;
+    float ra, rb, marg;
+    bool inc;
+    if constexpr (CLIP == 1) {
+        inc = fa | fb | !(xa == xa) | !(xb == xb);                      // wholly behind the clip plane: never hit
+        if (fa != fb) {                                                 // clip the hidden end to x' = x_clip
+            const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
+            const float yc = __builtin_fmaf(t, yb - ya, ya);
+            if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
+        }
+        const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
+        ra = __builtin_fmaf(-ysa, c_b, c_a); rb = __builtin_fmaf(-ysb, c_b, c_a);
+        marg = __builtin_fmaf(1e-4f, fabsf(ra) + fabsf(rb), 0.05f);
+    } else {
+        inc = fa | fb;                                                  // (a NaN coordinate: the reference never hits such a line)
+        const float ia = fa ? ya*__builtin_amdgcn_rcpf(xa) : 0.f, ib = fb ? yb*__builtin_amdgcn_rcpf(xb) : 0.f;
+        const float fra = __builtin_fmaf(-ia, c_b, c_a), frb = __builtin_fmaf(-ib, c_b, c_a);
+        marg = __builtin_fmaf(1e-4f, fabsf(fra) + fabsf(frb), 0.05f);
+        const float edge = (xa*yb - ya*xb > 0.f) ? -INFINITY : INFINITY;   // from a towards b the ray index falls / rises
+        ra = fa ? fra : -edge; rb = fb ? frb : edge;
+    }
+    // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
+    const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
+    const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
+    lo = (int)ceilf(flo);
+    len = (live & inc) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
 }
 
 // IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
@@ -838,26 +934,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
             const float dbx = w.z - pp.x, dby = w.w - pp.y;
             s_cand_w[lane] = Cand{pqx, pqy, w.z - w.x, w.w - w.y};  // v = b - a
-            // agent-frame coordinates of both endpoints.  From here on everything only feeds the cull, whose margin
-            // is 10^5 roundings wide: fused multiply-adds and approximate reciprocals are fine
-            float xa = __builtin_fmaf(cs, pqx, sn*pqy), ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
-            float xb = __builtin_fmaf(cs, dbx, sn*dby), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
-            const bool fa = xa >= x_clip, fb = xb >= x_clip;
-            const bool inc = fa | fb | !(xa == xa) | !(xb == xb);       // wholly behind the clip plane: never hit
-            if (fa != fb) {                                             // clip the hidden end to x' = x_clip
-                const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
-                const float yc = __builtin_fmaf(t, yb - ya, ya);
-                if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
-            }
-            const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
-            const float ra = __builtin_fmaf(-ysa, c_b, c_a), rb = __builtin_fmaf(-ysb, c_b, c_a);
-            const float marg = __builtin_fmaf(1e-4f, fabsf(ra) + fabsf(rb), 0.05f);
-            // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
-            const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
-            const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
-            lo = (int)ceilf(flo);
-            len = (live & inc) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+            // agent-frame coordinates of both endpoints
+            const float xa = __builtin_fmaf(cs, pqx, sn*pqy), ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
+            const float xb = __builtin_fmaf(cs, dbx, sn*dby), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
+            ray_interval<(MS_V1_OPTS & 1) ? 0 : 1>(xa, ya, xb, yb, live, x_clip, c_a, c_b, g0, last_local, lo, len);
         };
+        int n_pairs_total = 0, n_windows = 0;    // telemetry
 
         for (int c0 = 0; c0 < L; c0 += WAVE) {
             int lo = 0, len = 0;
@@ -866,6 +948,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const int first = incl - len;                                    // this line's first pair
             const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
             s_info_w[lane] = (first << 6) | (lo & 63);
+            n_pairs_total += P; n_windows += (P + WAVE - 1)/WAVE;
             int carry = -1;
             for (int p0 = 0; p0 < P; p0 += WAVE) {
                 // which line owns pair p0 + lane: lines mark their first pair, a max-scan spreads the marks
@@ -893,6 +976,18 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
                     if (ray.z < sv) {                                        // beyond the near plane, kernels.cu:369
                         const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)(c0 + j);
+                        if constexpr ((MS_V1_OPTS & 2) != 0) {
+                            // one atomic; the ray is flagged (its third slot, unused otherwise, set to 0) unless the
+                            // loser of this merge is clearly behind the winner - see IMPL 2
+                            const unsigned long long old = atomicMin(&s_best_w[rr], key);
+                            const unsigned oh = (unsigned)(old >> 32);
+                            if (oh != 0xffffffffu) {
+                                const bool won = key < old;
+                                const float so = bits_f(oh);
+                                const float front = won ? sv : so, back = won ? so : sv;
+                                if (!(front < back - 1.e-4f)) s_third_w[rr] = 0ull;
+                            }
+                        } else {
                         // keep the three smallest keys: whatever loses at one level drops to the next
                         const unsigned long long old1 = atomicMin(&s_best_w[rr], key);
                         const unsigned long long lose1 = old1 > key ? old1 : key;
@@ -900,6 +995,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                             const unsigned long long old2 = atomicMin(&s_second_w[rr], lose1);
                             const unsigned long long lose2 = old2 > lose1 ? old2 : lose1;
                             if (lose2 != ~0ull) atomicMin(&s_third_w[rr], lose2);
+                        }
                         }
                     }
                 }
@@ -910,7 +1006,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long best = s_best_w[lane], second = s_second_w[lane], third = s_third_w[lane];
         bool ambiguous = false;
-        if (best != ~0ull) {
+        if (((MS_V1_OPTS & 2) != 0) && best != ~0ull) {
+            nearest_s = bits_f((uint32_t)(best >> 32));
+            nearest_idx = (int)(uint32_t)best;
+            ambiguous = third == 0ull;
+        } else if (best != ~0ull) {
             const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
             const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
             nearest_s = s1;
@@ -936,6 +1036,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
         // line order into the ray's own state, which lives in the ray's lane.
         const unsigned long long amb = __ballot(ambiguous);
+        if (out.workspace && lane == 0) {
+            atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
+        }
         if (amb && out.workspace && lane == 0) {
             atomicAdd(&out.workspace[1], __popcll(amb));
             if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
@@ -1059,23 +1162,13 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
             const float dbx = w.z - pp.x, dby = w.w - pp.y;
             cd = Cand{pqx, pqy, w.z - w.x, w.w - w.y};                 // v = b - a
-            // agent-frame coordinates of both endpoints.  From here on everything only feeds the cull, whose margin
-            // is 10^5 roundings wide: fused multiply-adds and approximate reciprocals are fine
+            // agent-frame coordinates of both endpoints
             const float xa = __builtin_fmaf(cs, pqx, sn*pqy), ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
             const float xb = __builtin_fmaf(cs, dbx, sn*dby), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
-            const bool fa = xa >= x_clip, fb = xb >= x_clip;            // (a NaN coordinate: the reference never hits such a line)
-            // continuous ray index of a visible end; a hidden end is replaced by the edge of the fan its line leaves by
-            const float ia = fa ? ya*__builtin_amdgcn_rcpf(xa) : 0.f, ib = fb ? yb*__builtin_amdgcn_rcpf(xb) : 0.f;
-            const float fra = __builtin_fmaf(-ia, c_b, c_a), frb = __builtin_fmaf(-ib, c_b, c_a);
-            const float marg = __builtin_fmaf(1e-4f, fabsf(fra) + fabsf(frb), 0.05f);
-            const float edge = (xa*yb - ya*xb > 0.f) ? -INFINITY : INFINITY;   // from a towards b the ray index falls / rises
-            const float ra = fa ? fra : -edge, rb = fb ? frb : edge;
-            const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
-            const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
-            lo = (int)ceilf(flo);
-            len = (live & (fa | fb)) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+            ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, live, x_clip, c_a, c_b, g0, last_local, lo, len);
         };
 
+        int n_pairs_total = 0, n_windows = 0;    // telemetry
         int n_list = 0, n_pairs = 0;             // lines and pairs in the list (wave-uniform)
         // pass 2 over the list: windows of 64 pairs
         auto drain = [&]() {
@@ -1083,6 +1176,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int before = 0;                      // marks in earlier windows = lines that start before this one
+            n_pairs_total += n_pairs; n_windows += (n_pairs + WAVE - 1)/WAVE;
             for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {
                 const unsigned mlo = __builtin_amdgcn_readfirstlane(s_mark_w[p0 >> 5]);
                 const unsigned mhi = __builtin_amdgcn_readfirstlane(s_mark_w[(p0 >> 5) + 1]);
@@ -1144,6 +1238,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 atomicOr(&s_mark_w[first >> 5], 1u << (first & 31));
             }
             n_list += chunk_lines; n_pairs += chunk_pairs;
+            if constexpr ((MS_V2_OPTS & 1) != 0) drain();
         }
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1155,6 +1250,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1
         const unsigned long long amb = __ballot(ambiguous);
+        if (out.workspace && lane == 0) {
+            atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
+        }
         if (amb && out.workspace && lane == 0) {
             atomicAdd(&out.workspace[1], __popcll(amb));
             if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
@@ -1366,6 +1464,28 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         tstart = sc.textures_starts[start];
     }
     if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
+    if constexpr (OBS == 1) {
+        if (out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
+            bool fresh = false;
+            if (is_hit) {
+                const float wf = (float)sc.textures_widths[base + nearest_idx];
+                const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
+                const int epoch = out.seen_epoch[n];
+                fresh = atomicExch(&out.seen_stamp[tstart + along], epoch) != epoch;   // exactly one ray per texel sees the old stamp
+            }
+            const unsigned long long fm = __ballot(fresh);
+            if (fm && lane == 0) atomicAdd(&out.seen_count[n], __popcll(fm));
+        }
+        if (out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
+            const int sub = out.obs_subsample, W = R/sub;
+            const int r1 = (W/2 - 1)*sub + sub/2, r2 = (W/2)*sub + sub/2;
+            if ((r == r1) | (r == r2)) {
+                int seen = -1;
+                if ((nearest_idx >= 0) & (nearest_idx < AF)) seen = nearest_idx/sc.n_model;
+                out.obs_centre[((size_t)n*A + a)*2 + (r == r2 ? 1 : 0)] = seen;
+            }
+        }
+    }
 
     if (is_hit) {
         const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
@@ -2144,32 +2264,52 @@ void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, fl
     bake_wall_bins(p2(light_x, light_y), ax, ay, bx, by, *first, *count);
 }
 
-int ms_move_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, float* progress, const MsConfig* cfg,
-                    void* stream) {
+int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, const MsStepExtras* ex, float* progress,
+                    const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
     if (mv && (!mv->actions || !mv->table || mv->n_actions < 1 || !(mv->keep == mv->keep))) return MS_EINVAL;
+    if (ex) {
+        if (ex->spawn_positions && (!ex->spawn_angles || !ex->respawn_mask || !ex->respawn_choice || ex->n_spawns < 1 ||
+                                    ((uintptr_t)ex->spawn_positions % 8))) return MS_EINVAL;
+        if (ex->lifespans && (!ex->max_lifespans || !ex->fresh_max)) return MS_EINVAL;
+        if (ex->imu && !(ex->imu_ang_scale == ex->imu_ang_scale && ex->imu_speed_scale == ex->imu_speed_scale)) return MS_EINVAL;
+    }
     const size_t shmem = (sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
     if (shmem > 60*1024) return MS_EUNSUPPORTED;
-    if (mv)
-        hipLaunchKernelGGL(physics_kernel<1>, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
-                           *sc, *ag, progress, cfg->agent_radius, cfg->fps, *mv);
+    const MsMovement no_move{nullptr, nullptr, 0, 0.f};
+    const MsStepExtras no_extras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
+    const dim3 grid(sc->n_envs), block(WAVE);
+    const hipStream_t hs = (hipStream_t)stream;
+    if (mv && ex)
+        hipLaunchKernelGGL((physics_kernel<1, 1>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, *mv, *ex);
+    else if (ex)
+        hipLaunchKernelGGL((physics_kernel<0, 1>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, no_move, *ex);
+    else if (mv)
+        hipLaunchKernelGGL((physics_kernel<1, 0>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, *mv, no_extras);
     else
-        hipLaunchKernelGGL(physics_kernel<0>, dim3(sc->n_envs), dim3(WAVE), shmem, (hipStream_t)stream,
-                           *sc, *ag, progress, cfg->agent_radius, cfg->fps, MsMovement{nullptr, nullptr, 0, 0.f});
+        hipLaunchKernelGGL((physics_kernel<0, 0>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, no_move, no_extras);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
 
+int ms_move_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, float* progress, const MsConfig* cfg,
+                    void* stream) {
+    return ms_step_physics(sc, ag, mv, nullptr, progress, cfg, stream);
+}
+
 int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const MsConfig* cfg, void* stream) {
-    return ms_move_physics(sc, ag, nullptr, progress, cfg, stream);
+    return ms_step_physics(sc, ag, nullptr, nullptr, progress, cfg, stream);
 }
 
 int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !sc->textures_vals || !sc->textures_widths ||
         !sc->textures_starts || !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
-    if (out->obs_rgb || out->obs_depth) {
+    if ((out->seen_stamp != nullptr) != (out->seen_epoch != nullptr) || (out->seen_stamp != nullptr) != (out->seen_count != nullptr)) return MS_EINVAL;
+    if (out->obs_rgb || out->obs_depth || out->obs_centre) {
         const int sub = out->obs_subsample;
-        if (sub < 1 || (sub & (sub - 1)) || sub > WAVE || cfg->res % sub || !(out->obs_max_depth > 0.f)) return MS_EINVAL;
+        if (sub < 1 || (sub & (sub - 1)) || sub > WAVE || cfg->res % sub) return MS_EINVAL;
+        if (out->obs_depth && !(out->obs_max_depth > 0.f)) return MS_EINVAL;
+        if (out->obs_centre && cfg->res/sub < 2) return MS_EINVAL;
     }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
@@ -2208,7 +2348,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     }
     // dynlight_kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
     const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
-    const bool pooled = out->obs_rgb || out->obs_depth;
+    const bool pooled = out->obs_rgb || out->obs_depth || out->obs_centre || out->seen_stamp;
     if ((!all_planes || pooled) && !(grid || sc->n_agents == 1)) return MS_EUNSUPPORTED;   // dynlight_kernel patches `screen` afterwards
     if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
     const bool obs = pooled || !all_planes;

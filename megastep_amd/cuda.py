@@ -310,9 +310,10 @@ class Render:
     """Result of :func:`render` (reference: common.h:216-222, wrappers.cpp:147-164). Fields that were not asked for
     are ``None``; ``obs_rgb``/``obs_depth`` are the pooled observations when the call asked for them."""
 
-    def __init__(self, indices, locations, dots, distances, screen, obs_rgb=None, obs_depth=None, obs_subsample=None):
+    def __init__(self, indices, locations, dots, distances, screen, obs_rgb=None, obs_depth=None, obs_subsample=None,
+                 obs_centre=None):
         self._t = (indices, locations, dots, distances, screen)
-        self._obs = (obs_rgb, obs_depth, obs_subsample)
+        self._obs = (obs_rgb, obs_depth, obs_subsample, obs_centre)
 
     indices = property(lambda self: self._t[0])
     locations = property(lambda self: self._t[1])
@@ -322,6 +323,7 @@ class Render:
     obs_rgb = property(lambda self: self._obs[0])
     obs_depth = property(lambda self: self._obs[1])
     obs_subsample = property(lambda self: self._obs[2])
+    obs_centre = property(lambda self: self._obs[3])
 
 
 class Physics:
@@ -379,19 +381,29 @@ def bake(scenery, scratch=True):
         _lib.check(_lib.lib().ms_bake(C.byref(struct), cfg, _stream(dev)))
 
 
-def physics(scenery, agents, movement=None, out=None):
+def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None):
     """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
     returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230).
 
-    Beyond the reference: ``movement=(actions, table, keep)`` runs the movement modules' velocity update inside the same
-    launch first (include/megastep_hip.h, MsMovement): ``actions`` (N, A) int64 rows of ``table`` (K, 3) = agent-frame
-    [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns). ``out``: the
-    :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating."""
+    Beyond the reference, the tensor ops its callers run around the step can ride in the same launch
+    (include/megastep_hip.h, MsMovement / MsStepExtras):
+
+    * ``movement=(actions, table, keep)``: the movement modules' velocity update first: ``actions`` (N, A) int64 rows of
+      ``table`` (K, 3) = agent-frame [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns);
+    * ``respawn=dict(mask, choices, positions, angles, after=False)``: agents marked in the (N, A) bool ``mask`` get
+      pose ``positions[n, a, choices[n, a]]`` / ``angles[...]`` and zero velocities - before the step (and before the
+      movement), or after it with ``after=True``;
+    * ``lifespans=dict(lifespans, max_lifespans, fresh)``: (N, A) int32 ages tick first; agents at their maximum are
+      added to ``respawn['mask']`` (required with it), start over and take ``fresh`` as their new maximum;
+    * ``imu=(out, ang_scale, speed_scale)``: the (N, A, 3) IMU observation of the state the step leaves behind.
+
+    ``out``: the :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating."""
     dev = scenery._device()
     _agents_on(agents, dev)
-    if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
+    shape = (len(scenery.lines), scenery.n_agents)
+    if agents.angles.shape != shape:
         raise RuntimeError('agents do not match the scenery: expected (n_envs, n_agents) = '
-                           f'{(len(scenery.lines), scenery.n_agents)}, got {tuple(agents.angles.shape)}')
+                           f'{shape}, got {tuple(agents.angles.shape)}')
     mv = None
     if movement is not None:
         actions, table, keep = movement
@@ -401,10 +413,43 @@ def physics(scenery, agents, movement=None, out=None):
             raise RuntimeError('movement must be ((N, A) contiguous int64 actions, (K, 3) float32 table, keep)')
         _require_gpu(actions, table)
         mv = C.byref(_lib.MsMovement(actions.data_ptr(), table.data_ptr(), table.shape[0], float(keep)))
+    ex = None
+    if respawn is not None or lifespans is not None or imu is not None:
+        x = _lib.MsStepExtras(imu_ang_scale=1., imu_speed_scale=1.)
+        used = []
+        if respawn is not None:
+            mask, choices = respawn['mask'], respawn['choices']
+            positions, angles = respawn['positions'], respawn['angles']
+            if mask.dtype != torch.bool or mask.shape != shape or choices.dtype != torch.int64 or choices.shape != shape \
+                    or positions.dtype != torch.float32 or positions.ndim != 4 or positions.shape[:2] != shape \
+                    or positions.shape[3] != 2 or angles.dtype != torch.float32 or angles.shape != positions.shape[:3] \
+                    or not all(t.is_contiguous() for t in (mask, choices, positions, angles)):
+                raise RuntimeError('respawn needs a (N, A) bool mask, (N, A) int64 choices, (N, A, S, 2) float32 positions '
+                                   'and (N, A, S) float32 angles, all contiguous')
+            x.respawn_mask, x.respawn_choice = mask.data_ptr(), choices.data_ptr()
+            x.spawn_positions, x.spawn_angles, x.n_spawns = positions.data_ptr(), angles.data_ptr(), positions.shape[2]
+            x.respawn_after = int(bool(respawn.get('after', False)))
+            used += [mask, choices, positions, angles]
+        if lifespans is not None:
+            if respawn is None:
+                raise RuntimeError('lifespans need a respawn mask to report into')
+            ages, maxima, fresh = lifespans['lifespans'], lifespans['max_lifespans'], lifespans['fresh']
+            if any(t.dtype != torch.int32 or t.shape != shape or not t.is_contiguous() for t in (ages, maxima, fresh)):
+                raise RuntimeError('lifespans, max_lifespans and fresh must be contiguous (N, A) int32 tensors')
+            x.lifespans, x.max_lifespans, x.fresh_max = ages.data_ptr(), maxima.data_ptr(), fresh.data_ptr()
+            used += [ages, maxima, fresh]
+        if imu is not None:
+            obs, ang_scale, speed_scale = imu
+            if obs.dtype != torch.float32 or obs.shape != shape + (3,) or not obs.is_contiguous():
+                raise RuntimeError('the imu output must be a contiguous (N, A, 3) float32 tensor')
+            x.imu, x.imu_ang_scale, x.imu_speed_scale = obs.data_ptr(), float(ang_scale), float(speed_scale)
+            used.append(obs)
+        _require_gpu(*used)
+        ex = C.byref(x)
     progress = torch.empty_like(agents.angles) if out is None else out.progress      # `out`: an earlier call's Physics
     with _on(dev):
-        _lib.check(_lib.lib().ms_move_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
-                                              mv, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
+        _lib.check(_lib.lib().ms_step_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
+                                              mv, ex, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
     agents._cached = agents._use_cache
     return Physics(progress) if out is None else out
 
@@ -412,7 +457,7 @@ def physics(scenery, agents, movement=None, out=None):
 FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
 
 
-def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None):
+def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None, seen=None):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
 
@@ -422,6 +467,10 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None)
     (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s)). ``out`` takes the :class:`Render` of an
     earlier call with the same arguments and writes into its tensors instead of allocating (the reference allocates
     five tensors per call, kernels.cu:461-469; a caller that consumes a frame before asking for the next need not).
+    ``pooled['centre']=True`` adds ``Render.obs_centre`` (n, a, 2) int32: the agent each of the two central observation
+    pixels shows, or -1 (all that Deathmatch reads from ``indices``). ``seen=(stamp, epoch, count)`` - int32 tensors
+    with one entry per texel, per env and per env - has the kernel do Explorer's first-sight bookkeeping: texels under
+    this frame's rays get their env's epoch as stamp, those that did not carry it yet are added to ``count``.
     ``telemetry=True`` (tests) takes the self-contained path whose scratch counters end up in ``Render._telemetry``."""
     dev = scenery._device()
     _agents_on(agents, dev)
@@ -429,7 +478,14 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None)
     if (n, a) != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery')
     cfg = _cfg()
-    key = (n, a, cfg.res, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), dev)
+    if seen is not None:
+        stamp, epoch, count = seen
+        if any(t.dtype != torch.int32 or not t.is_contiguous() for t in seen) or stamp.shape != (scenery.textures.vals.shape[0],) \
+                or epoch.shape != (n,) or count.shape != (n,):
+            raise RuntimeError('seen must be contiguous int32 tensors (stamp per texel, epoch per env, count per env)')
+        _require_gpu(*seen)
+    key = (n, a, cfg.res, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), dev,
+           None if seen is None else tuple(t.data_ptr() for t in seen))
     if out is not None:
         if getattr(out, '_key', None) != key:
             raise RuntimeError('`out` must come from a render call with the same shapes, fields and pooling')
@@ -437,6 +493,8 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None)
     else:
         result = _render_buffers(scenery, n, a, cfg.res, fields, pooled, dev)
         result._key = key
+        if seen is not None:
+            result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = (t.data_ptr() for t in seen)
     with _on(dev):
         use_cache = agents._cached and not telemetry
         _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
@@ -456,7 +514,7 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
         # planes back and patches `screen` - after any pooling. All planes then, and the caller pools.
         want, pooled = FIELDS, None
     sub, max_depth, w = 1, 1., r
-    n_rgb = n_depth = 0
+    n_rgb = n_depth = n_centre = 0
     if pooled is not None:
         sub, max_depth = int(pooled.get('subsample', 1)), float(pooled.get('max_depth', 10.))
         if sub < 1 or sub & (sub - 1) or 64 % sub or r % sub:
@@ -464,8 +522,9 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
         w = r//sub
         n_rgb = 3*n*a*w if pooled.get('rgb', True) else 0
         n_depth = n*a*w if pooled.get('depth', True) else 0
+        n_centre = 2*n*a if pooled.get('centre', False) else 0
     plane = n*a*r
-    sizes = [plane*(3 if f == 'screen' else 1) if f in want else 0 for f in FIELDS] + [n_rgb, n_depth]
+    sizes = [plane*(3 if f == 'screen' else 1) if f in want else 0 for f in FIELDS] + [n_rgb, n_depth, n_centre]
     sizes = [(x + 3) & ~3 for x in sizes]                                # keep every piece 16-byte aligned
     offs = [0]
     for x in sizes:
@@ -477,8 +536,10 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
     outs = [piece(i, (n, a, r, 3) if f == 'screen' else (n, a, r)) for i, f in enumerate(FIELDS)]
     if outs[0] is not None:
         outs[0] = outs[0].view(torch.int32)
-    obs_rgb, obs_depth = piece(5, (n, a, 3, w)), piece(6, (n, a, w))
-    result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None)
-    result._struct = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth)
+    obs_rgb, obs_depth, obs_centre = piece(5, (n, a, 3, w)), piece(6, (n, a, w)), piece(7, (n, a, 2))
+    if obs_centre is not None:
+        obs_centre = obs_centre.view(torch.int32)
+    result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None, obs_centre)
+    result._struct = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth, ptr(7))
     result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel; read by the tests
     return result

@@ -66,17 +66,24 @@ class Deathmatch:
 
     # -- pieces of a step ---------------------------------------------------------------------------------------
 
-    def _revive(self, who):
-        """Respawns the agents marked in the (n_floorplans, n_agents) mask at full health."""
-        self._respawn(who)
+    def _revive(self, who, respawn=True):
+        """Respawns the agents marked in the (n_floorplans, n_agents) mask at full health. ``respawn=False`` leaves
+        the respawn itself to the caller (the step hands it to the physics launch)."""
+        if respawn:
+            self._respawn(who)
         self._health.masked_fill_(who, 1.)
         self._damage.masked_fill_(who, 0.)
         return who.reshape(-1)
 
-    def _exchange_fire(self, line_indices):
-        """Updates health and damage from this frame's crosshairs; returns each agent's hits, the reward."""
+    def _exchange_fire(self, line_indices=None, centre=None):
+        """Updates health and damage from this frame's crosshairs; returns each agent's hits, the reward. The crosshairs
+        come either from the full-resolution hit lines or from the render kernel's two centre pixels per agent
+        (``centre`` (n_floorplans, n_agents, 2): the agent seen, or -1)."""
         c = self.core
-        self.matchings = crosshair_matrix(line_indices, len(c.scenery.model), c.n_agents, self._rgb.subsample)
+        if centre is not None:
+            self.matchings = (centre[..., None] == torch.arange(c.n_agents, device=centre.device)).any(-2)
+        else:
+            self.matchings = crosshair_matrix(line_indices, len(c.scenery.model), c.n_agents, self._rgb.subsample)
         dealt = self.matchings.sum(2).float()                # opponents in my crosshair
         taken = self.matchings.sum(1).float()                # crosshairs I am in
         where = c.agents.positions
@@ -86,9 +93,9 @@ class Deathmatch:
         return dealt.reshape(-1)
 
     def _look(self):
-        # pooled RGB-D straight from the render kernel; the crosshair only needs the line each ray landed on
-        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices',))
-        reward = self._exchange_fire(frame.indices)
+        # pooled RGB-D and who sits in whose crosshair, straight from the render kernel: no per-ray output is needed
+        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=(), centre=True)
+        reward = self._exchange_fire(frame.indices) if 'centre' not in frame else self._exchange_fire(centre=frame.centre)
         obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu(),
                               health=self._health.unsqueeze(-1).clone())
         return per_agent(obs), reward
@@ -103,8 +110,9 @@ class Deathmatch:
 
     @torch.no_grad()
     def step(self, decision):
-        reset = self._revive(self._health <= 0)              # the dead come back before anyone moves
-        self._mover(per_floorplan(decision, self.core.n_agents))
+        dead = self._health <= 0                             # the dead come back before anyone moves:
+        reset = self._revive(dead, respawn=False)            # respawn, movement, physics and the IMU reading are one launch
+        self._mover(per_floorplan(decision, self.core.n_agents), respawn=self._respawn.draw(dead), imu=self._imu)
         obs, reward = self._look()
         return arrdict.arrdict(obs=obs, reward=reward, reset=reset)
 

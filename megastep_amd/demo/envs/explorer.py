@@ -12,54 +12,53 @@ from ... import arrdict, core, cubicasa, dotdict, modules, scene
 EPISODE_SLACK = 200     # steps an agent gets on top of one per texel seen
 
 
+def texels_hit(scenery, frame):
+    """(n_envs, n_agents, 1, res) texel under each ray of a render result with ``indices`` and ``locations``; -1 for the
+    rays that missed (explorer.py:34-43). The render kernel works the same index out for itself when it keeps the
+    :class:`SeenTexels` books; this is the tensor-op statement of it."""
+    hit = frame.indices >= 0
+    line = (scenery.lines.starts[:, None, None, None] + frame.indices.clamp(min=0)).long()
+    width = scenery.textures.widths[line].float()
+    along = torch.min(torch.floor(width*frame.locations), width - 1)                 # explorer.py:38-41
+    texel = scenery.textures.starts[line].long() + torch.where(hit, along, torch.zeros_like(along)).long()
+    return torch.where(hit, texel, torch.full_like(texel, -1))
+
+
 class SeenTexels:
     """Which texels each env has seen since its last respawn, and how many.
 
     A texel counts as seen while its stamp equals its env's epoch; a respawn bumps the env's epoch, which forgets all
-    of its texels at once without touching them. ``claim`` settles which of several rays on one texel counts it. One
-    extra slot at the end of both arrays takes the rays that hit nothing."""
+    of its texels at once without touching them. The render kernel keeps the books as it shades (``cuda.render``'s
+    ``seen``): it stamps the texel under every ray and adds the ones that were not stamped yet to ``tally``."""
 
     def __init__(self, scenery, n_envs):
         device = scenery.textures.vals.device
         self.texel_env = scenery.lines.inverse[scenery.textures.inverse.long()].long()       # texel -> env
-        n_texels = len(self.texel_env)
-        self.nowhere = torch.tensor(n_texels, device=device)
         self.epoch = torch.ones(n_envs, dtype=torch.int32, device=device)
-        self.stamp = torch.zeros(n_texels + 1, dtype=torch.int32, device=device)
-        self.claim = torch.full((n_texels + 1,), -1, dtype=torch.long, device=device)
-        self.count = torch.zeros(n_envs, device=device)
-        self._scenery = scenery
+        self.stamp = torch.zeros(len(self.texel_env), dtype=torch.int32, device=device)
+        self.tally = torch.zeros(n_envs, dtype=torch.int32, device=device)
+        self._before = torch.zeros_like(self.tally)
 
-    def texels_hit(self, frame):
-        """(n_envs, n_agents, 1, res) texel under each ray of a render result; ``nowhere`` for the rays that missed."""
-        sc = self._scenery
-        hit = frame.indices >= 0
-        line = (sc.lines.starts[:, None, None, None] + frame.indices.clamp(min=0)).long()
-        width = sc.textures.widths[line].float()
-        along = torch.min(torch.floor(width*frame.locations), width - 1)                 # explorer.py:38-41
-        texel = sc.textures.starts[line].long() + torch.where(hit, along, torch.zeros_like(along)).long()
-        return torch.where(hit, texel, self.nowhere)
+    #: what a render call needs to keep the books
+    books = property(lambda self: (self.stamp, self.epoch, self.tally))
+    #: texels seen per env since its last respawn, as the reference's float potential
+    count = property(lambda self: self.tally.float())
 
-    def look(self, frame):
-        """Marks what ``frame`` shows as seen; returns how many texels each env saw for the first time."""
-        texel = self.texels_hit(frame).reshape(-1)
-        ray = torch.arange(len(texel), device=texel.device)
-        epoch = self.epoch.repeat_interleave(len(texel)//len(self.epoch))                 # of each ray's env
-        self.claim[texel] = ray                                                           # one of the rays on a texel wins
-        new = (self.claim[texel] == ray) & (self.stamp[texel] != epoch) & (texel != self.nowhere)
-        self.stamp[texel] = epoch
-        gained = new.view(len(self.epoch), -1).sum(1).float()
-        self.count = self.count + gained
-        return gained
+    def gained(self):
+        """How many texels each env saw for the first time since the last call (or its last respawn)."""
+        new = (self.tally - self._before).float()
+        self._before = self.tally.clone()
+        return new
 
     def forget(self, envs):
         """Envs marked in the bool mask start over."""
         self.epoch += envs.int()
-        self.count = self.count.masked_fill(envs, 0)
+        self.tally.masked_fill_(envs, 0)
+        self._before.masked_fill_(envs, 0)
 
     def mask(self):
         """Per texel: has its env seen it since the env's last respawn."""
-        return self.stamp[:-1] == self.epoch[self.texel_env]
+        return self.stamp == self.epoch[self.texel_env]
 
 
 class Explorer:
@@ -93,10 +92,11 @@ class Explorer:
         self._lengths.masked_fill_(which, 0)
 
     def _world(self, reset):
-        # pooled RGB-D straight from the render kernel; the reward only needs which texel each ray landed on
-        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=('indices', 'locations'))
+        # pooled RGB-D straight from the render kernel, which also keeps the books of the texels it sees: no per-ray
+        # output is needed at all
+        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=(), seen=self._memory.books)
         pixels = self.core.res//self._rgb.subsample
-        reward = (self._memory.look(frame)/pixels).masked_fill(reset, 0.)      # nothing for the frame after a respawn
+        reward = (self._memory.gained()/pixels).masked_fill(reset, 0.)         # nothing for the frame after a respawn
         obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu())
         return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
 
@@ -108,10 +108,13 @@ class Explorer:
 
     @torch.no_grad()
     def step(self, decision):
-        self._mover(decision)
+        # Who is over does not depend on this step's movement (explorer.py:83-90 moves first, then checks), so it is
+        # settled up front and the respawn rides in the physics launch, after the integration - as does the IMU reading.
         self._lengths += 1
         over = self._lengths >= self._memory.count + EPISODE_SLACK
-        self._restart(over)
+        self._mover(decision, respawn=self._respawner.draw(over.unsqueeze(-1), after=True), imu=self._imu)
+        self._memory.forget(over)
+        self._lengths.masked_fill_(over, 0)
         return self._world(over)
 
     def state(self, e=0):

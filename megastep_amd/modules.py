@@ -33,13 +33,22 @@ def _actionset(core, linear, angular):
     return arrdict.arrdict(velocity=linear/core.fps*velocity, angvelocity=angular/core.fps*angvelocity).to(core.device)
 
 
-def _move(core, actionset, actions, keep):
+def _move(core, actionset, actions, keep, respawn=None, imu=None):
     """The velocity update of both movement modules, then physics. On the GPU it is part of the physics launch
-    (cuda.physics' ``movement``); the tensor ops below are the same arithmetic, and what the reference runs."""
+    (cuda.physics' ``movement``) - as are, when the env hands them over, the respawn of the agents it wants respawned
+    (``respawn``: :meth:`RandomSpawns.draw`) and the IMU observation of the new state (``imu``: the :class:`IMU`
+    module, which then returns it from its next call). The tensor ops below are the same arithmetic, and what the
+    reference runs."""
     agents = core.agents
     if agents.angles.is_cuda:
         table = torch.cat([actionset.velocity, actionset.angvelocity[:, None]], 1).contiguous()
-        return cuda.physics(core.scenery, agents, movement=(actions.long().contiguous(), table, keep))
+        reading = None if imu is None else (torch.empty(agents.angles.shape + (3,), device=core.device), imu.ang_scale, imu.speed_scale)
+        result = cuda.physics(core.scenery, agents, movement=(actions.long().contiguous(), table, keep), respawn=respawn, imu=reading)
+        if imu is not None:
+            imu._pending = reading[0]
+        return result
+    if respawn is not None and not respawn['after']:
+        _respawn(agents, respawn)
     delta = actionset[actions.long()]
     if keep == 0:
         agents.angvelocity[:] = delta.angvelocity
@@ -47,7 +56,21 @@ def _move(core, actionset, actions, keep):
     else:
         agents.angvelocity[:] = keep*agents.angvelocity + delta.angvelocity
         agents.velocity[:] = keep*agents.velocity + to_global_frame(agents.angles, delta.velocity)
-    return cuda.physics(core.scenery, agents)
+    result = cuda.physics(core.scenery, agents)
+    if respawn is not None and respawn['after']:
+        _respawn(agents, respawn)
+    return result
+
+
+def _respawn(agents, request):
+    """Applies a :meth:`RandomSpawns.draw` request with tensor ops (what the kernel does inside the physics launch)."""
+    reset, choices = request['mask'], request['choices']
+    angles = request['angles'].gather(2, choices[..., None]).squeeze(2)
+    positions = request['positions'].gather(2, choices[..., None, None].expand(-1, -1, 1, 2)).squeeze(2)
+    agents.angles[:] = torch.where(reset, angles, agents.angles)
+    agents.positions[:] = torch.where(reset[..., None], positions, agents.positions)
+    agents.velocity[:] = torch.where(reset[..., None], torch.zeros_like(agents.velocity), agents.velocity)
+    agents.angvelocity[:] = torch.where(reset, torch.zeros_like(agents.angvelocity), agents.angvelocity)
 
 
 class SimpleMovement:
@@ -59,9 +82,10 @@ class SimpleMovement:
         self._actionset = _actionset(core, speed, ang_speed)
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
-    def __call__(self, decision):
-        """Sets the agents' velocities from ``decision.actions`` ((n_env, n_agent) ints in 0..6), then steps physics."""
-        return _move(self.core, self._actionset, decision.actions, 0.)
+    def __call__(self, decision, respawn=None, imu=None):
+        """Sets the agents' velocities from ``decision.actions`` ((n_env, n_agent) ints in 0..6), then steps physics.
+        ``respawn`` / ``imu``: see :func:`_move`."""
+        return _move(self.core, self._actionset, decision.actions, 0., respawn, imu)
 
 
 class MomentumMovement:
@@ -74,8 +98,8 @@ class MomentumMovement:
         self.decay = decay
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
-    def __call__(self, decision):
-        return _move(self.core, self._actionset, decision.actions, 1 - self.decay)
+    def __call__(self, decision, respawn=None, imu=None):
+        return _move(self.core, self._actionset, decision.actions, 1 - self.decay, respawn, imu)
 
 
 def unpack(d):
@@ -85,14 +109,16 @@ def unpack(d):
     return arrdict.arrdict({k: unpack(getattr(d, k)) for k in dir(d) if not k.startswith('_')})
 
 
-def render(core, observers=None, fields=None):
+def render(core, observers=None, fields=None, centre=False, seen=None):
     """Calls :func:`cuda.render` and reshapes for torch convs: every field gets a height-1 axis, ``screen`` becomes
     (n_env, n_agent, 3, 1, res) (reference: modules.py:126-136).
 
     Beyond the reference: pass the :class:`RGB` / :class:`Depth` modules that will consume the result as ``observers``
     and their mean-pooled observations come straight out of the render kernel (they pick them up from the result
     instead of running a chain of tensor ops over the full-resolution outputs), and name in ``fields`` the
-    full-resolution outputs that are still needed (default: all five) - the others are not even written."""
+    full-resolution outputs that are still needed (default: all five) - the others are not even written.
+    ``centre=True`` adds ``centre`` (n_env, n_agent, 2): the agent in each of the two central observation pixels, or -1
+    (needs observers); ``seen`` is passed on to :func:`cuda.render` (first-sight texel bookkeeping)."""
     pooled = None
     if observers:
         subs = {o.subsample for o in observers}
@@ -100,8 +126,8 @@ def render(core, observers=None, fields=None):
         if len(subs) != 1 or len({o.max_depth for o in depth}) > 1:
             raise ValueError('observers of one render must share their subsample and max_depth')
         pooled = dict(subsample=subs.pop(), max_depth=depth[0].max_depth if depth else 10.,
-                      rgb=any(isinstance(o, RGB) for o in observers), depth=bool(depth))
-    raw = cuda.render(core.scenery, core.agents, fields=fields, pooled=pooled)
+                      rgb=any(isinstance(o, RGB) for o in observers), depth=bool(depth), centre=bool(centre))
+    raw = cuda.render(core.scenery, core.agents, fields=fields, pooled=pooled, seen=seen)
     r = arrdict.arrdict({k: getattr(raw, k).unsqueeze(2) for k in cuda.FIELDS if getattr(raw, k) is not None})
     if 'screen' in r:
         r['screen'] = r.screen.permute(0, 1, 4, 2, 3)
@@ -112,6 +138,8 @@ def render(core, observers=None, fields=None):
         if raw.obs_depth is not None:
             r['pooled_depth'] = raw.obs_depth.unsqueeze(2).unsqueeze(3)      # (n_env, n_agent, 1, 1, res/subsample)
             r['pooled_max_depth'] = pooled['max_depth']
+        if raw.obs_centre is not None:
+            r['centre'] = raw.obs_centre
     return r
 
 
@@ -172,8 +200,12 @@ class IMU:
         self.space = spaces.MultiVector(n_agents or core.n_agents, 3)
         self.speed_scale = speed_scale
         self.ang_scale = ang_scale
+        self._pending = None        # a reading the physics launch has already taken of the current state (see _move)
 
     def __call__(self):
+        if self._pending is not None:
+            reading, self._pending = self._pending, None
+            return reading
         agents = self.core.agents
         return torch.cat([
             agents.angvelocity[..., None]/self.ang_scale,
@@ -233,19 +265,19 @@ class RandomSpawns:
         angles = core.random.uniform(-180, +180, (len(geometries), core.n_agents, n_spawns))
         self._spawns = arrdict.torchify(arrdict.arrdict(positions=positions, angles=angles)).to(core.device)
 
+    def draw(self, reset, after=False):
+        """The respawn of the agents marked in the (n_env, n_agent) bool mask ``reset`` as a request that
+        :func:`cuda.physics` (through the movement modules' ``respawn=``) carries out inside its launch - before the
+        step, or after it with ``after=True``. Same draw as :meth:`__call__`."""
+        choices = torch.randint(0, self._spawns.angles.shape[1], reset.shape, device=reset.device)
+        return dict(mask=reset.contiguous(), choices=choices, positions=self._spawns.positions, angles=self._spawns.angles, after=after)
+
     def __call__(self, reset):
         """``reset`` is an (n_env, n_agent) bool mask; the marked agents get a new pose and zero velocity.
 
         Same draw as the reference (a uniform choice among the first ``spawns.shape[1]`` spawn points), but made for
         every agent and applied through the mask, so the step needs no ``nonzero`` and with it no host sync."""
-        agents = self.core.agents
-        choices = torch.randint(0, self._spawns.angles.shape[1], reset.shape, device=reset.device)
-        angles = self._spawns.angles.gather(2, choices[..., None]).squeeze(2)
-        positions = self._spawns.positions.gather(2, choices[..., None, None].expand(-1, -1, 1, 2)).squeeze(2)
-        agents.angles[:] = torch.where(reset, angles, agents.angles)
-        agents.positions[:] = torch.where(reset[..., None], positions, agents.positions)
-        agents.velocity[:] = torch.where(reset[..., None], torch.zeros_like(agents.velocity), agents.velocity)
-        agents.angvelocity[:] = torch.where(reset, torch.zeros_like(agents.angvelocity), agents.angvelocity)
+        _respawn(self.core.agents, self.draw(reset))
 
 
 class RandomLifespans:
