@@ -892,6 +892,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
     float nearest_s = INFINITY;
     int nearest_idx = -1;
+    bool s_is_approximate = false;               // IMPL 2 with MS_V2_OPTS bit 2: nearest_s awaits its exact quotient
 
     if constexpr (IMPL == 1) {
         // ------------------------------------------------------------------------------------------
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                                 const bool won = key < old;
                                 const float so = bits_f(oh);
                                 const float front = won ? sv : so, back = won ? so : sv;
-                                if (!(front < back - 1.e-4f)) s_third_w[rr] = 0ull;
+                                if (!(front < back - 1.e-4f)) atomicMin(&s_third_w[rr], (unsigned long long)f_bits(front));
                             }
                         } else {
                         // keep the three smallest keys: whatever loses at one level drops to the next
@@ -1009,7 +1010,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         if (((MS_V1_OPTS & 2) != 0) && best != ~0ull) {
             nearest_s = bits_f((uint32_t)(best >> 32));
             nearest_idx = (int)(uint32_t)best;
-            ambiguous = third == 0ull;
+            ambiguous = third == (best >> 32);
         } else if (best != ~0ull) {
             const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
             const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
@@ -1124,18 +1125,23 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         //  * a line marks the bit of its first pair in an LDS bit vector; a window's 64 mark bits M are one
         //    broadcast read, and the line that owns pair q of the window is (#marks before the window) +
         //    popcount(M & bits 0..q) - 1: two mbcnt instructions instead of a marks array and a DPP max-scan;
-        //  * ONE 64-bit LDS atomicMin per hit.  Its return value is the ray's previous best, so the lane sees the
-        //    loser of that merge; if the loser is not clearly behind the winner (not `winner < loser - 1e-4f`, the
-        //    reference's comparison) the ray is flagged.  For an unflagged ray every hit k other than the final
-        //    minimum b met, at the moment the later of the two arrived, either b itself or something no farther
-        //    than k as the other party, so s_b < s_k - 1e-4f for all k: the fold takes b when it reaches it (its
-        //    state is inf or some s_k) and nothing after b can pass `s < s_b - 1e-4f`.  Flagged rays (a ray
-        //    through a shared wall corner, coincident walls) take the literal sequential fold below.
+        //  * ONE 64-bit LDS atomicMin per hit.  Its return value is the ray's previous best, so the lane sees both
+        //    parties of that merge; if the loser is not clearly behind the winner (not `winner < loser - 1e-4f`, the
+        //    reference's comparison) the WINNER's s is min-ed into the ray's doubt slot.  At the end a ray is in
+        //    doubt iff its doubt slot equals its best s.  Why that is exact: let b be the final minimum.  Any hit k
+        //    that is not clearly behind b was merged, when the later of the two arrived, against b itself (k later)
+        //    or b against something no farther than k (b later) - either way a close merge won by b, which puts
+        //    s_b, the smallest value there is, into the slot.  Conversely, with no close merge won by b every other
+        //    hit has s_b < s_k - 1e-4f: the fold takes b when it reaches it (its state is inf or some s_k) and nothing
+        //    after b can pass `s < s_b - 1e-4f`.  Close merges among hits that end up behind b (coincident walls
+        //    hidden behind a nearer one: about one ray per wave on the benchmark) leave a larger value and do not
+        //    count.  Rays in doubt (coincident visible walls, a ray through a shared corner) take the literal
+        //    sequential fold below.
         //  * a line with an end behind the near clip plane is not clipped: its interval runs from the visible
         //    end's ray to the edge of the fan on the side it leaves by - the sign of cross(a, b).  (Clipping would
         //    only give less when the crossing is within centimetres of the agent.)
-        // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first pair << 6 | first ray, line)
-        //               3072 ray (64 x 16 B)    | 4096 best (64 x 8 B) | 4608 marks (4096 bits) | 5120 flags (64 x 4 B)
+        // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first ray - first pair, line)
+        //               3072 ray (64 x 16 B)    | 4096 best (64 x 8 B) | 4608 marks (4096 bits) | 5120 doubt slots (64 x 4 B)
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = 128, P_CAP = 4096;
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][2048]);
@@ -1146,7 +1152,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
         s_best_w[lane] = ~0ull;
         s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
-        s_flag_w[lane] = 0u;
+        s_flag_w[lane] = 0xffffffffu;                         // the doubt slot: least s that won a close merge
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection, and the conservative
         // interval [lo, lo + len) of this wave's rays that can hit it
@@ -1186,10 +1192,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const int upto = (int)(mlo & 1u) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(Ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Ms, 0u));
                 const int p = p0 + lane;
                 const bool valid = p < n_pairs;
-                const int k = valid ? before + upto - 1 : 0;
+                const int k = before + upto - 1;             // (past the last pair there are no marks: the last line, harmless)
                 before += __popcll(M);
                 const int2 info = s_info_w[k];
-                const int rr = valid ? (info.x & 63) + (p - (info.x >> 6)) : 0;   // ray of this pair, wave-local
+                const int rr = (p + info.x) & 63;            // ray of this pair, wave-local (in range as it is for valid pairs)
                 const Cand cd = s_cand_w[k];
                 const float4 ray = s_ray_w[rr];
                 const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
@@ -1199,8 +1205,27 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked)
                 const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
                 if (hit) {
-                    const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
-                    if (ray.z < sv) {                                        // beyond the near plane, kernels.cu:369
+                    const float num = cd.pqx*cd.vy - cd.pqy*cd.vx;           // cross(PQ, V)
+                    float sv;
+                    bool beyond;
+                    if constexpr ((MS_V2_OPTS & 4) != 0) {
+                        // s = num/d to within 3 parts in 10^7 from the reciprocal; the quotient itself only where the
+                        // near-plane test would not be safe without it.  Keys, and with them the close-merge test
+                        // below, then run on approximate s - with the band widened to cover it - and the winner's
+                        // exact s is worked out once per ray after the fold.
+                        sv = num*__builtin_amdgcn_rcpf(d);
+                        const bool doubtful = fabsf(sv - ray.z) <= 1e-6f*ray.z;
+                        if (__builtin_amdgcn_ballot_w64(doubtful) != 0ull) {  // uniform, and rare
+                            float dd = d;
+                            asm volatile("" : "+v"(dd));                     // (else hipcc divides everywhere and selects)
+                            if (doubtful) sv = num/dd;
+                        }
+                        beyond = ray.z < sv;
+                    } else {
+                        sv = num/d;                                          // q.s = cross(PQ, V)/UxV
+                        beyond = ray.z < sv;                                 // beyond the near plane, kernels.cu:369
+                    }
+                    if (beyond) {
                         const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)info.y;
                         const unsigned long long old = atomicMin(&s_best_w[rr], key);
                         const unsigned oh = (unsigned)(old >> 32);
@@ -1208,7 +1233,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                             const bool won = key < old;
                             const float so = bits_f(oh);
                             const float front = won ? sv : so, back = won ? so : sv;
-                            if (!(front < back - 1.e-4f)) s_flag_w[rr] = 1u;
+                            bool clear;
+                            if constexpr ((MS_V2_OPTS & 4) != 0) clear = front < back*(1.f - 2e-6f) - 1.01e-4f;
+                            else clear = front < back - 1.e-4f;
+                            if (!clear) atomicMin(&s_flag_w[rr], f_bits(front));
                         }
                     }
                 }
@@ -1234,7 +1262,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
                 const int first = n_pairs + incl - len;                      // this line's first pair
                 s_cand_w[k] = cd;
-                s_info_w[k] = make_int2((first << 6) | (lo & 63), c0 + lane);
+                s_info_w[k] = make_int2(lo - first, c0 + lane);                 // pair p of the list is ray p + (lo - first)
                 atomicOr(&s_mark_w[first >> 5], 1u << (first & 31));
             }
             n_list += chunk_lines; n_pairs += chunk_pairs;
@@ -1243,10 +1271,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long best = s_best_w[lane];
-        const bool ambiguous = s_flag_w[lane] != 0u;
+        const bool ambiguous = (best != ~0ull) & (s_flag_w[lane] == (unsigned)(best >> 32));
         if (best != ~0ull) {
             nearest_s = bits_f((uint32_t)(best >> 32));
             nearest_idx = (int)(uint32_t)best;
+            s_is_approximate = (MS_V2_OPTS & 4) != 0;
         }
         // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1
         const unsigned long long amb = __ballot(ambiguous);
@@ -1289,7 +1318,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     }
                 }
             }
-            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; s_is_approximate = false; }
         } else if (amb) {
             float x = INFINITY;
             int xi = -1;
@@ -1328,7 +1357,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     }
                 }
             }
-            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; s_is_approximate = false; }
         }
     } else {
         for (int c0 = 0; c0 < L; c0 += WAVE) {
@@ -1424,6 +1453,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const float d = rx*vy - ry*vx;
         const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
         loc = (pqx*ry - pqy*rx)/d;
+        if (s_is_approximate) nearest_s = (pqx*vy - pqy*vx)/d;              // q.s = cross(PQ, V)/UxV, as the fold computes it
         const float dtop = rx*vx + ry*vy;
         const float dbot = rlen*sqrtf(vx*vx + vy*vy);
         dt = dtop/(dbot + 1.e-6f);

@@ -469,3 +469,27 @@ def test_heading_cache_is_used_only_while_it_is_true():
     ref = util.OracleWorld(c)
     ref.pull_baked(c); ref.pull_agents(c)
     util.assert_render_matches(c, fresh, ref.render())
+
+
+def test_outputs_can_be_reused_between_calls():
+    """cuda.render / cuda.physics write into the tensors of an earlier call's result when given it as `out` (the
+    benchmark's hot path does, so that nothing is allocated per step): same values as fresh calls, same objects."""
+    from megastep_amd import cuda
+    c, _ = _world(6, 3, 64, 110, seed=4)
+    rng = np.random.RandomState(0)
+    held_p = held_r = None
+    for step in range(3):
+        util.random_velocities(c, rng)
+        twin = cuda.Agents(*(t.clone() for t in (c.agents.angles, c.agents.positions, c.agents.angvelocity, c.agents.velocity)))
+        p_fresh = cuda.physics(c.scenery, twin)
+        r_fresh = cuda.render(c.scenery, twin)
+        p = cuda.physics(c.scenery, c.agents, out=held_p)
+        r = cuda.render(c.scenery, c.agents, out=held_r)
+        assert held_p is None or (p is held_p and r is held_r)
+        held_p, held_r = p, r
+        assert torch.equal(p.progress, p_fresh.progress)
+        for k in cuda.FIELDS:
+            a, b = getattr(r, k), getattr(r_fresh, k)
+            assert torch.equal(torch.nan_to_num(a.float(), nan=-7.), torch.nan_to_num(b.float(), nan=-7.)), k
+    with pytest.raises(RuntimeError, match='same shapes'):
+        cuda.render(c.scenery, c.agents, fields=('indices',), out=held_r)
