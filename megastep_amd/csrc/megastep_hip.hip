@@ -220,16 +220,21 @@ constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
 // EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
-template <int MOVE, int EXTRA>
-__global__ __launch_bounds__(WAVE) void physics_kernel(
+// WPB = envs (= independent wavefronts) per workgroup; the dynamic LDS holds WPB slices of `slice` float4s
+template <int MOVE, int EXTRA, int WPB>
+__global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex) {
-    extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
-    __shared__ float4 s_wall[WAVE];              // walls near ...
-    __shared__ int s_tag[WAVE];                  // ... this agent
+        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex, const int slice) {
+    extern __shared__ float4 s_dyn_all[];        // per agent: (p, v/fps) | reach box | reach^2 | progress bits
+    __shared__ float4 s_wall_all[WPB][WAVE];     // walls near ...
+    __shared__ int s_tag_all[WPB][WAVE];         // ... this agent
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int lane = threadIdx.x;
-    const int n = blockIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int n = blockIdx.x*WPB + wv;
+    if (n >= sc.n_envs) return;                  // waves are independent: no workgroup barriers below
+    float4* const s_dyn = s_dyn_all + (size_t)wv*slice;
+    float4* const s_wall = s_wall_all[wv];
+    int* const s_tag = s_tag_all[wv];
     float4* s_task = s_dyn;
     float4* s_box = s_task + A;
     float* s_reach2 = reinterpret_cast<float*>(s_box + A);
@@ -2304,20 +2309,25 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
         if (ex->lifespans && (!ex->max_lifespans || !ex->fresh_max)) return MS_EINVAL;
         if (ex->imu && !(ex->imu_ang_scale == ex->imu_ang_scale && ex->imu_speed_scale == ex->imu_speed_scale)) return MS_EINVAL;
     }
-    const size_t shmem = (sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents;
-    if (shmem > 60*1024) return MS_EUNSUPPORTED;
+    // per env: 2 float4 + a float + an unsigned per agent, rounded up to whole float4s
+    const size_t slice = ((sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents + 15)/16;
+    if (slice*16 > 60*1024) return MS_EUNSUPPORTED;
     const MsMovement no_move{nullptr, nullptr, 0, 0.f};
     const MsStepExtras no_extras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
-    const dim3 grid(sc->n_envs), block(WAVE);
+    const MsMovement mvv = mv ? *mv : no_move;
+    const MsStepExtras exv = ex ? *ex : no_extras;
     const hipStream_t hs = (hipStream_t)stream;
-    if (mv && ex)
-        hipLaunchKernelGGL((physics_kernel<1, 1>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, *mv, *ex);
-    else if (ex)
-        hipLaunchKernelGGL((physics_kernel<0, 1>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, no_move, *ex);
-    else if (mv)
-        hipLaunchKernelGGL((physics_kernel<1, 0>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, *mv, no_extras);
-    else
-        hipLaunchKernelGGL((physics_kernel<0, 0>), grid, block, shmem, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, no_move, no_extras);
+    // MEGASTEP_PHYS_WPB=4: four envs per workgroup (A/B knob; the waves stay independent either way)
+    const char* wpb_env = getenv("MEGASTEP_PHYS_WPB");
+    const bool four = wpb_env && wpb_env[0] == '4' && slice*16*4 <= 60*1024;
+#define MS_LAUNCH_PHYSICS(M, E) \
+    do { if (four) hipLaunchKernelGGL((physics_kernel<M, E, 4>), dim3((sc->n_envs + 3)/4), dim3(4*WAVE), slice*16*4, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); \
+         else hipLaunchKernelGGL((physics_kernel<M, E, 1>), dim3(sc->n_envs), dim3(WAVE), slice*16, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); } while (0)
+    if (mv && ex) MS_LAUNCH_PHYSICS(1, 1);
+    else if (ex) MS_LAUNCH_PHYSICS(0, 1);
+    else if (mv) MS_LAUNCH_PHYSICS(1, 0);
+    else MS_LAUNCH_PHYSICS(0, 0);
+#undef MS_LAUNCH_PHYSICS
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }

@@ -1,0 +1,86 @@
+"""Per-section cycle counters (s_memtime) of render_kernel<2,1,*>: builds scratch/probe2.so with the counters written over
+out.distances (lanes 0-7 of every ray group = sections, lanes 8-11 = pairs, windows, chunks with visible lines, drains),
+runs it on the benchmark world and prints the breakdown. Results of the probed render are garbage by design.
+usage: python tools/probe_v2.py [build|run|both]"""
+import os, subprocess, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build():
+    src = open(f'{root}/megastep_amd/csrc/megastep_hip.hip').read()
+    i2 = src.index("    } else if constexpr (IMPL == 2) {")
+
+    def rep(old, new, start=0):
+        nonlocal src
+        k = src.index(old, start)
+        src = src[:k] + new + src[k + len(old):]
+    rep("    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w",
+        "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_vis_ = 0, n_drain_ = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w")
+    i2 = src.index("    } else if constexpr (IMPL == 2) {")
+    rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(2) n_drain_++;\n", i2)
+    rep("            // the list starts over\n", "            TICK(3)\n            // the list starts over\n", i2)
+    rep("        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            Cand cd;\n            int lo = 0, len = 0;\n            line_setup2(c0, cd, lo, len);\n",
+        "        TICK(0)\n        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            Cand cd;\n            int lo = 0, len = 0;\n            line_setup2(c0, cd, lo, len);\n            TICK(1)\n", i2)
+    rep("            if (!vm) continue;                                               // uniform\n", "            if (!vm) continue;                                               // uniform\n            n_vis_++;\n", i2)
+    rep("        if (n_pairs) drain();\n", "        TICK(2)\n        if (n_pairs) drain();\n", i2)
+    rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(4)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
+    rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(5)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
+    rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(6)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
+    # telemetry variables of IMPL 2 are local to its branch: export them through function-scope shadows
+    rep("    bool s_is_approximate = false;", "    bool s_is_approximate = false; int probe_pairs_ = 0, probe_windows_ = 0;")
+    i2 = src.index("    } else if constexpr (IMPL == 2) {")
+    rep("        // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1\n", "        probe_pairs_ = n_pairs_total; probe_windows_ = n_windows;\n        // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1\n", i2)
+    assert src.count("    // ---- pooled observations") == 1
+    src = src.replace("    // ---- pooled observations", """    TICK(7)
+    {
+        int v = 0;
+        #pragma unroll
+        for (int k = 0; k < 8; k++) if (lane == k) v = (int)T_[k];
+        if (lane == 8) v = probe_pairs_; if (lane == 9) v = probe_windows_; if (lane == 10) v = n_vis_; if (lane == 11) v = n_drain_;
+        if (lane < 12) reinterpret_cast<int*>(out.distances)[((size_t)n*A + a)*R + g*WAVE + lane] = v;
+    }
+    // ---- pooled observations""", 1)
+    os.makedirs(f'{root}/scratch', exist_ok=True)
+    open(f'{root}/scratch/probe2.hip', 'w').write(src.replace('../../include/megastep_hip.h', 'megastep_hip.h'))
+    flags = '--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize'.split()
+    subprocess.check_call(['/opt/rocm/bin/hipcc', *flags, f'-I{root}/include', '-o', f'{root}/scratch/probe2.so', f'{root}/scratch/probe2.hip'])
+    print('built scratch/probe2.so')
+
+
+def run():
+    os.environ['MEGASTEP_HIP_LIB'] = f'{root}/scratch/probe2.so'
+    os.environ['MEGASTEP_RENDER_IMPL'] = 'v2'
+    sys.path.insert(0, root)
+    import numpy as np, torch, bench
+    from megastep_amd import cuda, modules
+    N, A, R = 4096, 4, 64
+    core, _ = bench.build_world(N, A, R, 130., torch.device('cuda'), seed=1)
+    mover = modules.MomentumMovement(core)
+
+    class D:
+        pass
+    acc, cnt = np.zeros(12), 0
+    for i in range(60):
+        D.actions = torch.randint(0, 7, (N, A), device='cuda')
+        mover(D)
+        r = cuda.render(core.scenery, core.agents)
+        if i >= 40:
+            d = r.distances.reshape(N*A, R)[:, :12].contiguous().view(torch.int32).double()
+            acc += d.mean(0).cpu().numpy(); cnt += 1
+            if i == 59:
+                tot = d[:, :8].sum(1)
+                print('per-wave total cycles: mean %.0f  p50 %.0f p90 %.0f p99 %.0f max %.0f' % (tot.mean().item(), *[torch.quantile(tot, q).item() for q in (.5, .9, .99)], tot.max().item()))
+    acc /= cnt
+    names = ['prologue', 'pass1 line_setup', 'scan+compaction', 'pass2 windows', 'resolve+fold', 'loc/dot+out', 'lighting', 'shade+store',
+             'pairs', 'windows', 'chunks with visible lines', 'drains']
+    tot = acc[:8].sum()
+    for n, v in zip(names, acc):
+        print('%-26s %10.1f  %s' % (n, v, '%.1f%%' % (100*v/tot) if names.index(n) < 8 else ''))
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'both'
+    if what in ('build', 'both'):
+        build()
+    if what in ('run', 'both'):
+        run()
