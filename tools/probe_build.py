@@ -11,7 +11,7 @@ rep("    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Can
     "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int Psum = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w")
 rep("        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            line_setup(c0, lo, len);\n            const int incl = wave_scan_add(len);",
     "        TICK(0)\n        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            line_setup(c0, lo, len);\n            TICK(1)\n            const int incl = wave_scan_add(len);")
-rep("            s_info_w[lane] = (first << 6) | (lo & 63);\n            int carry = -1;", "            s_info_w[lane] = (first << 6) | (lo & 63);\n            int carry = -1;\n            TICK(2)\n            Psum += P;")
+rep("            n_pairs_total += P; n_windows += (P + WAVE - 1)/WAVE;\n            int carry = -1;", "            n_pairs_total += P; n_windows += (P + WAVE - 1)/WAVE;\n            int carry = -1;\n            TICK(2)\n            Psum += P;")
 rep("                __builtin_amdgcn_wave_barrier();\n            }\n            __builtin_amdgcn_wave_barrier();\n        }\n        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        const unsigned long long best",
     "                __builtin_amdgcn_wave_barrier();\n            }\n            __builtin_amdgcn_wave_barrier();\n            TICK(3)\n        }\n        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        const unsigned long long best")
 rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(4)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
@@ -29,6 +29,6 @@ src = src.replace("    // ---- pooled observations", """    TICK(7)
     // ---- pooled observations""", 1)
 os.makedirs(f'{root}/scratch', exist_ok=True)
 open(f'{root}/scratch/probe.hip', 'w').write(src.replace('../../include/megastep_hip.h', 'megastep_hip.h'))
-flags = '--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero'.split()
+flags = '--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize'.split()
 subprocess.check_call(['/opt/rocm/bin/hipcc', *flags, f'-I{root}/include', '-o', f'{root}/scratch/probe.so', f'{root}/scratch/probe.hip'])
 print('built scratch/probe.so')

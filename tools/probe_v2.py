@@ -70,6 +70,12 @@ def run():
             if i == 59:
                 tot = d[:, :8].sum(1)
                 print('per-wave total cycles: mean %.0f  p50 %.0f p90 %.0f p99 %.0f max %.0f' % (tot.mean().item(), *[torch.quantile(tot, q).item() for q in (.5, .9, .99)], tot.max().item()))
+                lines = core.scenery.lines.widths.repeat_interleave(A).double()
+                slow = tot >= torch.quantile(tot, .99)
+                print('slowest 1%% of the waves: mean sections', d[slow].mean(0).cpu().numpy().round(0).tolist(), 'lines/env %.0f vs %.0f overall' % (lines[slow].mean().item(), lines.mean().item()))
+                worst = tot.argmax()
+                print('the slowest wave:', d[worst].cpu().numpy().round(0).tolist(), 'lines', lines[worst].item())
+                print('corr(total, lines) %.2f  corr(total, pairs) %.2f' % (torch.corrcoef(torch.stack([tot, lines]))[0, 1].item(), torch.corrcoef(torch.stack([tot, d[:, 8]]))[0, 1].item()))
     acc /= cnt
     names = ['prologue', 'pass1 line_setup', 'scan+compaction', 'pass2 windows', 'resolve+fold', 'loc/dot+out', 'lighting', 'shade+store',
              'pairs', 'windows', 'chunks with visible lines', 'drains']
