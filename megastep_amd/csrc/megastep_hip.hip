@@ -674,6 +674,7 @@ __device__ inline float grid_light_intensity(
 //   MS_V1_OPTS  bit 0: IMPL 1 takes IMPL 2's interval arithmetic (no clipping); bit 1: IMPL 1 takes IMPL 2's single
 //               atomic + hysteresis flag instead of the three-slot cascade
 //   MS_V2_OPTS  bit 0: IMPL 2 drains its list after every chunk; bit 1: IMPL 2 clips like IMPL 1
+//               (tried and dropped: keys from v_rcp_f32 with the exact quotient once per ray - correct, not faster)
 #ifndef MS_V1_OPTS
 #define MS_V1_OPTS 0
 #endif
@@ -804,8 +805,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     //   3584 info   (64 x 4 B)   per line: (first pair << 6) | first ray
     //   3840 mark   (64 x 4 B)   pair window: which line starts here
     //   4096 screen (192 x 4 B)  RGB staging
-    // IMPL 2 lays its block out differently (see there): 5376 B
-    constexpr int LDS_PER_WAVE = IMPL == 2 ? 5376 : 4864;
+    // IMPL 2 lays its block out differently (see there): 6144 B
+    constexpr int LDS_PER_WAVE = IMPL == 2 ? 6144 : 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -829,6 +830,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
+    // IMPL 2 asks for the first chunk of lines before anything else: nothing below needs it until the raycast
+    float4 w_first = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (IMPL == 2) {
+        if ((lane < L) & (lane >= sc.n_agents*sc.n_model)) w_first = ln[lane];
+    }
 
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
     // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
@@ -897,7 +903,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
     float nearest_s = INFINITY;
     int nearest_idx = -1;
-    bool s_is_approximate = false;               // IMPL 2 with MS_V2_OPTS bit 2: nearest_s awaits its exact quotient
 
     if constexpr (IMPL == 1) {
         // ------------------------------------------------------------------------------------------
@@ -1130,42 +1135,44 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         //  * a line marks the bit of its first pair in an LDS bit vector; a window's 64 mark bits M are one
         //    broadcast read, and the line that owns pair q of the window is (#marks before the window) +
         //    popcount(M & bits 0..q) - 1: two mbcnt instructions instead of a marks array and a DPP max-scan;
-        //  * ONE 64-bit LDS atomicMin per hit.  Its return value is the ray's previous best, so the lane sees both
-        //    parties of that merge; if the loser is not clearly behind the winner (not `winner < loser - 1e-4f`, the
-        //    reference's comparison) the WINNER's s is min-ed into the ray's doubt slot.  At the end a ray is in
-        //    doubt iff its doubt slot equals its best s.  Why that is exact: let b be the final minimum.  Any hit k
-        //    that is not clearly behind b was merged, when the later of the two arrived, against b itself (k later)
-        //    or b against something no farther than k (b later) - either way a close merge won by b, which puts
-        //    s_b, the smallest value there is, into the slot.  Conversely, with no close merge won by b every other
-        //    hit has s_b < s_k - 1e-4f: the fold takes b when it reaches it (its state is inf or some s_k) and nothing
-        //    after b can pass `s < s_b - 1e-4f`.  Close merges among hits that end up behind b (coincident walls
-        //    hidden behind a nearer one: about one ray per wave on the benchmark) leave a larger value and do not
-        //    count.  Rays in doubt (coincident visible walls, a ray through a shared corner) take the literal
-        //    sequential fold below.
+        //  * ONE 64-bit LDS atomicMin per hit in the normal case.  Its return value is the ray's previous best, so
+        //    the lane sees both parties of that merge; only when the loser is NEAR the winner (within 4e-4 of it:
+        //    a few hits in a hundred) does it go on into the runner-up and third slots as in IMPL 1.  That is enough
+        //    for IMPL 1's resolution to come out the same: every hit but the final best b loses exactly one merge,
+        //    to a winner no nearer than b, so every hit within 3e-4 of s_b reaches the slots; the resolution only
+        //    ever asks whether the runner-up is within 1e-4 of b and the third within 1e-4 of the runner-up, and
+        //    whatever is missing from the slots is farther than that from either.
         //  * a line with an end behind the near clip plane is not clipped: its interval runs from the visible
         //    end's ray to the edge of the fan on the side it leaves by - the sign of cross(a, b).  (Clipping would
         //    only give less when the crossing is within centimetres of the agent.)
         // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first ray - first pair, line)
-        //               3072 ray (64 x 16 B)    | 4096 best (64 x 8 B) | 4608 marks (4096 bits) | 5120 doubt slots (64 x 4 B)
+        //               3072 ray (64 x 16 B)    | 4096 best, 4608 second, 5120 third (64 x 8 B each) | 5632 marks (4096 bits)
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = 128, P_CAP = 4096;
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][2048]);
         float4* const s_ray_w = reinterpret_cast<float4*>(&s_raw[wave][3072]);
         unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4096]);
-        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][4608]);
-        unsigned* const s_flag_w = reinterpret_cast<unsigned*>(&s_raw[wave][5120]);
+        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4608]);
+        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][5120]);
+        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][5632]);
         s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
         s_best_w[lane] = ~0ull;
         s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
-        s_flag_w[lane] = 0xffffffffu;                         // the doubt slot: least s that won a close merge
+        s_second_w[lane] = ~0ull;
+        s_third_w[lane] = ~0ull;
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection, and the conservative
         // interval [lo, lo + len) of this wave's rays that can hit it
-        auto line_setup2 = [&](const int c0, Cand& cd, int& lo, int& len) {   // every lane comes in; dead ones leave with len 0
+        // a chunk's static lines, lane = line (zeros for dead lanes and for agent lines, which are derived instead)
+        auto fetch = [&](const int c0) {
+            const int l = c0 + lane;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((l < L) & (l >= AF)) w = ln[l];
+            return w;
+        };
+        auto line_setup2 = [&](const int c0, float4 w, Cand& cd, int& lo, int& len) {   // every lane comes in; dead ones leave with len 0
             const int l = c0 + lane;
             const bool live = l < L;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live & (l >= AF)) w = ln[l];
             if (c0 < AF) {                                              // chunk with agent lines in it
                 const float4 aw = agent_line(l);
                 if (l < AF) w = aw;
@@ -1210,38 +1217,22 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked)
                 const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
                 if (hit) {
-                    const float num = cd.pqx*cd.vy - cd.pqy*cd.vx;           // cross(PQ, V)
-                    float sv;
-                    bool beyond;
-                    if constexpr ((MS_V2_OPTS & 4) != 0) {
-                        // s = num/d to within 3 parts in 10^7 from the reciprocal; the quotient itself only where the
-                        // near-plane test would not be safe without it.  Keys, and with them the close-merge test
-                        // below, then run on approximate s - with the band widened to cover it - and the winner's
-                        // exact s is worked out once per ray after the fold.
-                        sv = num*__builtin_amdgcn_rcpf(d);
-                        const bool doubtful = fabsf(sv - ray.z) <= 1e-6f*ray.z;
-                        if (__builtin_amdgcn_ballot_w64(doubtful) != 0ull) {  // uniform, and rare
-                            float dd = d;
-                            asm volatile("" : "+v"(dd));                     // (else hipcc divides everywhere and selects)
-                            if (doubtful) sv = num/dd;
-                        }
-                        beyond = ray.z < sv;
-                    } else {
-                        sv = num/d;                                          // q.s = cross(PQ, V)/UxV
-                        beyond = ray.z < sv;                                 // beyond the near plane, kernels.cu:369
-                    }
+                    const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
+                    const bool beyond = ray.z < sv;                          // beyond the near plane, kernels.cu:369
                     if (beyond) {
                         const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)info.y;
                         const unsigned long long old = atomicMin(&s_best_w[rr], key);
                         const unsigned oh = (unsigned)(old >> 32);
-                        if (oh != 0xffffffffu) {                             // there was a hit before: is the loser clearly behind?
+                        if (oh != 0xffffffffu) {                             // there was a hit before: is the loser anywhere near?
                             const bool won = key < old;
                             const float so = bits_f(oh);
                             const float front = won ? sv : so, back = won ? so : sv;
-                            bool clear;
-                            if constexpr ((MS_V2_OPTS & 4) != 0) clear = front < back*(1.f - 2e-6f) - 1.01e-4f;
-                            else clear = front < back - 1.e-4f;
-                            if (!clear) atomicMin(&s_flag_w[rr], f_bits(front));
+                            if (back < front + 4.e-4f) {                     // rare: the loser may matter to the resolution
+                                const unsigned long long lose1 = won ? old : key;
+                                const unsigned long long old2 = atomicMin(&s_second_w[rr], lose1);
+                                const unsigned long long lose2 = old2 > lose1 ? old2 : lose1;
+                                if (lose2 != ~0ull) atomicMin(&s_third_w[rr], lose2);
+                            }
                         }
                     }
                 }
@@ -1252,10 +1243,13 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             n_list = 0; n_pairs = 0;
         };
 
+        float4 w_ahead = w_first;                                            // the next chunk's lines travel while this one is worked on
         for (int c0 = 0; c0 < L; c0 += WAVE) {
             Cand cd;
             int lo = 0, len = 0;
-            line_setup2(c0, cd, lo, len);
+            const float4 w_now = w_ahead;
+            w_ahead = fetch(c0 + WAVE);
+            line_setup2(c0, w_now, cd, lo, len);
             const bool seen = len > 0;
             const unsigned long long vm = __ballot(seen);
             if (!vm) continue;                                               // uniform
@@ -1275,14 +1269,27 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long best = s_best_w[lane];
-        const bool ambiguous = (best != ~0ull) & (s_flag_w[lane] == (unsigned)(best >> 32));
-        if (best != ~0ull) {
-            nearest_s = bits_f((uint32_t)(best >> 32));
-            nearest_idx = (int)(uint32_t)best;
-            s_is_approximate = (MS_V2_OPTS & 4) != 0;
+        const unsigned long long best = s_best_w[lane], second = s_second_w[lane], third = s_third_w[lane];
+        bool ambiguous = false;
+        if (best != ~0ull) {                     // the resolution of IMPL 1, word for word
+            const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
+            const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
+            nearest_s = s1;
+            nearest_idx = i1;
+            if ((second != ~0ull) && !(s1 < s2 - 1.e-4f)) {
+                if ((third == ~0ull) || (s2 < s3 - 1.e-4f)) {
+                    const bool first_is_1 = i1 < i2;
+                    const float sa = first_is_1 ? s1 : s2, sb = first_is_1 ? s2 : s1;
+                    const int ia = first_is_1 ? i1 : i2, ib = first_is_1 ? i2 : i1;
+                    const bool b_wins = sb < sa - 1.e-4f;
+                    nearest_s = b_wins ? sb : sa;
+                    nearest_idx = b_wins ? ib : ia;
+                } else {
+                    ambiguous = true;
+                }
+            }
         }
-        // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1
+        // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1
         const unsigned long long amb = __ballot(ambiguous);
         if (out.workspace && lane == 0) {
             atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
@@ -1299,7 +1306,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             for (int c0 = 0; c0 < L; c0 += WAVE) {
                 Cand mine;
                 int lo = 0, len = 0;
-                line_setup2(c0, mine, lo, len);
+                line_setup2(c0, fetch(c0), mine, lo, len);
                 __builtin_amdgcn_wave_barrier();
                 s_cand_w[lane] = mine;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1323,7 +1330,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     }
                 }
             }
-            if (ambiguous) { nearest_s = x; nearest_idx = xi; s_is_approximate = false; }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
         } else if (amb) {
             float x = INFINITY;
             int xi = -1;
@@ -1362,7 +1369,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                     }
                 }
             }
-            if (ambiguous) { nearest_s = x; nearest_idx = xi; s_is_approximate = false; }
+            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
         }
     } else {
         for (int c0 = 0; c0 < L; c0 += WAVE) {
@@ -1458,7 +1465,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const float d = rx*vy - ry*vx;
         const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
         loc = (pqx*ry - pqy*rx)/d;
-        if (s_is_approximate) nearest_s = (pqx*vy - pqy*vx)/d;              // q.s = cross(PQ, V)/UxV, as the fold computes it
         const float dtop = rx*vx + ry*vy;
         const float dbot = rlen*sqrtf(vx*vx + vy*vy);
         dt = dtop/(dbot + 1.e-6f);

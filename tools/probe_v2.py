@@ -19,17 +19,17 @@ def build():
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
     rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(2) n_drain_++;\n", i2)
     rep("            // the list starts over\n", "            TICK(3)\n            // the list starts over\n", i2)
-    rep("        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            Cand cd;\n            int lo = 0, len = 0;\n            line_setup2(c0, cd, lo, len);\n",
-        "        TICK(0)\n        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            Cand cd;\n            int lo = 0, len = 0;\n            line_setup2(c0, cd, lo, len);\n            TICK(1)\n", i2)
+    rep("        float4 w_ahead = w_first;", "        TICK(0)\n        float4 w_ahead = w_first;", i2)
+    rep("            line_setup2(c0, w_now, cd, lo, len);\n", "            line_setup2(c0, w_now, cd, lo, len);\n            TICK(1)\n", i2)
     rep("            if (!vm) continue;                                               // uniform\n", "            if (!vm) continue;                                               // uniform\n            n_vis_++;\n", i2)
     rep("        if (n_pairs) drain();\n", "        TICK(2)\n        if (n_pairs) drain();\n", i2)
     rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(4)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
     rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(5)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
     rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(6)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
     # telemetry variables of IMPL 2 are local to its branch: export them through function-scope shadows
-    rep("    bool s_is_approximate = false;", "    bool s_is_approximate = false; int probe_pairs_ = 0, probe_windows_ = 0;")
+    rep("    int nearest_idx = -1;\n", "    int nearest_idx = -1; int probe_pairs_ = 0, probe_windows_ = 0;\n")
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
-    rep("        // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1\n", "        probe_pairs_ = n_pairs_total; probe_windows_ = n_windows;\n        // The literal fold for the flagged rays (kernels.cu:352-377), as in IMPL 1\n", i2)
+    rep("        // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1\n", "        probe_pairs_ = n_pairs_total; probe_windows_ = n_windows;\n        // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1\n", i2)
     assert src.count("    // ---- pooled observations") == 1
     src = src.replace("    // ---- pooled observations", """    TICK(7)
     {
