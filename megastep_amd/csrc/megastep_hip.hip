@@ -2366,11 +2366,11 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
     // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
     // (kept for A/B verification); both produce the same bits.
-    // MEGASTEP_RENDER_IMPL: "seq" (literal order, slowest), "pairs" (round 1's pair raycast), "v2" (compacted pairs);
-    // all three produce the same bits.  Read per call: tests switch it.
+    // MEGASTEP_RENDER_IMPL: "seq" (literal order, slowest), "pairs" (round 1's pair raycast), "v2" (compacted pairs, the
+    // default); all three produce the same bits.  Read per call: tests switch it.
     const char* impl_env = getenv("MEGASTEP_RENDER_IMPL");
     const bool seq = impl_env && impl_env[0] == 's';
-    const bool pairs1 = !(impl_env && impl_env[0] == 'v');                     // (the default until v2 has been through the GPU suite)
+    const bool pairs1 = impl_env && impl_env[0] == 'p';                        // default: "v2"
     // the light grid is all or nothing: render_kernel lights agent-hit rays itself when it is there
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
