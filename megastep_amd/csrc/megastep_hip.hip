@@ -362,6 +362,33 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     };
     // lane = wall: which agents' reach boxes does its bounding box touch?  Those (wall, agent) pairs are compacted
     // into LDS and get the distance test and then the exact one, one pair per lane (kernels.cu:202-221)
+    auto keep = [&](const int t, const bool in, const float4 u) {       // appends the lanes with `in` set as (wall, agent t) pairs
+        const unsigned long long m = __ballot(in);
+        if (m) {
+            const int nk = __popcll(m);
+            if (cnt + nk > WAVE) flush();
+            if (in) {
+                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                s_wall[pos] = u;
+                s_tag[pos] = t;
+            }
+            cnt += nk;
+        }
+    };
+    // Up to four agents: their boxes sit in scalar registers and one ballot per chunk says whether any wall of it is
+    // near any of them - mostly none is, and the chunk costs a dozen compares.  (A box no wall can touch for the
+    // missing agents; a NaN box, from NaN velocities, rejects nothing, as before.)
+    constexpr int BOXED = 4;
+    float bx0[BOXED], by0[BOXED], bx1[BOXED], by1[BOXED];
+    {
+        const float4 mine = s_box[min(lane, A - 1)];
+        #pragma unroll
+        for (int t = 0; t < BOXED; t++) {
+            const bool have = t < A;
+            bx0[t] = have ? readlane_f(mine.x, min(t, A - 1)) : INFINITY;  by0[t] = have ? readlane_f(mine.y, min(t, A - 1)) : INFINITY;
+            bx1[t] = have ? readlane_f(mine.z, min(t, A - 1)) : -INFINITY; by1[t] = have ? readlane_f(mine.w, min(t, A - 1)) : -INFINITY;
+        }
+    }
     for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
@@ -374,19 +401,22 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             if (l0 + k*WAVE >= L) continue;                             // uniform
             const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
             const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
-            for (int t = 0; t < A; t++) {
-                const float4 bx = s_box[t];
-                const bool in = live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w)));
-                const unsigned long long m = __ballot(in);
-                if (m) {
-                    const int nk = __popcll(m);
-                    if (cnt + nk > WAVE) flush();
-                    if (in) {
-                        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                        s_wall[pos] = u;
-                        s_tag[pos] = t;
-                    }
-                    cnt += nk;
+            if (A <= BOXED) {
+                bool in[BOXED];
+                bool any = false;
+                #pragma unroll
+                for (int t = 0; t < BOXED; t++) {
+                    in[t] = (t < A) & live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));
+                    any |= in[t];
+                }
+                if (__ballot(any)) {
+                    #pragma unroll
+                    for (int t = 0; t < BOXED; t++) keep(t, in[t], u);
+                }
+            } else {
+                for (int t = 0; t < A; t++) {
+                    const float4 bx = s_box[t];
+                    keep(t, live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w))), u);
                 }
             }
         }
