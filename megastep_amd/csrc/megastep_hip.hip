@@ -216,7 +216,7 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // arithmetic; the few (agent, wall) pairs in reach are compacted into LDS and only those pay for the ten
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
-constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave
+constexpr int PHYS_AHEAD = 6;          // wall chunks in flight per wave (a typical plan's 300 walls: all of them, requested at once)
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
 // EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
