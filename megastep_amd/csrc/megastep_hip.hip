@@ -216,7 +216,8 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // arithmetic; the few (agent, wall) pairs in reach are compacted into LDS and only those pay for the ten
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
-constexpr int PHYS_AHEAD = 6;          // wall chunks in flight per wave (a typical plan's 300 walls: all of them, requested at once)
+constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave (six: no faster at 300 walls, 12 % slower at 1000 - fewer waves fit)
+constexpr int PHYS_PAIRS = 5*WAVE;     // capacity of a wave's (wall, agent) pair list: a flush's worth + a chunk's worth for four agents
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
 // EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
         const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex, const int slice) {
     extern __shared__ float4 s_dyn_all[];        // per agent: (p, v/fps) | reach box | reach^2 | progress bits
-    __shared__ float4 s_wall_all[WPB][WAVE];     // walls near ...
-    __shared__ int s_tag_all[WPB][WAVE];         // ... this agent
+    __shared__ float4 s_wall_all[WPB][PHYS_PAIRS];   // walls near ...
+    __shared__ int s_tag_all[WPB][PHYS_PAIRS];       // ... this agent
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const int n = blockIdx.x*WPB + wv;
@@ -336,25 +337,33 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
         }
     }
 
+    // The exact tests are ~600 instructions; the sweep below is written so that they exist ONCE in its loop (plus once
+    // behind it): (wall, agent) pairs collect in a list with room for a whole chunk's worth on top of a flush's, and
+    // the chunk loop is not unrolled (the chunks in flight rotate through four registers instead).  With the tests
+    // inlined at every step of an unrolled sweep the kernel was 80 KB of code, and waves spent half their time in
+    // this sweep waiting for instructions rather than walls.
     int cnt = 0;
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < cnt) {
-            const float4 u = s_wall[lane];
-            const int t = s_tag[lane];
-            const float4 tk = s_task[t];
-            // squared distance from the agent to the segment, shaved so it is a lower bound
-            const float vx = u.z - u.x, vy = u.w - u.y;
-            const float pqx = u.x - tk.x, pqy = u.y - tk.y;
-            float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
-            tc = fminf(fmaxf(tc, 0.f), 1.f);
-            tc = (tc == tc) ? tc : 0.f;
-            const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-            if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {             // NaNs stay in
-                const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
-                if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+        #pragma unroll 1
+        for (int p0 = 0; p0 < cnt; p0 += WAVE) {
+            if (p0 + lane < cnt) {
+                const float4 u = s_wall[p0 + lane];
+                const int t = s_tag[p0 + lane];
+                const float4 tk = s_task[t];
+                // squared distance from the agent to the segment, shaved so it is a lower bound
+                const float vx = u.z - u.x, vy = u.w - u.y;
+                const float pqx = u.x - tk.x, pqy = u.y - tk.y;
+                float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+                tc = fminf(fmaxf(tc, 0.f), 1.f);
+                tc = (tc == tc) ? tc : 0.f;
+                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+                if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {             // NaNs stay in
+                    const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
+                    if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -365,14 +374,12 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     auto keep = [&](const int t, const bool in, const float4 u) {       // appends the lanes with `in` set as (wall, agent t) pairs
         const unsigned long long m = __ballot(in);
         if (m) {
-            const int nk = __popcll(m);
-            if (cnt + nk > WAVE) flush();
             if (in) {
                 const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
                 s_wall[pos] = u;
                 s_tag[pos] = t;
             }
-            cnt += nk;
+            cnt += __popcll(m);
         }
     };
     // Up to four agents: their boxes sit in scalar registers and one ballot per chunk says whether any wall of it is
@@ -389,32 +396,37 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             bx1[t] = have ? readlane_f(mine.z, min(t, A - 1)) : -INFINITY; by1[t] = have ? readlane_f(mine.w, min(t, A - 1)) : -INFINITY;
         }
     }
-    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
-        #pragma unroll
-        for (int k = 0; k < PHYS_AHEAD; k++) {
-            const float4 u = w[k];
-            const bool live = l0 + k*WAVE + lane < L;
-            // the chunk PHYS_AHEAD further on takes this one's place
-            const int nl = l0 + (k + PHYS_AHEAD)*WAVE + lane;
-            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nl < L) w[k] = ln[nl];
-            if (l0 + k*WAVE >= L) continue;                             // uniform
-            const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
-            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
-            if (A <= BOXED) {
-                bool in[BOXED];
-                bool any = false;
+    static_assert(PHYS_AHEAD == 4, "the sweep rotates four chunks by hand");
+    #pragma unroll 1
+    for (int l0 = AF; l0 < L; l0 += WAVE) {
+        const float4 u = w[0];
+        const bool live = l0 + lane < L;
+        // the chunks in flight move up one; the chunk PHYS_AHEAD further on joins them
+        w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
+        const int nl = l0 + PHYS_AHEAD*WAVE + lane;
+        w[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nl < L) w[3] = ln[nl];
+        if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();                     // room for whatever this chunk may add
+        const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
+        const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
+        if (A <= BOXED) {
+            bool in[BOXED];
+            bool any = false;
+            #pragma unroll
+            for (int t = 0; t < BOXED; t++) {
+                in[t] = (t < A) & live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));
+                any |= in[t];
+            }
+            if (__ballot(any)) {
                 #pragma unroll
-                for (int t = 0; t < BOXED; t++) {
-                    in[t] = (t < A) & live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));
-                    any |= in[t];
-                }
-                if (__ballot(any)) {
-                    #pragma unroll
-                    for (int t = 0; t < BOXED; t++) keep(t, in[t], u);
-                }
-            } else {
-                for (int t = 0; t < A; t++) {
+                for (int t = 0; t < BOXED; t++) keep(t, in[t], u);
+            }
+        } else {
+            #pragma unroll 1
+            for (int t0 = 0; t0 < A; t0 += BOXED) {
+                if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();
+                #pragma unroll 1
+                for (int t = t0; t < min(t0 + BOXED, A); t++) {
                     const float4 bx = s_box[t];
                     keep(t, live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w))), u);
                 }
@@ -718,18 +730,32 @@ constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair
 struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
 
 // The drawn (world-frame) model line `l` of env n: draw_kernel, kernels.cu:297-318.
-__device__ inline float4 drawn_line(const MsScenery& sc, const MsAgents& ag, int n, int l) {
-    const int M = sc.n_model, a = l / M, m = l - a*M;
+// sin/cos of a heading where it is not worth a copy of the code: (sin(pi x), cos(pi x)), as sincospi_f gives them
+__device__ __attribute__((noinline)) float2 sincospi_called(const float x) {
+    float s_, c_;
+    sincospi_f(x, s_, c_);
+    return make_float2(s_, c_);
+}
+
+// (The work is in a function that is not inlined and takes plain pointers: it serves sceneries with more than 64 agents
+// per env only, and a copy of its binary64 sin/cos at each of the render kernel's half-dozen call sites is code every
+// wave would have to be fetched past.)
+__device__ __attribute__((noinline)) float4 drawn_line_of(const float* angles, const float* positions, const float* model,
+                                                          const int n_agents, const int M, const int n, const int l) {
+    const int a = l / M, m = l - a*M;
     float s, c;
-    sincospi_f(ag.angles[n*sc.n_agents + a]/180.f, s, c);
-    const float2 p = reinterpret_cast<const float2*>(ag.positions)[n*sc.n_agents + a];
-    const float4 mdl = reinterpret_cast<const float4*>(sc.model)[m];
+    sincospi_f(angles[n*n_agents + a]/180.f, s, c);
+    const float2 p = reinterpret_cast<const float2*>(positions)[n*n_agents + a];
+    const float4 mdl = reinterpret_cast<const float4*>(model)[m];
     float4 w;
     w.x = c*mdl.x - s*mdl.y + p.x;
     w.y = s*mdl.x + c*mdl.y + p.y;
     w.z = c*mdl.z - s*mdl.w + p.x;
     w.w = s*mdl.z + c*mdl.w + p.y;
     return w;
+}
+__device__ inline float4 drawn_line(const MsScenery& sc, const MsAgents& ag, int n, int l) {
+    return drawn_line_of(ag.angles, ag.positions, sc.model, sc.n_agents, sc.n_model, n, l);
 }
 
 // kernels.cu:394-405
@@ -875,12 +901,13 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const float4 h = reinterpret_cast<const float4*>(ag.headings)[n*A + lane];
             const float angle = ag.angles[n*A + lane];
             ag_s = h.y; ag_c = h.z;
-            if (f_bits(h.x) != f_bits(angle)) sincospi_f(angle/180.f, ag_s, ag_c);
+            if (f_bits(h.x) != f_bits(angle)) { const float2 sc_ = sincospi_called(angle/180.f); ag_s = sc_.x; ag_c = sc_.y; }   // (rare: a respawn)
         } else if (out.workspace) {
             const float2 sc_ = reinterpret_cast<const float2*>(out.workspace + 16 + ((n_fans + 1) & ~1))[n*A + lane];
             ag_s = sc_.x; ag_c = sc_.y;
         } else {
-            sincospi_f(ag.angles[n*A + lane]/180.f, ag_s, ag_c);
+            const float2 sc_ = sincospi_called(ag.angles[n*A + lane]/180.f);
+            ag_s = sc_.x; ag_c = sc_.y;
         }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
@@ -914,7 +941,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         sn = readlane_f(ag_s, a); cs = readlane_f(ag_c, a);
         pp = make_float2(readlane_f(ag_p.x, a), readlane_f(ag_p.y, a));
     } else {
-        sincospi_f(ag.angles[n*A + a]/180.f, sn, cs);
+        const float2 sc_ = sincospi_called(ag.angles[n*A + a]/180.f);
+        sn = sc_.x; cs = sc_.y;
         pp = reinterpret_cast<const float2*>(ag.positions)[n*A + a];
     }
     const float Rf = (float)R;
