@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     __shared__ float4 s_wall_all[WPB][PHYS_PAIRS];   // walls near ...
     __shared__ int s_tag_all[WPB][PHYS_PAIRS];       // ... this agent
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int lane = WPB == 1 ? threadIdx.x : threadIdx.x & (WAVE - 1), wv = WPB == 1 ? 0 : threadIdx.x >> 6;   // (0 spelled out: keeps n scalar)
     const int n = blockIdx.x*WPB + wv;
     if (n >= sc.n_envs) return;                  // waves are independent: no workgroup barriers below
     float4* const s_dyn = s_dyn_all + (size_t)wv*slice;
@@ -865,7 +865,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     constexpr int LDS_PER_WAVE = IMPL == 2 ? 6144 : 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
+    // would otherwise keep env, agent, line count and every address derived from them in vector registers)
+    const int tid = threadIdx.x, wave = RW == 1 ? 0 : tid >> 6, lane = RW == 1 ? tid : tid & 63;
     Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);
     float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][IMPL == 2 ? 0 : 4096]);   // (IMPL 2: the raycast is over by then)
 
