@@ -337,11 +337,8 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
         }
     }
 
-    // The exact tests are ~600 instructions; the sweep below is written so that they exist ONCE in its loop (plus once
-    // behind it): (wall, agent) pairs collect in a list with room for a whole chunk's worth on top of a flush's, and
-    // the chunk loop is not unrolled (the chunks in flight rotate through four registers instead).  With the tests
-    // inlined at every step of an unrolled sweep the kernel was 80 KB of code, and waves spent half their time in
-    // this sweep waiting for instructions rather than walls.
+    // (wall, agent) pairs collect in an LDS list with room for a chunk's worth (four agents) on top of a flush's worth,
+    // so that the sweep asks "is there room" once per chunk rather than once per agent.
     int cnt = 0;
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -396,37 +393,35 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             bx1[t] = have ? readlane_f(mine.z, min(t, A - 1)) : -INFINITY; by1[t] = have ? readlane_f(mine.w, min(t, A - 1)) : -INFINITY;
         }
     }
-    static_assert(PHYS_AHEAD == 4, "the sweep rotates four chunks by hand");
-    #pragma unroll 1
-    for (int l0 = AF; l0 < L; l0 += WAVE) {
-        const float4 u = w[0];
-        const bool live = l0 + lane < L;
-        // the chunks in flight move up one; the chunk PHYS_AHEAD further on joins them
-        w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
-        const int nl = l0 + PHYS_AHEAD*WAVE + lane;
-        w[3] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nl < L) w[3] = ln[nl];
-        if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();                     // room for whatever this chunk may add
-        const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
-        const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
-        if (A <= BOXED) {
-            bool in[BOXED];
-            bool any = false;
-            #pragma unroll
-            for (int t = 0; t < BOXED; t++) {
-                in[t] = (t < A) & live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));
-                any |= in[t];
-            }
-            if (__ballot(any)) {
+    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
+        #pragma unroll
+        for (int k = 0; k < PHYS_AHEAD; k++) {
+            const float4 u = w[k];
+            const bool live = l0 + k*WAVE + lane < L;
+            // the chunk PHYS_AHEAD further on takes this one's place
+            const int nl = l0 + (k + PHYS_AHEAD)*WAVE + lane;
+            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nl < L) w[k] = ln[nl];
+            if (l0 + k*WAVE >= L) continue;                             // uniform
+            const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
+            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
+            if (A <= BOXED) {
+                bool in[BOXED];
+                bool any = false;
                 #pragma unroll
-                for (int t = 0; t < BOXED; t++) keep(t, in[t], u);
-            }
-        } else {
-            #pragma unroll 1
-            for (int t0 = 0; t0 < A; t0 += BOXED) {
-                if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();
+                for (int t = 0; t < BOXED; t++) {
+                    in[t] = (t < A) & live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));
+                    any |= in[t];
+                }
+                if (__ballot(any)) {
+                    if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();            // room for whatever this chunk may add
+                    #pragma unroll
+                    for (int t = 0; t < BOXED; t++) keep(t, in[t], u);
+                }
+            } else {
                 #pragma unroll 1
-                for (int t = t0; t < min(t0 + BOXED, A); t++) {
+                for (int t = 0; t < A; t++) {
+                    if (cnt > PHYS_PAIRS - WAVE) flush();
                     const float4 bx = s_box[t];
                     keep(t, live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w))), u);
                 }

@@ -7,8 +7,8 @@ def rep(old, new):
     global src
     assert src.count(old) >= 1, old
     src = src.replace(old, new, 1)
-rep("    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w",
-    "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int Psum = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w")
+rep("    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);",
+    "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int Psum = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);")
 rep("        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            line_setup(c0, lo, len);\n            const int incl = wave_scan_add(len);",
     "        TICK(0)\n        for (int c0 = 0; c0 < L; c0 += WAVE) {\n            int lo = 0, len = 0;\n            line_setup(c0, lo, len);\n            TICK(1)\n            const int incl = wave_scan_add(len);")
 rep("            n_pairs_total += P; n_windows += (P + WAVE - 1)/WAVE;\n            int carry = -1;", "            n_pairs_total += P; n_windows += (P + WAVE - 1)/WAVE;\n            int carry = -1;\n            TICK(2)\n            Psum += P;")

@@ -14,8 +14,8 @@ def build():
         nonlocal src
         k = src.index(old, start)
         src = src[:k] + new + src[k + len(old):]
-    rep("    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w",
-        "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_vis_ = 0, n_drain_ = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;\n    Cand* const s_cand_w")
+    rep("    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);",
+        "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_vis_ = 0, n_drain_ = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);")
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
     rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(2) n_drain_++;\n", i2)
     rep("            // the list starts over\n", "            TICK(3)\n            // the list starts over\n", i2)
