@@ -410,13 +410,14 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
                 bool any = false;
                 #pragma unroll
                 for (int t = 0; t < BOXED; t++) {
-                    in[t] = (t < A) & live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));
+                    in[t] = false;
+                    if (t < A) in[t] = live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));   // (uniform)
                     any |= in[t];
                 }
                 if (__ballot(any)) {
                     if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();            // room for whatever this chunk may add
                     #pragma unroll
-                    for (int t = 0; t < BOXED; t++) keep(t, in[t], u);
+                    for (int t = 0; t < BOXED; t++) if (t < A) keep(t, in[t], u);
                 }
             } else {
                 #pragma unroll 1
