@@ -17,15 +17,15 @@ def build():
     rep("    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);",
         "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_vis_ = 0, n_drain_ = 0;\n#define TICK(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);")
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
-    rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(2) n_drain_++;\n", i2)
+    rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(4) n_drain_++;\n", i2)
     rep("            // the list starts over\n", "            TICK(3)\n            // the list starts over\n", i2)
     rep("        float4 w_ahead = w_first;", "        TICK(0)\n        float4 w_ahead = w_first;", i2)
-    rep("            line_setup2(c0, w_now, cd, lo, len);\n", "            line_setup2(c0, w_now, cd, lo, len);\n            TICK(1)\n", i2)
-    rep("            if (!vm) continue;                                               // uniform\n", "            if (!vm) continue;                                               // uniform\n            n_vis_++;\n", i2)
-    rep("        if (n_pairs) drain();\n", "        TICK(2)\n        if (n_pairs) drain();\n", i2)
-    rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(4)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
-    rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(5)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
-    rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(6)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
+    rep("            line_math(w, l, live, agent_lines, cd, lo, len);\n", "            TICK(1)\n            line_math(w, l, live, agent_lines, cd, lo, len);\n            TICK(2)\n", i2)
+    rep("            if (!vm) return;                                                 // uniform\n", "            if (!vm) return;                                                 // uniform\n            n_vis_++;\n", i2)
+    rep("        if (n_pairs) drain();\n", "        TICK(1)\n        if (n_pairs) drain();\n", i2)
+    rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(5)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
+    rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(6)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
+    rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(7)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
     # telemetry variables of IMPL 2 are local to its branch: export them through function-scope shadows
     rep("    int nearest_idx = -1;\n", "    int nearest_idx = -1; int probe_pairs_ = 0, probe_windows_ = 0;\n")
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
@@ -77,8 +77,8 @@ def run():
                 print('the slowest wave:', d[worst].cpu().numpy().round(0).tolist(), 'lines', lines[worst].item())
                 print('corr(total, lines) %.2f  corr(total, pairs) %.2f' % (torch.corrcoef(torch.stack([tot, lines]))[0, 1].item(), torch.corrcoef(torch.stack([tot, d[:, 8]]))[0, 1].item()))
     acc /= cnt
-    names = ['prologue', 'pass1 line_setup', 'scan+compaction', 'pass2 windows', 'resolve+fold', 'loc/dot+out', 'lighting', 'shade+store',
-             'pairs', 'windows', 'chunks with visible lines', 'drains']
+    names = ['prologue', 'pass 0 + queue', 'pass 1 line math', 'pass2 windows', 'scan+compaction', 'resolve+fold', 'loc/dot+out', 'lighting+shade+store',
+             'pairs', 'windows', 'batches with visible lines', 'drains']
     tot = acc[:8].sum()
     for n, v in zip(names, acc):
         print('%-26s %10.1f  %s' % (n, v, '%.1f%%' % (100*v/tot) if names.index(n) < 8 else ''))
