@@ -885,10 +885,17 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
-    // IMPL 2 asks for the first chunk of lines before anything else: nothing below needs it until the raycast
-    float4 w_first = make_float4(0.f, 0.f, 0.f, 0.f);
+    // IMPL 2 asks for its first chunks of lines before anything else: nothing below needs them until the raycast, and a
+    // chunk of pass 0 is too short to hide the next one's trip (1600 cycles under load) on its own
+    constexpr int AHEAD = 3;                     // chunks in flight
+    float4 w_first[AHEAD];
     if constexpr (IMPL == 2) {
-        if ((lane < L) & (lane >= sc.n_agents*sc.n_model)) w_first = ln[lane];
+        #pragma unroll
+        for (int k = 0; k < AHEAD; k++) {
+            const int l = k*WAVE + lane;
+            w_first[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((l < L) & (l >= sc.n_agents*sc.n_model)) w_first[k] = ln[l];
+        }
     }
 
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
@@ -1325,7 +1332,16 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if constexpr ((MS_V2_OPTS & 1) != 0) drain();
         };
 
-        float4 w_ahead = w_first;                                            // the next chunk's lines travel while this one is worked on
+        float4 w_next[AHEAD];                                                // the next chunks' lines travel while this one is worked on
+        #pragma unroll
+        for (int k = 0; k < AHEAD; k++) w_next[k] = w_first[k];
+        auto next_chunk = [&](const int c0) {                                // chunk c0's lines; asks for chunk c0 + AHEAD*64
+            const float4 w = w_next[0];
+            #pragma unroll
+            for (int k = 0; k + 1 < AHEAD; k++) w_next[k] = w_next[k + 1];
+            w_next[AHEAD - 1] = fetch(c0 + AHEAD*WAVE);
+            return w;
+        };
         if constexpr ((MS_V2_OPTS & 4) == 0) {
             // PASS 0, lane = line, every chunk: a dozen instructions that throw out the lines wholly behind the agent
             // (about half) or wholly to one side of this wave's wedge of rays (with several ray groups per agent:
@@ -1351,8 +1367,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 q_head = (q_head + take) & 127; q_count -= take;
             };
             for (int c0 = 0; c0 < L; c0 += WAVE) {
-                const float4 w = w_ahead;
-                w_ahead = fetch(c0 + WAVE);
+                const float4 w = next_chunk(c0);
                 const int l = c0 + lane;
                 const float pqx = w.x - pp.x, pqy = w.y - pp.y, dbx = w.z - pp.x, dby = w.w - pp.y;
                 const float xa = __builtin_fmaf(cs, pqx, sn*pqy), xb = __builtin_fmaf(cs, dbx, sn*dby);
@@ -1375,8 +1390,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             while (q_count > 0) pop();
         } else {
             for (int c0 = 0; c0 < L; c0 += WAVE) {
-                const float4 w_now = w_ahead;
-                w_ahead = fetch(c0 + WAVE);
+                const float4 w_now = next_chunk(c0);
                 admit(w_now, c0 + lane, c0 + lane < L, c0 < AF);
             }
         }

@@ -19,7 +19,7 @@ def build():
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
     rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(4) n_drain_++;\n", i2)
     rep("            // the list starts over\n", "            TICK(3)\n            // the list starts over\n", i2)
-    rep("        float4 w_ahead = w_first;", "        TICK(0)\n        float4 w_ahead = w_first;", i2)
+    rep("        float4 w_next[AHEAD];", "        TICK(0)\n        float4 w_next[AHEAD];", i2)
     rep("            line_math(w, l, live, agent_lines, cd, lo, len);\n", "            TICK(1)\n            line_math(w, l, live, agent_lines, cd, lo, len);\n            TICK(2)\n", i2)
     rep("            if (!vm) return;                                                 // uniform\n", "            if (!vm) return;                                                 // uniform\n            n_vis_++;\n", i2)
     rep("        if (n_pairs) drain();\n", "        TICK(1)\n        if (n_pairs) drain();\n", i2)
