@@ -249,11 +249,9 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
     float4 w[PHYS_AHEAD];
     #pragma unroll
-    for (int k = 0; k < PHYS_AHEAD; k++) {
-        const int l = AF + k*WAVE + lane;
-        w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (l < L) w[k] = ln[l];
-    }
+    // (unconditional loads from a clamped row - behind a branch hipcc waits for every load in flight at the first use of
+    // any of them; lanes past the last wall are masked by `live` in the sweep)
+    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = ln[min(AF + k*WAVE + lane, max(L - 1, 0))];
 
     // one lane per agent: its state and reach ...
     float2 my_p = make_float2(0.f, 0.f), my_v = make_float2(0.f, 0.f);   // agent `lane`, kept for the epilogue
@@ -399,9 +397,7 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             const float4 u = w[k];
             const bool live = l0 + k*WAVE + lane < L;
             // the chunk PHYS_AHEAD further on takes this one's place
-            const int nl = l0 + (k + PHYS_AHEAD)*WAVE + lane;
-            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (nl < L) w[k] = ln[nl];
+            w[k] = ln[min(l0 + (k + PHYS_AHEAD)*WAVE + lane, max(L - 1, 0))];
             if (l0 + k*WAVE >= L) continue;                             // uniform
             const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
             const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
@@ -890,12 +886,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     constexpr int AHEAD = 3;                     // chunks in flight
     float4 w_first[AHEAD];
     if constexpr (IMPL == 2) {
+        // (unconditional loads from a clamped row: behind a branch hipcc waits for every load in flight at the first
+        // use of any of them, which turns "in flight" into "one at a time"; rows that are not wanted are ignored later)
         #pragma unroll
-        for (int k = 0; k < AHEAD; k++) {
-            const int l = k*WAVE + lane;
-            w_first[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((l < L) & (l >= sc.n_agents*sc.n_model)) w_first[k] = ln[l];
-        }
+        for (int k = 0; k < AHEAD; k++) w_first[k] = ln[min(k*WAVE + lane, max(L - 1, 0))];
     }
 
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
@@ -1228,13 +1222,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection, and the conservative
         // interval [lo, lo + len) of this wave's rays that can hit it
-        // a chunk's static lines, lane = line (zeros for dead lanes and for agent lines, which are derived instead)
-        auto fetch = [&](const int c0) {
-            const int l = c0 + lane;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((l < L) & (l >= AF)) w = ln[l];
-            return w;
-        };
+        // a chunk's lines as they are in memory, lane = line (dead lanes get the last row, agent rows whatever the last
+        // render left there: neither is used)
+        auto fetch = [&](const int c0) { return ln[min(c0 + lane, max(L - 1, 0))]; };   // (clamped, not guarded: see w_first)
         // the full work on one line per lane (any line `l`; `agent_lines`: some lane holds one, wave-uniform): the
         // ray-independent half of the intersection, and the conservative interval [lo, lo + len) of this wave's rays
         // that can hit it.  Every lane comes in; dead ones leave with len 0
@@ -1361,8 +1351,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const bool live = lane < take;
                 int l = AF;
                 if (live) l = (int)s_queue_w[(q_head + lane) & 127];
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live & (l >= AF)) w = ln[l];
+                const float4 w = ln[min(l, max(L - 1, 0))];
                 admit(w, l, live, __ballot(live & (l < AF)) != 0ull);
                 q_head = (q_head + take) & 127; q_count -= take;
             };
