@@ -707,8 +707,7 @@ __device__ inline float grid_light_intensity(
 // A/B knobs of the pair raycasts (tools/ab_variants.sh builds one library per setting; the defaults are the product):
 //   MS_V1_OPTS  bit 0: IMPL 1 takes IMPL 2's interval arithmetic (no clipping); bit 1: IMPL 1 takes IMPL 2's single
 //               atomic + hysteresis flag instead of the three-slot cascade
-//   MS_V2_OPTS  bit 0: IMPL 2 drains its list after every chunk; bit 1: IMPL 2 clips like IMPL 1; bit 2: no pass 0
-//               (every line of every chunk gets the full pass 1)
+//   MS_V2_OPTS  bit 0: IMPL 2 drains its list after every chunk; bit 1: IMPL 2 clips like IMPL 1
 //               (tried and dropped: keys from v_rcp_f32 with the exact quotient once per ray - correct, not faster)
 #ifndef MS_V1_OPTS
 #define MS_V1_OPTS 0
@@ -854,8 +853,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     //   3584 info   (64 x 4 B)   per line: (first pair << 6) | first ray
     //   3840 mark   (64 x 4 B)   pair window: which line starts here
     //   4096 screen (192 x 4 B)  RGB staging
-    // IMPL 2 lays its block out differently (see there): 6656 B
-    constexpr int LDS_PER_WAVE = IMPL == 2 ? 6656 : 4864;
+    // IMPL 2 lays its block out differently (see there): 6144 B
+    constexpr int LDS_PER_WAVE = IMPL == 2 ? 6144 : 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
@@ -881,8 +880,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
-    // IMPL 2 asks for its first chunks of lines before anything else: nothing below needs them until the raycast, and a
-    // chunk of pass 0 is too short to hide the next one's trip (1600 cycles under load) on its own
+    // IMPL 2 asks for its first chunks of lines before anything else: nothing below needs them until the raycast, and one
+    // chunk's work does not hide the next one's trip (1600 cycles under load) on its own
     constexpr int AHEAD = 3;                     // chunks in flight
     float4 w_first[AHEAD];
     if constexpr (IMPL == 2) {
@@ -1205,7 +1204,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         //    only give less when the crossing is within centimetres of the agent.)
         // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first ray - first pair, line)
         //               3072 ray (64 x 16 B)    | 4096 best, 4608 second, 5120 third (64 x 8 B each) | 5632 marks (4096 bits)
-        //               6144 queue (128 x 4 B: lines waiting for pass 1)
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = 128, P_CAP = 4096;
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][2048]);
@@ -1332,56 +1330,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             w_next[AHEAD - 1] = fetch(c0 + AHEAD*WAVE);
             return w;
         };
-        if constexpr ((MS_V2_OPTS & 4) == 0) {
-            // PASS 0, lane = line, every chunk: a dozen instructions that throw out the lines wholly behind the agent
-            // (about half) or wholly to one side of this wave's wedge of rays (with several ray groups per agent:
-            // most of the rest), and queue the others' indices.  The full work above then runs on full batches of 64
-            // queued lines - gathered back from the cache - about half as often as there are chunks.  Conservative
-            // by construction: the queue only ever loses lines whose interval would have come out empty.
-            unsigned* const s_queue_w = reinterpret_cast<unsigned*>(&s_raw[wave][6144]);   // 128 line indices, a ring
-            int q_head = 0, q_count = 0;
-            // the wedge in screen coordinates ys = y'/x' (ray r sits at (c_a - r)/c_b), grown by a ray on either side
-            const float inv_cb = 1.f/c_b;
-            const float ys_hi = (c_a - g0 + 1.f)*inv_cb, ys_lo = (c_a - (g0 + 63.f) - 1.f)*inv_cb;
-            auto pop = [&]() {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int take = min(q_count, WAVE);
-                const bool live = lane < take;
-                int l = AF;
-                if (live) l = (int)s_queue_w[(q_head + lane) & 127];
-                const float4 w = ln[min(l, max(L - 1, 0))];
-                admit(w, l, live, __ballot(live & (l < AF)) != 0ull);
-                q_head = (q_head + take) & 127; q_count -= take;
-            };
-            for (int c0 = 0; c0 < L; c0 += WAVE) {
-                const float4 w = next_chunk(c0);
-                const int l = c0 + lane;
-                const float pqx = w.x - pp.x, pqy = w.y - pp.y, dbx = w.z - pp.x, dby = w.w - pp.y;
-                const float xa = __builtin_fmaf(cs, pqx, sn*pqy), xb = __builtin_fmaf(cs, dbx, sn*dby);
-                const bool fa = xa >= x_clip, fb = xb >= x_clip;
-                bool keep = (l < L) & ((l < AF) | fa | fb);                  // (agent lines are not looked at here)
-                if (G > 1) {                                                 // both ends in front and on one side of the wedge
-                    const float ya = __builtin_fmaf(cs, pqy, -(sn*pqx)), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
-                    const float tol = 1e-5f*(fabsf(pqx) + fabsf(pqy) + fabsf(dbx) + fabsf(dby));   // ~100 roundings of the sides below
-                    const bool left = (__builtin_fmaf(-ys_hi, xa, ya) > tol) & (__builtin_fmaf(-ys_hi, xb, yb) > tol);
-                    const bool right = (__builtin_fmaf(-ys_lo, xa, ya) < -tol) & (__builtin_fmaf(-ys_lo, xb, yb) < -tol);
-                    keep = keep & !(fa & fb & (l >= AF) & (left | right));
-                }
-                const unsigned long long km = __ballot(keep);
-                if (km) {
-                    if (keep) s_queue_w[(q_head + q_count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u))) & 127] = (unsigned)l;
-                    q_count += __popcll(km);
-                    if (q_count >= WAVE) pop();
-                }
-            }
-            while (q_count > 0) pop();
-        } else {
-            for (int c0 = 0; c0 < L; c0 += WAVE) {
-                const float4 w_now = next_chunk(c0);
-                admit(w_now, c0 + lane, c0 + lane < L, c0 < AF);
-            }
+        for (int c0 = 0; c0 < L; c0 += WAVE) {
+            const float4 w_now = next_chunk(c0);
+            admit(w_now, c0 + lane, c0 + lane < L, c0 < AF);
         }
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -77,7 +77,7 @@ def run():
                 print('the slowest wave:', d[worst].cpu().numpy().round(0).tolist(), 'lines', lines[worst].item())
                 print('corr(total, lines) %.2f  corr(total, pairs) %.2f' % (torch.corrcoef(torch.stack([tot, lines]))[0, 1].item(), torch.corrcoef(torch.stack([tot, d[:, 8]]))[0, 1].item()))
     acc /= cnt
-    names = ['prologue', 'pass 0 + queue', 'pass 1 line math', 'pass2 windows', 'scan+compaction', 'resolve+fold', 'loc/dot+out', 'lighting+shade+store',
+    names = ['prologue', 'line loads + loop', 'pass 1 line math', 'pass2 windows', 'scan+compaction', 'resolve+fold', 'loc/dot+out', 'lighting+shade+store',
              'pairs', 'windows', 'batches with visible lines', 'drains']
     tot = acc[:8].sum()
     for n, v in zip(names, acc):
