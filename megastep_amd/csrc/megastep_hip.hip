@@ -895,13 +895,17 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
     float ag_s = 0.f, ag_c = 0.f;
     float2 ag_p = make_float2(0.f, 0.f);
-    if (lane < A) {
-        if (ag.headings) {                                   // ms_physics' cache, valid while the angle has not changed
-            const float4 h = reinterpret_cast<const float4*>(ag.headings)[n*A + lane];
-            const float angle = ag.angles[n*A + lane];
-            ag_s = h.y; ag_c = h.z;
+    const int lane_a = n*A + min(lane, A - 1);   // (lanes past the last agent re-read it: loads without a guard overlap)
+    if (ag.headings) {
+        const float4 h = reinterpret_cast<const float4*>(ag.headings)[lane_a];
+        const float angle = ag.angles[lane_a];
+        const float2 p_ = reinterpret_cast<const float2*>(ag.positions)[lane_a];
+        if (lane < A) {                                      // ms_physics' cache, valid while the angle has not changed
+            ag_s = h.y; ag_c = h.z; ag_p = p_;
             if (f_bits(h.x) != f_bits(angle)) { const float2 sc_ = sincospi_called(angle/180.f); ag_s = sc_.x; ag_c = sc_.y; }   // (rare: a respawn)
-        } else if (out.workspace) {
+        }
+    } else if (lane < A) {
+        if (out.workspace) {
             const float2 sc_ = reinterpret_cast<const float2*>(out.workspace + 16 + ((n_fans + 1) & ~1))[n*A + lane];
             ag_s = sc_.x; ag_c = sc_.y;
         } else {
@@ -1522,12 +1526,18 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
 
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
+    // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
+    // asked for here, for every lane, from a row that exists (the env's first for a miss): unconditional loads are
+    // the ones hipcc lets overlap.
+    const int row = min(max(nearest_idx, 0), max(L - 1, 0));
+    const float4 hw_mem = ln[row];
+    const int tex_w = sc.textures_widths[base + row], tstart = sc.textures_starts[base + row];
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
     if (__ballot((nearest_idx >= 0) & (nearest_idx < AF))) aw = agent_line(nearest_idx);
     if (nearest_idx >= 0) {
-        hw = (nearest_idx < AF) ? aw : ln[nearest_idx];
+        hw = (nearest_idx < AF) ? aw : hw_mem;
         const float vx = hw.z - hw.x, vy = hw.w - hw.y;
         const float d = rx*vy - ry*vx;
         const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
@@ -1564,19 +1574,19 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
     }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    Filt f = Filt{0, 0, 0.f, 0.f};
-    int tstart = 0;
-    if (is_hit) {
-        const int start = base + nearest_idx;
-        f = tex_filter(loc, sc.textures_widths[start]);
-        tstart = sc.textures_starts[start];
-    }
-    if (is_hit & !dynamic) intensity = f.lw*sc.baked_vals[tstart + f.l] + f.rw*sc.baked_vals[tstart + f.r];
+    // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
+    // env's first line and throws the result away)
+    const Filt f = tex_filter(is_hit ? loc : 0.f, tex_w);
+    const float bk_l = sc.baked_vals[tstart + f.l], bk_r = sc.baked_vals[tstart + f.r];
+    const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
+    const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
+    const float tl0 = tl[0], tl1 = tl[1], tl2 = tl[2], tr0 = tr[0], tr1 = tr[1], tr2 = tr[2];
+    if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
     if constexpr (OBS == 1) {
         if (out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
             bool fresh = false;
             if (is_hit) {
-                const float wf = (float)sc.textures_widths[base + nearest_idx];
+                const float wf = (float)tex_w;
                 const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
                 const int epoch = out.seen_epoch[n];
                 fresh = atomicExch(&out.seen_stamp[tstart + along], epoch) != epoch;   // exactly one ray per texel sees the old stamp
@@ -1596,12 +1606,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
 
     if (is_hit) {
-        const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
-        const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
         const float dn = 1 - dt*dt;
-        s0 = dn*intensity*(f.lw*tl[0] + f.rw*tr[0]);
-        s1 = dn*intensity*(f.lw*tl[1] + f.rw*tr[1]);
-        s2 = dn*intensity*(f.lw*tl[2] + f.rw*tr[2]);
+        s0 = dn*intensity*(f.lw*tl0 + f.rw*tr0);
+        s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
+        s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
     }
     if (!OBS || out.screen) {
         // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
