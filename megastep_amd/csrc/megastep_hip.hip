@@ -244,19 +244,24 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     const float2* pos2 = reinterpret_cast<const float2*>(ag.positions);
     const float2* vel2 = reinterpret_cast<const float2*>(ag.velocity);
 
-    // the first wall chunks are requested before anything else: nothing below depends on them until the sweep
     const int L = sc.lines_widths[n];
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
+    // one lane per agent: its state (kept for the epilogue) - asked for first, because it is needed first and loads
+    // return in order; lanes past the last agent re-read it (loads without a guard overlap, see below)
+    float2 my_p, my_v;
+    float my_w, my_ang;
+    {
+        const int i = n*A + min(lane, A - 1);
+        my_p = pos2[i]; my_v = vel2[i]; my_w = ag.angvelocity[i]; my_ang = ag.angles[i];
+    }
+    // then the first wall chunks: nothing below depends on them until the sweep
     float4 w[PHYS_AHEAD];
-    #pragma unroll
     // (unconditional loads from a clamped row - behind a branch hipcc waits for every load in flight at the first use of
     // any of them; lanes past the last wall are masked by `live` in the sweep)
+    #pragma unroll
     for (int k = 0; k < PHYS_AHEAD; k++) w[k] = ln[min(AF + k*WAVE + lane, max(L - 1, 0))];
+    if (lane >= A) { my_p = make_float2(0.f, 0.f); my_v = make_float2(0.f, 0.f); my_w = 0.f; my_ang = 0.f; }
 
-    // one lane per agent: its state and reach ...
-    float2 my_p = make_float2(0.f, 0.f), my_v = make_float2(0.f, 0.f);   // agent `lane`, kept for the epilogue
-    float my_w = 0.f, my_ang = 0.f;
-    if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
     // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)
     auto spawn_pose = [&](const int i, float2& p, float& ang) {
         const long long c = min(max(ex.respawn_choice[i], 0ll), (long long)ex.n_spawns - 1);
@@ -880,17 +885,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
-    // IMPL 2 asks for its first chunks of lines before anything else: nothing below needs them until the raycast, and one
-    // chunk's work does not hide the next one's trip (1600 cycles under load) on its own
-    constexpr int AHEAD = 3;                     // chunks in flight
-    float4 w_first[AHEAD];
-    if constexpr (IMPL == 2) {
-        // (unconditional loads from a clamped row: behind a branch hipcc waits for every load in flight at the first
-        // use of any of them, which turns "in flight" into "one at a time"; rows that are not wanted are ignored later)
-        #pragma unroll
-        for (int k = 0; k < AHEAD; k++) w_first[k] = ln[min(k*WAVE + lane, max(L - 1, 0))];
-    }
-
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
     // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
     float ag_s = 0.f, ag_c = 0.f;
@@ -914,6 +908,18 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
+    // IMPL 2 asks for its first chunks of lines here - right behind the agents' state, which is needed first and, loads
+    // returning in order, would otherwise wait for them: nothing needs the lines until the raycast, and one chunk's work
+    // does not hide the next one's trip (1600 cycles under load) on its own
+    constexpr int AHEAD = 3;                     // chunks in flight
+    float4 w_first[AHEAD];
+    if constexpr (IMPL == 2) {
+        // (unconditional loads from a clamped row: behind a branch hipcc waits for every load in flight at the first
+        // use of any of them, which turns "in flight" into "one at a time"; rows that are not wanted are ignored later)
+        #pragma unroll
+        for (int k = 0; k < AHEAD; k++) w_first[k] = ln[min(k*WAVE + lane, max(L - 1, 0))];
+    }
+
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
     // there is one.  Lanes exchange data in here: call it from wave-uniform control flow only.
     auto agent_line = [&](const int l_) {

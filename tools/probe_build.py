@@ -16,7 +16,7 @@ rep("                __builtin_amdgcn_wave_barrier();\n            }\n          
     "                __builtin_amdgcn_wave_barrier();\n            }\n            __builtin_amdgcn_wave_barrier();\n            TICK(3)\n        }\n        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n        const unsigned long long best")
 rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(4)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
 rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(5)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
-rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(6)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
+rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n", "    TICK(6)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n")
 src = src.rstrip()
 assert src.count("    // ---- pooled observations") == 1
 src = src.replace("    // ---- pooled observations", """    TICK(7)

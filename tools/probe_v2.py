@@ -25,7 +25,7 @@ def build():
     rep("        if (n_pairs) drain();\n", "        TICK(1)\n        if (n_pairs) drain();\n", i2)
     rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(5)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
     rep("    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit", "    TICK(6)\n    // ---- pass 3: shade (kernels.cu:407-450)\n    const bool is_hit")
-    rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {", "    TICK(7)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n    Filt f = Filt{0, 0, 0.f, 0.f};\n    int tstart = 0;\n    if (is_hit) {")
+    rep("    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n", "    TICK(7)\n    float s0 = 0.f, s1 = 0.f, s2 = 0.f;\n")
     # telemetry variables of IMPL 2 are local to its branch: export them through function-scope shadows
     rep("    int nearest_idx = -1;\n", "    int nearest_idx = -1; int probe_pairs_ = 0, probe_windows_ = 0;\n")
     i2 = src.index("    } else if constexpr (IMPL == 2) {")
