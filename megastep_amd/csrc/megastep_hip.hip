@@ -1259,9 +1259,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int before = 0;                      // marks in earlier windows = lines that start before this one
             n_pairs_total += n_pairs; n_windows += (n_pairs + WAVE - 1)/WAVE;
+            // the mark bits of all 64 possible windows in one read: lane w holds window w's, and each window fetches
+            // its own with two v_readlane - no LDS round trip per window
+            const unsigned long long my_marks = reinterpret_cast<const unsigned long long*>(s_mark_w)[lane];
             for (int p0 = 0; p0 < n_pairs; p0 += WAVE) {
-                const unsigned mlo = __builtin_amdgcn_readfirstlane(s_mark_w[p0 >> 5]);
-                const unsigned mhi = __builtin_amdgcn_readfirstlane(s_mark_w[(p0 >> 5) + 1]);
+                const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_marks, p0 >> 6);
+                const unsigned mhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_marks >> 32), p0 >> 6);
                 const unsigned long long M = ((unsigned long long)mhi << 32) | mlo;
                 // marks at positions 0..lane of this window, via the bits of M >> 1 below the lane
                 const unsigned long long Ms = M >> 1;
@@ -1333,16 +1336,17 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         float4 w_next[AHEAD];                                                // the next chunks' lines travel while this one is worked on
         #pragma unroll
         for (int k = 0; k < AHEAD; k++) w_next[k] = w_first[k];
-        auto next_chunk = [&](const int c0) {                                // chunk c0's lines; asks for chunk c0 + AHEAD*64
-            const float4 w = w_next[0];
+        // (the chunk loop is unrolled by hand over the chunks in flight: rotating them through registers would make the
+        // moves wait for the loads they move)
+        for (int c0 = 0; c0 < L; c0 += AHEAD*WAVE) {
             #pragma unroll
-            for (int k = 0; k + 1 < AHEAD; k++) w_next[k] = w_next[k + 1];
-            w_next[AHEAD - 1] = fetch(c0 + AHEAD*WAVE);
-            return w;
-        };
-        for (int c0 = 0; c0 < L; c0 += WAVE) {
-            const float4 w_now = next_chunk(c0);
-            admit(w_now, c0 + lane, c0 + lane < L, c0 < AF);
+            for (int k = 0; k < AHEAD; k++) {
+                const int ck = c0 + k*WAVE;
+                const float4 w_now = w_next[k];
+                w_next[k] = fetch(ck + AHEAD*WAVE);
+                if (ck >= L) continue;                                       // uniform
+                admit(w_now, ck + lane, ck + lane < L, ck < AF);
+            }
         }
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -14,7 +14,7 @@ def build():
         src = src.replace(old, new)
     rep("    extern __shared__ float4 s_dyn_all[];",
         "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_flush_ = 0;\n#define TICKP(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    extern __shared__ float4 s_dyn_all[];")
-    rep("    // one lane per agent: its state and reach ...\n", "    TICKP(0)\n    // one lane per agent: its state and reach ...\n")
+    rep("    // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)\n", "    TICKP(0)\n    // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)\n")
     rep("    // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane\n", "    TICKP(1)\n    // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane\n")
     rep("    int cnt = 0;\n    auto flush = [&]() {\n", "    TICKP(2)\n    int cnt = 0;\n    auto flush = [&]() {\n        TICKP(3) n_flush_++;\n")
     rep("        __builtin_amdgcn_wave_barrier();\n        cnt = 0;\n    };\n    // lane = wall: which agents' reach boxes", "        __builtin_amdgcn_wave_barrier();\n        cnt = 0;\n        TICKP(4)\n    };\n    // lane = wall: which agents' reach boxes")
