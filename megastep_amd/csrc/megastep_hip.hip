@@ -246,20 +246,20 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
 
     const int L = sc.lines_widths[n];
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
-    // one lane per agent: its state (kept for the epilogue) - asked for first, because it is needed first and loads
-    // return in order; lanes past the last agent re-read it (loads without a guard overlap, see below)
+    // the first wall chunks are requested before anything else: nothing below depends on them until the sweep, and on
+    // large maps the stream of walls is what the kernel lasts (asking for the agents first cost 12 % there).
+    // (Unconditional loads from a clamped row - behind a branch hipcc waits for every load in flight at the first use
+    // of any of them; lanes past the last wall are masked by `live` in the sweep.)
+    float4 w[PHYS_AHEAD];
+    #pragma unroll
+    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = ln[min(AF + k*WAVE + lane, max(L - 1, 0))];
+    // one lane per agent: its state (kept for the epilogue); lanes past the last agent re-read it and forget it
     float2 my_p, my_v;
     float my_w, my_ang;
     {
         const int i = n*A + min(lane, A - 1);
         my_p = pos2[i]; my_v = vel2[i]; my_w = ag.angvelocity[i]; my_ang = ag.angles[i];
     }
-    // then the first wall chunks: nothing below depends on them until the sweep
-    float4 w[PHYS_AHEAD];
-    // (unconditional loads from a clamped row - behind a branch hipcc waits for every load in flight at the first use of
-    // any of them; lanes past the last wall are masked by `live` in the sweep)
-    #pragma unroll
-    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = ln[min(AF + k*WAVE + lane, max(L - 1, 0))];
     if (lane >= A) { my_p = make_float2(0.f, 0.f); my_v = make_float2(0.f, 0.f); my_w = 0.f; my_ang = 0.f; }
 
     // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)
@@ -526,13 +526,15 @@ __device__ inline float grid_light_intensity(
     // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
     uint4 st = make_uint4(0u, 0u, 0u, 0u);
     uint2 lst = make_uint2(0u, 0u);              // the cell's candidate list: first pool word, 0x80000000 | count
-    if (dynamic) {
+    {
+        // (every lane reads a cell that exists - its own, or the env's first: loads without a guard overlap)
         const float fx = floorf((cx_l - geom.x)/sc.lg_cell), fy = floorf((cy_l - geom.y)/sc.lg_cell);
-        if ((fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w)) {
-            const size_t cell_id = (size_t)sc.lg_starts[n] + (int)fy*(int)geom.z + (int)fx;
-            st = reinterpret_cast<const uint4*>(sc.lg_vals)[cell_id];
-            if (sc.lg_list) lst = reinterpret_cast<const uint2*>(sc.lg_list)[cell_id];
-        }
+        const bool inside = dynamic & (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);
+        const size_t cell_id = (size_t)sc.lg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0);
+        const uint4 st_ = reinterpret_cast<const uint4*>(sc.lg_vals)[cell_id];
+        uint2 lst_ = make_uint2(0u, 0u);
+        if (sc.lg_list) lst_ = reinterpret_cast<const uint2*>(sc.lg_list)[cell_id];   // (uniform)
+        if (inside) { st = st_; lst = lst_; }
     }
     const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
     // ---- the sum over the lights the grid proves unblocked, in light order.  Rays around one target mostly share
