@@ -231,8 +231,9 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     __shared__ int s_tag_all[WPB][PHYS_PAIRS];       // ... this agent
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int lane = WPB == 1 ? threadIdx.x : threadIdx.x & (WAVE - 1), wv = WPB == 1 ? 0 : threadIdx.x >> 6;   // (0 spelled out: keeps n scalar)
-    const int n = blockIdx.x*WPB + wv;
-    if (n >= sc.n_envs) return;                  // waves are independent: no workgroup barriers below
+    // a wave works through envs blockIdx.x*WPB + wv, + gridDim.x*WPB, ... (one env per wave unless the host asks for
+    // fewer, fatter waves: MEGASTEP_PHYS_EPW); waves are independent: no workgroup barriers below
+    for (int n = blockIdx.x*WPB + wv; n < sc.n_envs; n += gridDim.x*WPB) {
     float4* const s_dyn = s_dyn_all + (size_t)wv*slice;
     float4* const s_wall = s_wall_all[wv];
     int* const s_tag = s_tag_all[wv];
@@ -256,11 +257,16 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     // one lane per agent: its state (kept for the epilogue); lanes past the last agent re-read it and forget it
     float2 my_p, my_v;
     float my_w, my_ang;
+#if MS_PHYS_OPTS & 1
+    my_p = make_float2(0.f, 0.f); my_v = make_float2(0.f, 0.f); my_w = 0.f; my_ang = 0.f;
+    if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
+#else
     {
         const int i = n*A + min(lane, A - 1);
         my_p = pos2[i]; my_v = vel2[i]; my_w = ag.angvelocity[i]; my_ang = ag.angles[i];
     }
     if (lane >= A) { my_p = make_float2(0.f, 0.f); my_v = make_float2(0.f, 0.f); my_w = 0.f; my_ang = 0.f; }
+#endif
 
     // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)
     auto spawn_pose = [&](const int i, float2& p, float& ang) {
@@ -474,6 +480,8 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
                 ex.imu[3*i + 2] = (-s_*v.x + c_*v.y)/ex.imu_speed_scale;
             }
         }
+    }
+    __builtin_amdgcn_wave_barrier();             // (the next env reuses this wave's LDS)
     }
 }
 
@@ -721,6 +729,11 @@ __device__ inline float grid_light_intensity(
 #endif
 #ifndef MS_V2_OPTS
 #define MS_V2_OPTS 0
+#endif
+//   MS_PHYS_OPTS  bit 0: the physics kernel reads its agents behind a `lane < A` guard (so everything requested before
+//                 them has arrived by then)
+#ifndef MS_PHYS_OPTS
+#define MS_PHYS_OPTS 0
 #endif
 constexpr int GROUPS = MS_GROUPS;     // ray groups (sub-wedges) per wave
 constexpr int GSIZE = WAVE/GROUPS;    // rays per group
@@ -2413,9 +2426,13 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
     // MEGASTEP_PHYS_WPB=4: four envs per workgroup (A/B knob; the waves stay independent either way)
     const char* wpb_env = getenv("MEGASTEP_PHYS_WPB");
     const bool four = wpb_env && wpb_env[0] == '4' && slice*16*4 <= 60*1024;
+    // MEGASTEP_PHYS_EPW=k: k envs per wave, one after the other (A/B knob)
+    const char* epw_env = getenv("MEGASTEP_PHYS_EPW");
+    const int epw = epw_env ? max(1, min(atoi(epw_env), 64)) : 1;
+    const int n_waves = (sc->n_envs + epw - 1)/epw;
 #define MS_LAUNCH_PHYSICS(M, E) \
-    do { if (four) hipLaunchKernelGGL((physics_kernel<M, E, 4>), dim3((sc->n_envs + 3)/4), dim3(4*WAVE), slice*16*4, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); \
-         else hipLaunchKernelGGL((physics_kernel<M, E, 1>), dim3(sc->n_envs), dim3(WAVE), slice*16, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); } while (0)
+    do { if (four) hipLaunchKernelGGL((physics_kernel<M, E, 4>), dim3((n_waves + 3)/4), dim3(4*WAVE), slice*16*4, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); \
+         else hipLaunchKernelGGL((physics_kernel<M, E, 1>), dim3(n_waves), dim3(WAVE), slice*16, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); } while (0)
     if (mv && ex) MS_LAUNCH_PHYSICS(1, 1);
     else if (ex) MS_LAUNCH_PHYSICS(0, 1);
     else if (mv) MS_LAUNCH_PHYSICS(1, 0);
