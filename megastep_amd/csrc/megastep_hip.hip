@@ -395,6 +395,25 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             bx1[t] = have ? readlane_f(mine.z, min(t, A - 1)) : -INFINITY; by1[t] = have ? readlane_f(mine.w, min(t, A - 1)) : -INFINITY;
         }
     }
+#if MS_PHYS_OPTS & 1
+    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
+        #pragma unroll
+        for (int k = 0; k < PHYS_AHEAD; k++) {
+            const float4 u = w[k];
+            const bool live = l0 + k*WAVE + lane < L;
+            w[k] = ln[min(l0 + (k + PHYS_AHEAD)*WAVE + lane, max(L - 1, 0))];
+            if (l0 + k*WAVE >= L) continue;                             // uniform
+            const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
+            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
+            for (int t = 0; t < A; t++) {
+                const float4 bx = s_box[t];
+                const bool in = live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w)));
+                if (cnt > PHYS_PAIRS - WAVE) flush();
+                keep(t, in, u);
+            }
+        }
+    }
+#else
     for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
@@ -429,6 +448,7 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             }
         }
     }
+#endif
     if (cnt) flush();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // epilogue, kernels.cu:224-227
@@ -723,10 +743,15 @@ __device__ inline float grid_light_intensity(
 #ifndef MS_V2_OPTS
 #define MS_V2_OPTS 0
 #endif
+//   MS_PHYS_OPTS  bit 0: the physics sweep reads the agents' reach boxes from LDS, one agent at a time
+#ifndef MS_PHYS_OPTS
+#define MS_PHYS_OPTS 0
+#endif
 
 constexpr int GROUPS = MS_GROUPS;     // ray groups (sub-wedges) per wave
 constexpr int GSIZE = WAVE/GROUPS;    // rays per group
 constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair list in the dynamic-light pass
+constexpr int MS_TELEMETRY_MAGIC = 0x7e1e7e1e;   // in workspace[5]: the caller wants the pair counters (workspace[3], [4])
 
 struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
 
@@ -1118,7 +1143,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
         // line order into the ray's own state, which lives in the ray's lane.
         const unsigned long long amb = __ballot(ambiguous);
-        if (out.workspace && lane == 0) {
+        // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
+        // per wave on one address are 1.3 ms at 262144 waves
+        if (out.workspace && lane == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
             atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
         }
         if (amb && out.workspace && lane == 0) {
@@ -1376,7 +1403,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1
         const unsigned long long amb = __ballot(ambiguous);
-        if (out.workspace && lane == 0) {
+        // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
+        // per wave on one address are 1.3 ms at 262144 waves
+        if (out.workspace && lane == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
             atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
         }
         if (amb && out.workspace && lane == 0) {

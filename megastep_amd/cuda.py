@@ -495,6 +495,8 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
         result._key = key
         if seen is not None:
             result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = (t.data_ptr() for t in seen)
+    if telemetry:
+        result._telemetry[5] = 0x7e1e7e1e                       # asks the kernels for their pair counters (tools/pair_stats.py)
     with _on(dev):
         use_cache = agents._cached and not telemetry
         _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
@@ -542,4 +544,5 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
     result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None, obs_centre)
     result._struct = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth, ptr(7))
     result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel; read by the tests
+    result._telemetry.zero_()                                             # (once per allocation: word 5 is the telemetry request)
     return result
