@@ -217,7 +217,7 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
 constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave (six: no faster at 300 walls, 12 % slower at 1000 - fewer waves fit)
-constexpr int PHYS_PAIRS = 5*WAVE;     // capacity of a wave's (wall, agent) pair list: a flush's worth + a chunk's worth for four agents
+constexpr int PHYS_PAIRS = 2*WAVE;     // capacity of a wave's (wall, agent) pair list: a flush's worth + one agent's worth of a chunk
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
 // EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
@@ -339,8 +339,7 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
         }
     }
 
-    // (wall, agent) pairs collect in an LDS list with room for a chunk's worth (four agents) on top of a flush's worth,
-    // so that the sweep asks "is there room" once per chunk rather than once per agent.
+    // (wall, agent) pairs collect in an LDS list with room for one agent's worth of a chunk on top of a flush's worth.
     int cnt = 0;
     auto flush = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -381,21 +380,6 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             cnt += __popcll(m);
         }
     };
-    // Up to four agents: their boxes sit in scalar registers and one ballot per chunk says whether any wall of it is
-    // near any of them - mostly none is, and the chunk costs a dozen compares.  (A box no wall can touch for the
-    // missing agents; a NaN box, from NaN velocities, rejects nothing, as before.)
-    constexpr int BOXED = 4;
-    float bx0[BOXED], by0[BOXED], bx1[BOXED], by1[BOXED];
-    {
-        const float4 mine = s_box[min(lane, A - 1)];
-        #pragma unroll
-        for (int t = 0; t < BOXED; t++) {
-            const bool have = t < A;
-            bx0[t] = have ? readlane_f(mine.x, min(t, A - 1)) : INFINITY;  by0[t] = have ? readlane_f(mine.y, min(t, A - 1)) : INFINITY;
-            bx1[t] = have ? readlane_f(mine.z, min(t, A - 1)) : -INFINITY; by1[t] = have ? readlane_f(mine.w, min(t, A - 1)) : -INFINITY;
-        }
-    }
-#if MS_PHYS_OPTS & 1
     for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
@@ -413,42 +397,6 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             }
         }
     }
-#else
-    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
-        #pragma unroll
-        for (int k = 0; k < PHYS_AHEAD; k++) {
-            const float4 u = w[k];
-            const bool live = l0 + k*WAVE + lane < L;
-            // the chunk PHYS_AHEAD further on takes this one's place
-            w[k] = ln[min(l0 + (k + PHYS_AHEAD)*WAVE + lane, max(L - 1, 0))];
-            if (l0 + k*WAVE >= L) continue;                             // uniform
-            const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
-            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
-            if (A <= BOXED) {
-                bool in[BOXED];
-                bool any = false;
-                #pragma unroll
-                for (int t = 0; t < BOXED; t++) {
-                    in[t] = false;
-                    if (t < A) in[t] = live & (odd | !((x1 < bx0[t]) | (x0 > bx1[t]) | (y1 < by0[t]) | (y0 > by1[t])));   // (uniform)
-                    any |= in[t];
-                }
-                if (__ballot(any)) {
-                    if (cnt > PHYS_PAIRS - BOXED*WAVE) flush();            // room for whatever this chunk may add
-                    #pragma unroll
-                    for (int t = 0; t < BOXED; t++) if (t < A) keep(t, in[t], u);
-                }
-            } else {
-                #pragma unroll 1
-                for (int t = 0; t < A; t++) {
-                    if (cnt > PHYS_PAIRS - WAVE) flush();
-                    const float4 bx = s_box[t];
-                    keep(t, live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w))), u);
-                }
-            }
-        }
-    }
-#endif
     if (cnt) flush();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // epilogue, kernels.cu:224-227
@@ -743,10 +691,7 @@ __device__ inline float grid_light_intensity(
 #ifndef MS_V2_OPTS
 #define MS_V2_OPTS 0
 #endif
-//   MS_PHYS_OPTS  bit 0: the physics sweep reads the agents' reach boxes from LDS, one agent at a time
-#ifndef MS_PHYS_OPTS
-#define MS_PHYS_OPTS 0
-#endif
+
 
 constexpr int GROUPS = MS_GROUPS;     // ray groups (sub-wedges) per wave
 constexpr int GSIZE = WAVE/GROUPS;    // rays per group

@@ -148,3 +148,25 @@ def test_crawling_agents_meet_far_walls_like_the_reference():
     assert (prog_ref < 1).sum() > 5
     util.assert_physics_matches(c, p, prog_ref, agents_ref)
     np.testing.assert_array_equal(p.progress.cpu().numpy(), prog_ref)
+
+
+def test_worlds_past_the_heading_cache_limit():
+    """More than cuda.Agents.HEADING_CACHE_MAX_AGENTS agents: ms_render runs its own prep kernel and works from the
+    workspace instead of the cache physics leaves. Same results; and no slower per wave than below the limit (a telemetry
+    counter once cost this path a millisecond of same-address atomics)."""
+    from megastep_amd import cuda
+    c, _, _ = _big_world(12288, 4, 64, 130, n_distinct=32, fast=True)
+    assert c.n_envs*c.n_agents > cuda.Agents.HEADING_CACHE_MAX_AGENTS and not c.agents._use_cache
+    _check_sample(c, [0, 31, 32, 7000, 12287], steps=2)
+    rng = np.random.RandomState(0)
+    util.random_velocities(c, rng)
+    held = cuda.render(c.scenery, c.agents)
+    torch.cuda.synchronize()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(5):
+        cuda.render(c.scenery, c.agents, out=held)
+    stop.record()
+    torch.cuda.synchronize()
+    per_render_ms = start.elapsed_time(stop)/5
+    assert per_render_ms < .6, f'{per_render_ms:.3f} ms per render of 49152 ray groups (expected ~0.15)'
