@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include "../../include/megastep_hip.h"
 
@@ -480,8 +481,15 @@ __device__ inline bool light_blocked(P2 I, P2 U, float ax, float ay, float vx, f
 struct LightPair { float ax, ay, vx, vy, ix, iy; int light; int pad; };
 constexpr int LG_PAIRS = 64;
 
+struct LightScene {                   // what grid_light_intensity reads of an MsScenery (handed over by value)
+    int n_agents, n_model;
+    const float* lights_vals; const int* lights_widths; const int* lights_starts;
+    const unsigned* lg_vals; const int* lg_starts; const float* lg_geom; float lg_cell;
+    const unsigned* lg_list; const unsigned* lg_pool;
+};
+
 __device__ inline float grid_light_intensity(
-        const MsScenery& sc, const MsAgents& ag, const int n, const int lane, const bool dynamic, const int nearest_idx,
+        const LightScene sc, const MsAgents& ag, const int n, const int lane, const bool dynamic, const int nearest_idx,
         const float cx_l, const float cy_l, const int L, const float4* __restrict__ ln,
         LightPair* s_pair, unsigned* s_shadow) {
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
@@ -503,7 +511,9 @@ __device__ inline float grid_light_intensity(
         const uint4 st_ = reinterpret_cast<const uint4*>(sc.lg_vals)[cell_id];
         uint2 lst_ = make_uint2(0u, 0u);
         if (sc.lg_list) lst_ = reinterpret_cast<const uint2*>(sc.lg_list)[cell_id];   // (uniform)
-        if (inside) { st = st_; lst = lst_; }
+        // (component by component: a whole-vector select made hipcc keep `st` in scratch and index it)
+        st.x = inside ? st_.x : 0u; st.y = inside ? st_.y : 0u; st.z = inside ? st_.z : 0u; st.w = inside ? st_.w : 0u;
+        lst.x = inside ? lst_.x : 0u; lst.y = inside ? lst_.y : 0u;
     }
     const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
     // ---- the sum over the lights the grid proves unblocked, in light order.  Rays around one target mostly share
@@ -776,6 +786,21 @@ __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int*
     }
 }
 
+// The render kernel's parameter list as a struct, and a pointer to the kernel-argument segment typed as one.  What the
+// kernel only needs at its end - texture and baked-light pointers, the light grid, the output planes - is read through
+// this pointer THERE: as plain parameters hipcc loads them at the top, runs out of scalar registers, and parks them in
+// vector-register lanes, which costs two memory round trips (a parked value has to have arrived) and ~40 instructions
+// per wave before the first ray is cast.  The asm statement keeps the loads from being hoisted back up.
+struct RenderArgs { MsScenery sc; MsAgents ag; MsRender out; float agent_radius, half_screen; int R, n_fans; RenderConsts rc; };
+static_assert(offsetof(RenderArgs, ag) == sizeof(MsScenery) && offsetof(RenderArgs, n_fans) + 4 == offsetof(RenderArgs, rc),
+              "RenderArgs must mirror render_kernel's parameters");
+typedef const RenderArgs __attribute__((address_space(4)))* LateArgs;
+__device__ inline LateArgs late_args() {
+    LateArgs p = (LateArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // Conservative interval [lo, lo + len) of a wave's rays that can hit a line, from the agent-frame coordinates of its
 // ends (x forward, y left; c_a - (y/x) c_b is the continuous ray index).  Everything here only feeds the cull, whose
 // margin is 10^5 roundings wide: fused multiply-adds and approximate reciprocals are fine.
@@ -896,24 +921,31 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
     // there is one.  Lanes exchange data in here: call it from wave-uniform control flow only.
-    auto agent_line = [&](const int l_) {
+    // The model rows the two early users want, asked for up front and for every lane: row `lane` (the draw step's) and
+    // row `lane mod M` (the first chunk's agent lines).  Fetched where they are used, behind those users' conditions,
+    // they would drain the line chunks in flight.
+    const float4 mdl_draw = reinterpret_cast<const float4*>(sc.model)[min(lane, sc.n_model - 1)];
+    const float4 mdl_first = reinterpret_cast<const float4*>(sc.model)[lane - div_by(lane, rc.by_m)*sc.n_model];
+    auto agent_line_m = [&](const int l_, const bool have_row, const float4 row) {
         const int l = min(max(l_, 0), AF - 1);
         if (A > WAVE) return drawn_line(sc, ag, n, l);
         const int la = div_by(l, rc.by_m);
         const float s_ = __shfl(ag_s, la, WAVE), c_ = __shfl(ag_c, la, WAVE);
         const float px_ = __shfl(ag_p.x, la, WAVE), py_ = __shfl(ag_p.y, la, WAVE);
-        const float4 mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];
+        float4 mdl = row;
+        if (!have_row) mdl = reinterpret_cast<const float4*>(sc.model)[l - la*sc.n_model];   // (uniform)
         float4 w;
         w.x = c_*mdl.x - s_*mdl.y + px_; w.y = s_*mdl.x + c_*mdl.y + py_;
         w.z = c_*mdl.z - s_*mdl.w + px_; w.w = s_*mdl.z + c_*mdl.w + py_;
         return w;
     };
+    auto agent_line = [&](const int l_) { return agent_line_m(l_, false, make_float4(0.f, 0.f, 0.f, 0.f)); };
     // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
     // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
     // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
     if (g == 0) {
         for (int m0 = 0; m0 < sc.n_model; m0 += WAVE) {
-            const float4 w = agent_line(a*sc.n_model + m0 + lane);
+            const float4 w = agent_line_m(a*sc.n_model + m0 + lane, m0 == 0, mdl_draw);
             if (m0 + lane < sc.n_model) ln[a*sc.n_model + m0 + lane] = w;
         }
     }
@@ -1212,9 +1244,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // the full work on one line per lane (any line `l`; `agent_lines`: some lane holds one, wave-uniform): the
         // ray-independent half of the intersection, and the conservative interval [lo, lo + len) of this wave's rays
         // that can hit it.  Every lane comes in; dead ones leave with len 0
-        auto line_math = [&](float4 w, const int l, const bool live, const bool agent_lines, Cand& cd, int& lo, int& len) {
+        auto line_math = [&](float4 w, const int l, const bool live, const bool agent_lines, const bool first_chunk, Cand& cd, int& lo, int& len) {
             if (agent_lines) {
-                const float4 aw = agent_line(l);
+                const float4 aw = agent_line_m(l, first_chunk, mdl_first);
                 if (l < AF) w = aw;
             }
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
@@ -1287,10 +1319,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         };
 
         // a batch of up to 64 lines (lane = line `l`) into the list: interval, pair numbering, compaction
-        auto admit = [&](const float4 w, const int l, const bool live, const bool agent_lines) {
+        auto admit = [&](const float4 w, const int l, const bool live, const bool agent_lines, const bool first_chunk) {
             Cand cd;
             int lo = 0, len = 0;
-            line_math(w, l, live, agent_lines, cd, lo, len);
+            line_math(w, l, live, agent_lines, first_chunk, cd, lo, len);
             const bool seen = len > 0;
             const unsigned long long vm = __ballot(seen);
             if (!vm) return;                                                 // uniform
@@ -1321,7 +1353,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const float4 w_now = w_next[k];
                 w_next[k] = fetch(ck + AHEAD*WAVE);
                 if (ck >= L) continue;                                       // uniform
-                admit(w_now, ck + lane, ck + lane < L, ck < AF);
+                admit(w_now, ck + lane, ck + lane < L, ck < AF, ck == 0);
             }
         }
         if (n_pairs) drain();
@@ -1365,7 +1397,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             for (int c0 = 0; c0 < L; c0 += WAVE) {
                 Cand mine;
                 int lo = 0, len = 0;
-                line_math(fetch(c0), c0 + lane, c0 + lane < L, c0 < AF, mine, lo, len);
+                line_math(fetch(c0), c0 + lane, c0 + lane < L, c0 < AF, c0 == 0, mine, lo, len);
                 __builtin_amdgcn_wave_barrier();
                 s_cand_w[lane] = mine;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1517,9 +1549,14 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
     // asked for here, for every lane, from a row that exists (the env's first for a miss): unconditional loads are
     // the ones hipcc lets overlap.
+    const LateArgs late = late_args();           // (see RenderArgs)
+    const int* const l_tex_widths = late->sc.textures_widths;
+    const int* const l_tex_starts = late->sc.textures_starts;
+    const float* const l_tex_vals = late->sc.textures_vals;
+    const float* const l_baked = late->sc.baked_vals;
     const int row = min(max(nearest_idx, 0), max(L - 1, 0));
     const float4 hw_mem = ln[row];
-    const int tex_w = sc.textures_widths[base + row], tstart = sc.textures_starts[base + row];
+    const int tex_w = l_tex_widths[base + row], tstart = l_tex_starts[base + row];
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1536,11 +1573,17 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
     const size_t o = ((size_t)n*A + a)*R + r;
     const float dist = nearest_s*rlen;
-    if (r < R) {
-        if (!OBS || out.indices) out.indices[o] = nearest_idx;
-        if (!OBS || out.locations) out.locations[o] = loc;
-        if (!OBS || out.dots) out.dots[o] = dt;
-        if (!OBS || out.distances) out.distances[o] = dist;
+    {
+        int* const o_indices = late->out.indices;
+        float* const o_locations = late->out.locations;
+        float* const o_dots = late->out.dots;
+        float* const o_distances = late->out.distances;
+        if (r < R) {
+            if (!OBS || o_indices) o_indices[o] = nearest_idx;
+            if (!OBS || o_locations) o_locations[o] = loc;
+            if (!OBS || o_dots) o_dots[o] = dt;
+            if (!OBS || o_distances) o_distances[o] = dist;
+        }
     }
 
     // ---- pass 3: shade (kernels.cu:407-450)
@@ -1555,7 +1598,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
-            intensity = grid_light_intensity(sc, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
+            const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
+                                 late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
+                                 late->sc.lg_list, late->sc.lg_pool};         // (fetched now: see RenderArgs)
+            intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
                 reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]));
         } else if (out.workspace) {
             if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
@@ -1565,9 +1611,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
     // env's first line and throws the result away)
     const Filt f = tex_filter(is_hit ? loc : 0.f, tex_w);
-    const float bk_l = sc.baked_vals[tstart + f.l], bk_r = sc.baked_vals[tstart + f.r];
-    const float* __restrict__ tl = sc.textures_vals + 3*(size_t)(tstart + f.l);
-    const float* __restrict__ tr = sc.textures_vals + 3*(size_t)(tstart + f.r);
+    const float bk_l = l_baked[tstart + f.l], bk_r = l_baked[tstart + f.r];
+    const float* __restrict__ tl = l_tex_vals + 3*(size_t)(tstart + f.l);
+    const float* __restrict__ tr = l_tex_vals + 3*(size_t)(tstart + f.r);
     const float tl0 = tl[0], tl1 = tl[1], tl2 = tl[2], tr0 = tr[0], tr1 = tr[1], tr2 = tr[2];
     if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
     if constexpr (OBS == 1) {
@@ -1599,14 +1645,15 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
         s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
     }
-    if (!OBS || out.screen) {
+    float* const o_screen = late->out.screen;
+    if (!OBS || o_screen) {
         // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
         s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int nfl = 3*(r_last - g*WAVE + 1);
-        float* __restrict__ scr = out.screen + 3*(((size_t)n*A + a)*R + g*WAVE);
+        float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + g*WAVE);
         #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int j = lane + k*WAVE;
