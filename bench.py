@@ -425,7 +425,7 @@ def main(argv=None):
         'eager': {'value': n_total*args.steps/eager_s, 'ms_per_step': 1e3*eager_s/args.steps,
                   'step_ms_hip_events': {'min': float(step_ms.min()), 'median': float(np.median(step_ms)), 'max': float(step_ms.max())}},
         'roofline': {
-            'kernel': 'ms_render = render_kernel<1,1,0> (headings cached by ms_physics)', 'bound': 'hbm', 'achieved': achieved,
+            'kernel': 'ms_render = render_kernel<%s,1,0> (headings cached by ms_physics)' % {'pairs': 1, 'seq': 0}.get(os.environ.get('MEGASTEP_RENDER_IMPL', 'v2'), 2), 'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,

@@ -218,26 +218,20 @@ __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 // divides and five square roots of the real test.  Results are folded with atomicMin on the float's bits:
 // every value is in [+0, 1], where the unsigned order is the float order, so the fold is exact in any order.
 constexpr int PHYS_AHEAD = 4;          // wall chunks in flight per wave (six: no faster at 300 walls, 12 % slower at 1000 - fewer waves fit)
-constexpr int PHYS_PAIRS = 2*WAVE;     // capacity of a wave's (wall, agent) pair list: a flush's worth + one agent's worth of a chunk
+constexpr int PHYS_FEW = 4;            // up to this many agents per env, their reach boxes ride in scalar registers
+constexpr int PHYS_PAIRS = (PHYS_FEW + 1)*WAVE;   // capacity of a wave's (wall, agent) pair list: a flush's worth + one chunk's worth for PHYS_FEW agents
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
 // EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
-// WPB = envs (= independent wavefronts) per workgroup; the dynamic LDS holds WPB slices of `slice` float4s
-template <int MOVE, int EXTRA, int WPB>
-__global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
+template <int MOVE, int EXTRA>
+__global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex, const int slice) {
-    extern __shared__ float4 s_dyn_all[];        // per agent: (p, v/fps) | reach box | reach^2 | progress bits
-    __shared__ float4 s_wall_all[WPB][PHYS_PAIRS];   // walls near ...
-    __shared__ int s_tag_all[WPB][PHYS_PAIRS];       // ... this agent
+        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex) {
+    extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
+    __shared__ float4 s_wall[PHYS_PAIRS];        // walls near ...
+    __shared__ int s_tag[PHYS_PAIRS];            // ... this agent
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int lane = WPB == 1 ? threadIdx.x : threadIdx.x & (WAVE - 1), wv = WPB == 1 ? 0 : threadIdx.x >> 6;   // (0 spelled out: keeps n scalar)
-    // a wave works through envs blockIdx.x*WPB + wv, + gridDim.x*WPB, ... (the host launches one wave per env); waves are
-    // independent: no workgroup barriers below
-    for (int n = blockIdx.x*WPB + wv; n < sc.n_envs; n += gridDim.x*WPB) {
-    float4* const s_dyn = s_dyn_all + (size_t)wv*slice;
-    float4* const s_wall = s_wall_all[wv];
-    int* const s_tag = s_tag_all[wv];
+    const int lane = threadIdx.x, n = blockIdx.x;                        // the host launches one wave per env
     float4* s_task = s_dyn;
     float4* s_box = s_task + A;
     float* s_reach2 = reinterpret_cast<float*>(s_box + A);
@@ -312,6 +306,7 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             moved(n*A + t, ag.angles[n*A + t], v, w);
         }
     }
+    float4 my_box = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int t = lane; t < A; t += WAVE) {
         const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
         const P2 p0 = p2(pp.x, pp.y);
@@ -323,7 +318,9 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
         // has decayed for a hundred steps), so those agents simply meet all the walls.
         if ((vl > 0.f) & (vl < 1e-3f)) reach = INFINITY;
         s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
-        s_box[t] = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
+        const float4 box = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
+        if (t == lane) my_box = box;
+        s_box[t] = box;
         s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
         s_prog[t] = f_bits(1.f);
     }
@@ -370,10 +367,9 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
     };
     // lane = wall: which agents' reach boxes does its bounding box touch?  Those (wall, agent) pairs are compacted
     // into LDS and get the distance test and then the exact one, one pair per lane (kernels.cu:202-221)
-    auto keep = [&](const int t, const bool in, const float4 u) {       // appends the lanes with `in` set as (wall, agent t) pairs
-        const unsigned long long m = __ballot(in);
+    auto keep = [&](const int t, const unsigned long long m, const float4 u) {   // appends the lanes of `m` as (wall, agent t) pairs
         if (m) {
-            if (in) {
+            if ((m >> lane) & 1ull) {
                 const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
                 s_wall[pos] = u;
                 s_tag[pos] = t;
@@ -381,20 +377,39 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
             cnt += __popcll(m);
         }
     };
+    // The usual case - a handful of agents - keeps their boxes in scalar registers, so a chunk's verdicts are four
+    // compares per agent straight into lane masks and nothing in the sweep waits for the LDS.
+    const bool few = A <= PHYS_FEW;
+    float bx[PHYS_FEW][4];
+    #pragma unroll
+    for (int t = 0; t < PHYS_FEW; t++) {
+        bx[t][0] = readlane_f(my_box.x, t); bx[t][1] = readlane_f(my_box.y, t);
+        bx[t][2] = readlane_f(my_box.z, t); bx[t][3] = readlane_f(my_box.w, t);
+    }
     for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
             const float4 u = w[k];
-            const bool live = l0 + k*WAVE + lane < L;
             w[k] = ln[min(l0 + (k + PHYS_AHEAD)*WAVE + lane, max(L - 1, 0))];
             if (l0 + k*WAVE >= L) continue;                             // uniform
+            const unsigned long long live = __ballot(l0 + k*WAVE + lane < L);
             const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
-            const bool odd = !((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w));   // NaN coordinates: keep
-            for (int t = 0; t < A; t++) {
-                const float4 bx = s_box[t];
-                const bool in = live & (odd | !((x1 < bx.x) | (x0 > bx.z) | (y1 < bx.y) | (y0 > bx.w)));
-                if (cnt > PHYS_PAIRS - WAVE) flush();
-                keep(t, in, u);
+            const unsigned long long odd = __ballot(!((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w)));   // NaN coordinates: keep
+            if (few) {
+                if (cnt > PHYS_PAIRS - PHYS_FEW*WAVE) flush();
+                #pragma unroll
+                for (int t = 0; t < PHYS_FEW; t++) {
+                    if (t >= A) break;                                  // uniform
+                    const unsigned long long out = __ballot(x1 < bx[t][0]) | __ballot(x0 > bx[t][2]) | __ballot(y1 < bx[t][1]) | __ballot(y0 > bx[t][3]);
+                    keep(t, live & (odd | ~out), u);
+                }
+            } else {
+                for (int t = 0; t < A; t++) {
+                    const float4 b = s_box[t];
+                    const unsigned long long out = __ballot(x1 < b.x) | __ballot(x0 > b.z) | __ballot(y1 < b.y) | __ballot(y0 > b.w);
+                    if (cnt > PHYS_PAIRS - WAVE) flush();
+                    keep(t, live & (odd | ~out), u);
+                }
             }
         }
     }
@@ -442,8 +457,6 @@ __global__ __launch_bounds__(WPB*WAVE) void physics_kernel(
                 ex.imu[3*i + 2] = (-s_*v.x + c_*v.y)/ex.imu_speed_scale;
             }
         }
-    }
-    __builtin_amdgcn_wave_barrier();             // (the next env reuses this wave's LDS)
     }
 }
 
@@ -2427,19 +2440,15 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
     }
     // per env: 2 float4 + a float + an unsigned per agent, rounded up to whole float4s
     const size_t slice = ((sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents + 15)/16;
-    if (slice*16 > 60*1024) return MS_EUNSUPPORTED;
+    if (slice*16 > 56*1024) return MS_EUNSUPPORTED;
     const MsMovement no_move{nullptr, nullptr, 0, 0.f};
     const MsStepExtras no_extras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
     const MsMovement mvv = mv ? *mv : no_move;
     const MsStepExtras exv = ex ? *ex : no_extras;
     const hipStream_t hs = (hipStream_t)stream;
-    // MEGASTEP_PHYS_WPB=4: four envs per workgroup (A/B knob; the waves stay independent either way)
-    const char* wpb_env = getenv("MEGASTEP_PHYS_WPB");
-    const bool four = wpb_env && wpb_env[0] == '4' && slice*16*4 <= 60*1024;
-    const int n_waves = sc->n_envs;              // (several envs per wave, one after the other: 2 -> +25 %, 4 -> +85 % at 4096 envs)
+    // one wavefront per env (several envs per wave, one after the other: 2 -> +25 %, 4 -> +85 % at 4096 envs)
 #define MS_LAUNCH_PHYSICS(M, E) \
-    do { if (four) hipLaunchKernelGGL((physics_kernel<M, E, 4>), dim3((n_waves + 3)/4), dim3(4*WAVE), slice*16*4, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); \
-         else hipLaunchKernelGGL((physics_kernel<M, E, 1>), dim3(n_waves), dim3(WAVE), slice*16, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, (int)slice); } while (0)
+    hipLaunchKernelGGL((physics_kernel<M, E>), dim3(sc->n_envs), dim3(WAVE), slice*16, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv)
     if (mv && ex) MS_LAUNCH_PHYSICS(1, 1);
     else if (ex) MS_LAUNCH_PHYSICS(0, 1);
     else if (mv) MS_LAUNCH_PHYSICS(1, 0);

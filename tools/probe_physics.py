@@ -1,4 +1,4 @@
-"""Per-section cycle counters (s_memtime) of physics_kernel<0,0,1>: builds scratch/probe_phys.so with the counters written
+"""Per-section cycle counters (s_memtime) of physics_kernel<0,0>: builds scratch/probe_phys.so with the counters written
 into the heading cache (16 ints per env at 4 agents), runs it on the benchmark world, prints the breakdown.
 usage: python tools/probe_physics.py [build|run|both]"""
 import os, subprocess, sys
@@ -12,8 +12,8 @@ def build():
         nonlocal src
         assert src.count(old) == 1, old
         src = src.replace(old, new)
-    rep("    extern __shared__ float4 s_dyn_all[];",
-        "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_flush_ = 0;\n#define TICKP(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    extern __shared__ float4 s_dyn_all[];")
+    rep("    extern __shared__ float4 s_dyn[];",
+        "    long long T_[8] = {0,0,0,0,0,0,0,0}; long long t_ = clock64(); int n_flush_ = 0;\n#define TICKP(k) { const long long n_ = clock64(); T_[k] += n_ - t_; t_ = n_; }\n    extern __shared__ float4 s_dyn[];")
     rep("    // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)\n", "    TICKP(0)\n    // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)\n")
     rep("    // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane\n", "    TICKP(1)\n    // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane\n")
     rep("    int cnt = 0;\n    auto flush = [&]() {\n", "    TICKP(2)\n    int cnt = 0;\n    auto flush = [&]() {\n        TICKP(3) n_flush_++;\n")
