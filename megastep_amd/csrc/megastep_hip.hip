@@ -201,6 +201,23 @@ __device__ inline float wave_max_f(float x) {                          // all-la
 }
 __device__ inline uint32_t f_bits(float f) { return __float_as_uint(f); }
 
+// One env's rows of `lines` behind a buffer descriptor.  A chunk of 64 rows is then ONE instruction with no address
+// arithmetic in front of it - `buffer_load_dwordx4` takes the lane's byte offset from a VGPR that never changes and the
+// chunk's from a scalar register - and rows past the end come back as zeros (the hardware's bounds check), where a
+// plain load needs its index clamped.  Built from wave-uniform values only, so the descriptor lives in SGPRs.
+struct LineRows {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ LineRows(const float4* base, int n_rows)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base), 0, n_rows*16, 0x00020000)) {}
+    __device__ float4 load(int lane_bytes, int first_row) const {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, first_row*16, 0);
+        return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
+    __device__ float4 chunk(int lane, int first_row) const { return load(lane*16, first_row); }   // rows first_row + lane
+    __device__ float4 row(int i) const { return load(i*16, 0); }
+};
+
 // ------------------------------------------------------------------------------------------------
 // physics                                                                    kernels.cu:179-230
 // ------------------------------------------------------------------------------------------------
@@ -244,11 +261,12 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
     // the first wall chunks are requested before anything else: nothing below depends on them until the sweep, and on
     // large maps the stream of walls is what the kernel lasts (asking for the agents first cost 12 % there).
-    // (Unconditional loads from a clamped row - behind a branch hipcc waits for every load in flight at the first use
-    // of any of them; lanes past the last wall are masked by `live` in the sweep.)
+    // (Unconditional loads - behind a branch hipcc waits for every load in flight at the first use of any of them;
+    // lanes past the last wall read zeros and are masked by `live` in the sweep.)
+    const LineRows rows(ln, L);
     float4 w[PHYS_AHEAD];
     #pragma unroll
-    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = ln[min(AF + k*WAVE + lane, max(L - 1, 0))];
+    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = rows.chunk(lane, AF + k*WAVE);
     // one lane per agent: its state (kept for the epilogue).  (Behind a guard on purpose: everything requested before it
     // has arrived by the time it is used, which measured no worse at 300 walls and 4 % better at 1000.)
     float2 my_p, my_v;
@@ -306,7 +324,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             moved(n*A + t, ag.angles[n*A + t], v, w);
         }
     }
-    float4 my_box = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 my_box = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);   // (no agent: a box no finite wall touches)
     for (int t = lane; t < A; t += WAVE) {
         const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
         const P2 p0 = p2(pp.x, pp.y);
@@ -390,18 +408,25 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
             const float4 u = w[k];
-            w[k] = ln[min(l0 + (k + PHYS_AHEAD)*WAVE + lane, max(L - 1, 0))];
+            w[k] = rows.chunk(lane, l0 + (k + PHYS_AHEAD)*WAVE);
             if (l0 + k*WAVE >= L) continue;                             // uniform
             const unsigned long long live = __ballot(l0 + k*WAVE + lane < L);
             const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
-            const unsigned long long odd = __ballot(!((u.x == u.x) & (u.y == u.y) & (u.z == u.z) & (u.w == u.w)));   // NaN coordinates: keep
-            if (few) {
-                if (cnt > PHYS_PAIRS - PHYS_FEW*WAVE) flush();
+            // walls with a NaN or an infinity among their coordinates are kept whatever the boxes say
+            const unsigned long long odd = __ballot(!(fabsf(u.x) < INFINITY)) | __ballot(!(fabsf(u.y) < INFINITY))
+                                         | __ballot(!(fabsf(u.z) < INFINITY)) | __ballot(!(fabsf(u.w) < INFINITY));
+            if (few & !odd) {
+                unsigned long long in[PHYS_FEW], any = 0ull;            // all the verdicts first, one branch for the lot
                 #pragma unroll
-                for (int t = 0; t < PHYS_FEW; t++) {
-                    if (t >= A) break;                                  // uniform
+                for (int t = 0; t < PHYS_FEW; t++) {                    // (agents that do not exist: see my_box)
                     const unsigned long long out = __ballot(x1 < bx[t][0]) | __ballot(x0 > bx[t][2]) | __ballot(y1 < bx[t][1]) | __ballot(y0 > bx[t][3]);
-                    keep(t, live & (odd | ~out), u);
+                    in[t] = live & ~out;
+                    any |= in[t];
+                }
+                if (any) {
+                    if (cnt > PHYS_PAIRS - PHYS_FEW*WAVE) flush();
+                    #pragma unroll
+                    for (int t = 0; t < PHYS_FEW; t++) keep(t, in[t], u);
                 }
             } else {
                 for (int t = 0; t < A; t++) {
@@ -897,6 +922,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
+    const LineRows rows(ln, L);
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
     // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
     float ag_s = 0.f, ag_c = 0.f;
@@ -926,10 +952,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     constexpr int AHEAD = 3;                     // chunks in flight
     float4 w_first[AHEAD];
     if constexpr (IMPL == 2) {
-        // (unconditional loads from a clamped row: behind a branch hipcc waits for every load in flight at the first
-        // use of any of them, which turns "in flight" into "one at a time"; rows that are not wanted are ignored later)
+        // (unconditional loads: behind a branch hipcc waits for every load in flight at the first use of any of them,
+        // which turns "in flight" into "one at a time"; rows past the end read zeros and are ignored later)
         #pragma unroll
-        for (int k = 0; k < AHEAD; k++) w_first[k] = ln[min(k*WAVE + lane, max(L - 1, 0))];
+        for (int k = 0; k < AHEAD; k++) w_first[k] = rows.chunk(lane, k*WAVE);
     }
 
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
@@ -1253,7 +1279,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // interval [lo, lo + len) of this wave's rays that can hit it
         // a chunk's lines as they are in memory, lane = line (dead lanes get the last row, agent rows whatever the last
         // render left there: neither is used)
-        auto fetch = [&](const int c0) { return ln[min(c0 + lane, max(L - 1, 0))]; };   // (clamped, not guarded: see w_first)
+        auto fetch = [&](const int c0) { return rows.chunk(lane, c0); };        // (not guarded: see w_first)
         // the full work on one line per lane (any line `l`; `agent_lines`: some lane holds one, wave-uniform): the
         // ray-independent half of the intersection, and the conservative interval [lo, lo + len) of this wave's rays
         // that can hit it.  Every lane comes in; dead ones leave with len 0
@@ -1568,7 +1594,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const float* const l_tex_vals = late->sc.textures_vals;
     const float* const l_baked = late->sc.baked_vals;
     const int row = min(max(nearest_idx, 0), max(L - 1, 0));
-    const float4 hw_mem = ln[row];
+    const float4 hw_mem = rows.row(row);
     const int tex_w = l_tex_widths[base + row], tstart = l_tex_starts[base + row];
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -150,6 +150,35 @@ def test_crawling_agents_meet_far_walls_like_the_reference():
     np.testing.assert_array_equal(p.progress.cpu().numpy(), prog_ref)
 
 
+@pytest.mark.parametrize('n_agents', [1, 4, 6])
+def test_walls_with_non_finite_coordinates_go_through_the_exact_test(n_agents):
+    """A NaN or an infinity among a wall's coordinates: the reach boxes cannot judge such a wall, so the sweep hands it to
+    the exact test for every agent (with four agents or fewer and with more - the two sweeps), like the reference, which
+    tests every wall. The progress must come out as the oracle's, whatever that is."""
+    from megastep_amd import core, cuda, scene, toys
+    sc = scene.scenery(48*[toys.box()], n_agents, device='cuda')
+    c = core.Core(sc, res=8, fps=10)
+    rng = np.random.RandomState(1)
+    AF = n_agents*sc.model.shape[0]
+    lines = sc.lines.vals.reshape(48, -1, 4)                  # (env, line, xyxy): the box's four walls follow the agents' lines
+    assert lines.shape[1] == AF + 4
+    bad = [np.nan, np.inf, -np.inf]
+    for e in range(1, 48):                                    # env 0 stays clean
+        wall, coord = AF + rng.randint(4), rng.randint(4)
+        lines[e, wall, coord] = bad[e % 3]
+        if e % 5 == 0:
+            lines[e, wall, (coord + 2) % 4] = bad[(e + 1) % 3]
+    c.agents.positions[:] = torch.as_tensor(rng.uniform(1.2, 4.8, (48, n_agents, 2)).astype(np.float32), device='cuda')
+    util.random_velocities(c, rng, speed=6.)
+    ref = util.OracleWorld(c)
+    p = cuda.physics(c.scenery, c.agents)
+    prog_ref, _ = ref.physics()
+    got = p.progress.cpu().numpy()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(prog_ref))
+    np.testing.assert_array_equal(np.nan_to_num(got, nan=-7.), np.nan_to_num(prog_ref, nan=-7.))
+    assert (prog_ref < 1).any() and (prog_ref == 1).any()
+
+
 def test_worlds_past_the_heading_cache_limit():
     """More than cuda.Agents.HEADING_CACHE_MAX_AGENTS agents: ms_render runs its own prep kernel and works from the
     workspace instead of the cache physics leaves. Same results; and no slower per wave than below the limit (a telemetry
