@@ -40,6 +40,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: 256 CUs x 2.4 GHz x 256 flop/clk (packed FMA), the VALU ceiling SURVEY 8(d) names
 _T0 = time.perf_counter()
 
 
@@ -83,6 +84,16 @@ def algorithmic_bytes(core):
                + 48*N*A                    # agent state read + written
                + 4*N*A)                    # progress
     return render, physics
+
+
+def all_pairs_flops(core):
+    """What the reference's raycast costs per render launch, SURVEY.md section 8(d): every ray against every line of its
+    env at ~30 flop a test, plus ~40 flop of shading per ray. The kernels here test a fraction of those pairs (a wave
+    intersects ~7 lines per ray out of ~330), so dividing this by the kernel time gives an *all-pairs-equivalent* rate
+    that may exceed the VALU peak; it is reported next to the HBM roofline as the survey asks, not as a utilisation."""
+    sc = core.scenery
+    A, R = core.n_agents, core.res
+    return float(sc.lines.vals.shape[0])*A*R*30 + float(core.n_envs)*A*R*40
 
 
 def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
@@ -404,6 +415,7 @@ def main(argv=None):
         dist.all_reduce(t)
         n_total = int(t)
     rb, pb = algorithmic_bytes(core)
+    flops = all_pairs_flops(core)
     achieved = rb/(render_ms*1e-3)/1e9
     ms_per_step = 1e3*elapsed/args.steps
     value = n_total*args.steps/elapsed
@@ -429,7 +441,12 @@ def main(argv=None):
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
-            'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9},
+            'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9,
+            # the raycast meets the fp32 VALU ceiling before the HBM one - the reference's all-pairs work
+            # over this kernel's time, against the vector peak (the kernel culls, so this is an equivalent rate)
+            'valu': {'all_pairs_flops_per_launch': flops, 'all_pairs_equivalent_TFLOPs': flops/(render_ms*1e-3)/1e12,
+                     'peak_fp32_vector_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
+                     'frac_of_peak': flops/(render_ms*1e-3)/1e12/FP32_VECTOR_PEAK_TFLOPS}},
     }
     if rank == 0 and world == 1 and not args.dry_run_cpu:
         if not args.no_cpu_baseline:
