@@ -1,0 +1,82 @@
+"""Random worlds against the oracle: shapes, views and speeds drawn per seed - agents per env 1..70, rays 1..600, fov
+20..175 degrees, small and large floorplans, toys - several physics + render steps each, with the movement / respawn
+extras and the pooled observations switched on at random. Prints one line per seed and a summary; exits 1 on a mismatch.
+usage: python tools/fuzz_parity.py [first_seed] [n_seeds]"""
+import sys, time, traceback
+sys.path.insert(0, '.')
+import numpy as np, torch
+from tests import util
+from megastep_amd import core, cubicasa, cuda, scene, toys
+
+
+def one(seed):
+    rng = np.random.RandomState(1000 + seed)
+    n_agents = int(rng.choice([1, 1, 2, 3, 4, 4, 5, 8, 17, 65, 70], p=[.15, .1, .15, .1, .15, .1, .1, .06, .05, .02, .02]))
+    res = int(rng.choice([1, 3, 8, 64, 64, 100, 128, 256, 512, 600]))
+    if n_agents > 8:
+        res = min(res, 128)
+    fov = float(rng.choice([20, 70, 90, 130, 130, 170, 175]))
+    kind = rng.choice(['plans', 'plans', 'plans', 'large', 'box', 'column'])
+    n_envs = int(rng.randint(1, 4 if kind == 'large' or n_agents > 8 else 12))
+    np.random.seed(seed)
+    if kind in ('box', 'column'):
+        geometries = n_envs*[getattr(toys, kind)()]
+    else:
+        geometries = cubicasa.sample(n_envs, n_unique=16, seed=seed + 1, large=kind == 'large')
+    sc = scene.scenery(geometries, n_agents, device='cuda', random=np.random.RandomState(seed))
+    c = core.Core(sc, res=res, fov=fov, fps=float(rng.choice([10, 10, 30, 3])))
+    util.spawn(c, geometries, seed=seed)
+    mutated = ''
+    if seed % 2:
+        # walls moved onto each other, collapsed to points, stretched: ties for the 1e-4 rule, degenerate segments
+        AF = n_agents*sc.model.shape[0]
+        lines = sc.lines.vals.reshape(-1, 4)
+        starts, widths = sc.lines.starts.cpu().numpy(), sc.lines.widths.cpu().numpy()
+        for e in range(n_envs):
+            walls = np.arange(starts[e] + AF, starts[e] + widths[e])
+            if len(walls) < 2:
+                continue
+            for _ in range(max(2, len(walls)//8)):
+                i, j = rng.choice(walls, 2, replace=False)
+                how = rng.randint(5)
+                if how == 0:   lines[i] = lines[j]                                   # coincident
+                elif how == 1: lines[i] = lines[j][[2, 3, 0, 1]]                     # coincident, reversed
+                elif how == 2: lines[i, 2:] = lines[i, :2]                           # a point
+                elif how == 3: lines[i] = lines[j] + float(rng.choice([2e-5, 9e-5, 1.1e-4, 1e-3]))   # inside / outside the band
+                else:          lines[i, 2:] = lines[i, :2] + 100*(lines[i, 2:] - lines[i, :2])       # very long
+        # (the envs no longer share floorplans: a scenery of its own, without the build's `geom` table)
+        sc = cuda.Scenery(n_agents, sc.lights, sc.lines, sc.textures, sc.model)
+        cuda.bake(sc)
+        c.scenery = sc
+        mutated = ' mutated'
+    ref = util.OracleWorld(c)
+    np.testing.assert_allclose(c.scenery.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+    ref.pull_baked(c)
+    fields = cuda.FIELDS
+    for step in range(3):
+        util.random_velocities(c, rng, speed=float(rng.choice([.01, 1., 4., 40.])), spin=float(rng.choice([0., 90., 720.])))
+        if step == 2:            # some agents standing still, one crawling
+            c.agents.velocity[::2] = 0.
+            c.agents.velocity[0, 0] = torch.tensor([3e-6, 0.], device='cuda')
+        ref.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        prog_ref, agents_ref = ref.physics()
+        util.assert_physics_matches(c, p, prog_ref, agents_ref)
+        util.assert_render_matches(c, r, ref.render())
+    return f'{kind:6s} envs {n_envs:2d} agents {n_agents:2d} rays {res:3d} fov {fov:5.1f}{mutated}'
+
+
+if __name__ == '__main__':
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    bad, t0 = [], time.time()
+    for seed in range(first, first + n):
+        try:
+            print(seed, one(seed), 'ok', flush=True)
+        except Exception as e:
+            bad.append(seed)
+            print(seed, 'MISMATCH', type(e).__name__, str(e)[:400].replace('\n', ' | '), flush=True)
+            traceback.print_exc(limit=3)
+    print(f'{n - len(bad)}/{n} seeds agree with the oracle in {time.time() - t0:.0f} s; mismatches: {bad}')
+    sys.exit(1 if bad else 0)
