@@ -1,6 +1,7 @@
 """Random worlds against the oracle (tools/fuzz_parity.py): shapes the fixed-shape parity tests do not name - up to 70
 agents per env, 1 to 600 rays, narrow and wide views, toys and floorplans, and for odd seeds walls moved onto each other,
-collapsed to points or stretched a hundredfold - bake, then three physics + render steps each."""
+collapsed to points or stretched a hundredfold - bake, then three physics + render steps each; and the render kernel's
+optional outputs (pooled RGB-D, crosshair ids, first-sight books, subsets of the planes) against tensor ops on a full render."""
 import importlib.util
 import os
 
@@ -18,3 +19,4 @@ _spec.loader.exec_module(fuzz)
 def test_random_worlds_match_the_oracle(first):
     for seed in range(first, first + 12):
         print(seed, fuzz.one(seed))
+        print(seed, fuzz.one_fused(seed))

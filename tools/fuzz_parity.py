@@ -67,6 +67,56 @@ def one(seed):
     return f'{kind:6s} envs {n_envs:2d} agents {n_agents:2d} rays {res:3d} fov {fov:5.1f}{mutated}'
 
 
+def one_fused(seed):
+    """What the render kernel can write besides the reference's five planes - pooled RGB-D, the crosshair ids, the
+    first-sight books, any subset of the planes - against tensor ops on a full render of the same state."""
+    rng = np.random.RandomState(5000 + seed)
+    n_agents = int(rng.choice([1, 2, 3, 4, 6]))
+    sub = int(rng.choice([1, 2, 4, 8, 16, 32, 64]))
+    px = int(rng.randint(2, 13))
+    res = sub*px
+    n_envs = int(rng.randint(1, 9))
+    np.random.seed(seed)
+    geometries = cubicasa.sample(n_envs, n_unique=16, seed=seed + 1) if rng.rand() < .7 else n_envs*[toys.column()]
+    sc = scene.scenery(geometries, n_agents, device='cuda', random=np.random.RandomState(seed))
+    c = core.Core(sc, res=res, fov=float(rng.choice([70, 130, 170])), fps=10)
+    util.spawn(c, geometries, seed=seed)
+    util.random_velocities(c, rng, speed=4.)
+    if rng.rand() < .7:
+        cuda.physics(sc, c.agents)                       # (leaves the heading cache for the renders)
+    full = cuda.render(sc, c.agents)
+    M, AF = sc.model.shape[0], n_agents*sc.model.shape[0]
+    max_depth = float(rng.choice([3., 10.]))
+    want_rgb = full.screen.reshape(n_envs, n_agents, px, sub, 3).mean(3).permute(0, 1, 3, 2)
+    want_d = (1 - ((full.distances - c.agent_radius)/max_depth).clamp(0, 1)).reshape(n_envs, n_agents, px, sub).mean(3)
+    r1, r2 = (px//2 - 1)*sub + sub//2, (px//2)*sub + sub//2
+    idx = full.indices[..., [r1, r2]]
+    want_centre = torch.where((idx >= 0) & (idx < AF), idx//M, torch.full_like(idx, -1))
+    hit = full.indices >= 0
+    line = (sc.lines.starts[:, None, None] + full.indices.clamp(min=0)).long()
+    width = sc.textures.widths[line].float()
+    along = torch.min(torch.floor(width*full.locations), width - 1)
+    texel = sc.textures.starts[line].long() + torch.where(hit, along, torch.zeros_like(along)).long()
+    want_stamp = torch.zeros(sc.textures.vals.shape[0], dtype=torch.int32, device='cuda')
+    want_stamp[texel[hit]] = 1
+    want_count = torch.stack([texel[e][hit[e]].unique().numel()*torch.ones((), dtype=torch.int32, device='cuda') for e in range(n_envs)])
+    fields = tuple(f for f in cuda.FIELDS if rng.rand() < .4)
+    books = (torch.zeros_like(want_stamp), torch.ones(n_envs, dtype=torch.int32, device='cuda'), torch.zeros(n_envs, dtype=torch.int32, device='cuda'))
+    fused = cuda.render(sc, c.agents, fields=fields, pooled=dict(subsample=sub, max_depth=max_depth, centre=True), seen=books)
+    for f in cuda.FIELDS:
+        if f in fields:
+            assert torch.equal(torch.nan_to_num(getattr(fused, f).float(), nan=-7.), torch.nan_to_num(getattr(full, f).float(), nan=-7.)), f
+        else:
+            assert getattr(fused, f) is None, f
+    torch.testing.assert_close(fused.obs_rgb, want_rgb, rtol=0, atol=1e-6)
+    torch.testing.assert_close(fused.obs_depth, want_d, rtol=0, atol=1e-6)
+    assert torch.equal(fused.obs_centre, want_centre.int())
+    assert torch.equal(books[0], want_stamp) and torch.equal(books[2], want_count)
+    again = cuda.render(sc, c.agents, fields=fields, pooled=dict(subsample=sub, max_depth=max_depth, centre=True), seen=books)
+    assert torch.equal(books[2], want_count), 'a second look adds nothing'
+    return f'fused  envs {n_envs:2d} agents {n_agents:2d} rays {res:3d} = {px} px x {sub} fields {",".join(fields) or "-"}'
+
+
 if __name__ == '__main__':
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -74,9 +124,11 @@ if __name__ == '__main__':
     for seed in range(first, first + n):
         try:
             print(seed, one(seed), 'ok', flush=True)
+            print(seed, one_fused(seed), 'ok', flush=True)
         except Exception as e:
             bad.append(seed)
             print(seed, 'MISMATCH', type(e).__name__, str(e)[:400].replace('\n', ' | '), flush=True)
             traceback.print_exc(limit=3)
+    bad = sorted(set(bad))
     print(f'{n - len(bad)}/{n} seeds agree with the oracle in {time.time() - t0:.0f} s; mismatches: {bad}')
     sys.exit(1 if bad else 0)
