@@ -146,20 +146,22 @@ def test_movement_inside_the_physics_launch_equals_the_tensor_ops(cls, kwargs):
             c.agents.velocity[0, 0] = 0.
 
 
-@pytest.mark.parametrize('after', [False, True])
-def test_respawn_and_imu_inside_the_physics_launch_equal_the_tensor_ops(after):
+@pytest.mark.parametrize('after,n_agents', [(False, 3), (True, 3), (False, 1), (True, 70), (False, 66)])
+def test_respawn_and_imu_inside_the_physics_launch_equal_the_tensor_ops(after, n_agents):
     """respawn (before the step - Deathmatch's order - or after it - Explorer's) and the IMU reading, done
-    by the physics launch, against the modules' tensor ops (modules.py:263-270,312-326) around a plain movement call."""
+    by the physics launch, against the modules' tensor ops (modules.py:263-270,312-326) around a plain movement call.
+    More than 64 agents per env: the ones past a wavefront's lanes go through memory."""
     from megastep_amd import arrdict, core, cubicasa, cuda, modules, scene
     np.random.seed(3); torch.manual_seed(3)
+    A = n_agents
     gs = cubicasa.sample(24, n_unique=32)
-    c = core.Core(scene.scenery(gs, 3, random=np.random.RandomState(0)), res=32, fov=100)
+    c = core.Core(scene.scenery(gs, A, random=np.random.RandomState(0)), res=32, fov=100)
     spawner = modules.RandomSpawns(gs, c)
     spawner(c.agent_full(True))
     mover, imu = modules.MomentumMovement(c), modules.IMU(c)
     for step in range(8):
-        actions = torch.randint(0, 7, (24, 3), device='cuda')
-        reset = torch.rand((24, 3), device='cuda') < (.3 if step % 2 else 0.)
+        actions = torch.randint(0, 7, (24, A), device='cuda')
+        reset = torch.rand((24, A), device='cuda') < (.3 if step % 2 else 0.)
         request = spawner.draw(reset, after=after)
         # the reference's way, on a copy of the state: tensor ops around the fused movement + physics
         ref = cuda.Agents(*(t.clone() for t in (c.agents.angles, c.agents.positions, c.agents.angvelocity, c.agents.velocity)))
@@ -174,7 +176,7 @@ def test_respawn_and_imu_inside_the_physics_launch_equal_the_tensor_ops(after):
         # ours: one launch
         p = mover(arrdict.arrdict(actions=actions), respawn=request, imu=imu)
         reading = imu()
-        assert imu._pending is None and reading.shape == (24, 3, 3)
+        assert imu._pending is None and reading.shape == (24, A, 3)
         for name in ('angles', 'positions', 'angvelocity', 'velocity'):
             torch.testing.assert_close(getattr(c.agents, name), getattr(ref, name), rtol=0, atol=2e-6, msg=name)
         torch.testing.assert_close(p.progress, p_ref.progress, rtol=0, atol=2e-6)

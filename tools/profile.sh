@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- p
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $out/sq -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_sq.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/active -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean > $out/bench_active.log 2>&1
 python - <<PY
 import pandas as pd, json
 out='$out'
@@ -38,5 +39,19 @@ g = sq[sq.k.notna()].groupby(['k','Counter_Name']).Counter_Value.mean().unstack(
 g['VALU_per_wave'] = g.SQ_INSTS_VALU/g.SQ_WAVES; g['SALU_per_wave'] = g.SQ_INSTS_SALU/g.SQ_WAVES; g['LDS_per_wave'] = g.SQ_INSTS_LDS/g.SQ_WAVES
 g.to_csv(f'{out}/sq_counters_mean_per_launch.csv')
 print(g.round(0).to_string())
+PY
+python - <<PY
+# How busy the vector ALUs are: SQ_ACTIVE_INST_VALU counts cycles (4 per wave64 instruction), summed over the chip's
+# 1024 SIMDs; GRBM_GUI_ACTIVE is the launch's length in shader cycles (summed over the 8 XCDs).
+import pandas as pd, json, os
+out='$out'
+f = f'{out}/active/bench_counter_collection.csv'
+if os.path.exists(f):
+    d = pd.read_csv(f)
+    d['k'] = d.Kernel_Name.str.extract(r'(render_kernel|physics_kernel)')
+    g = d[d.k.notna()].groupby(['k','Counter_Name']).Counter_Value.mean().unstack()
+    g['cycles_per_valu_inst'] = g.SQ_ACTIVE_INST_VALU/g.SQ_INSTS_VALU
+    g['valu_busy_frac'] = g.SQ_ACTIVE_INST_VALU/1024/(g.GRBM_GUI_ACTIVE/8)
+    g.to_csv(f'{out}/valu_busy.csv'); print(g.round(3).to_string())
 PY
 tail -1 $out/bench_stats.log | cut -c1-600
