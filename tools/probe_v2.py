@@ -20,7 +20,7 @@ def build():
     rep("        auto drain = [&]() {\n", "        auto drain = [&]() {\n            TICK(4) n_drain_++;\n", i2)
     rep("            // the list starts over\n", "            TICK(3)\n            // the list starts over\n", i2)
     rep("        float4 w_next[AHEAD];", "        TICK(0)\n        float4 w_next[AHEAD];", i2)
-    rep("            line_math(w, l, live, agent_lines, cd, lo, len);\n", "            TICK(1)\n            line_math(w, l, live, agent_lines, cd, lo, len);\n            TICK(2)\n", i2)
+    rep("            line_math(w, l, live, agent_lines, first_chunk, cd, lo, len);\n", "            TICK(1)\n            line_math(w, l, live, agent_lines, first_chunk, cd, lo, len);\n            TICK(2)\n", i2)
     rep("            if (!vm) return;                                                 // uniform\n", "            if (!vm) return;                                                 // uniform\n            n_vis_++;\n", i2)
     rep("        if (n_pairs) drain();\n", "        TICK(1)\n        if (n_pairs) drain();\n", i2)
     rep("    // ---- the winner's loc and dot, recomputed from the same inputs", "    TICK(5)\n    // ---- the winner's loc and dot, recomputed from the same inputs")
@@ -75,6 +75,12 @@ def run():
                 print('slowest 1%% of the waves: mean sections', d[slow].mean(0).cpu().numpy().round(0).tolist(), 'lines/env %.0f vs %.0f overall' % (lines[slow].mean().item(), lines.mean().item()))
                 worst = tot.argmax()
                 print('the slowest wave:', d[worst].cpu().numpy().round(0).tolist(), 'lines', lines[worst].item())
+                light = d[:, 7]
+                print('dynamic lighting per wave: share of waves above 2k / 5k / 10k / 20k cycles: %s; their share of all wave cycles: %s' % (
+                    [round((light > t).double().mean().item(), 4) for t in (2e3, 5e3, 1e4, 2e4)],
+                    [round((tot[light > t].sum()/tot.sum()).item(), 4) for t in (2e3, 5e3, 1e4, 2e4)]))
+                rest = tot - light
+                print('without the lighting section: mean %.0f p99 %.0f max %.0f' % (rest.mean().item(), torch.quantile(rest, .99).item(), rest.max().item()))
                 print('corr(total, lines) %.2f  corr(total, pairs) %.2f' % (torch.corrcoef(torch.stack([tot, lines]))[0, 1].item(), torch.corrcoef(torch.stack([tot, d[:, 8]]))[0, 1].item()))
     acc /= cnt
     names = ['prologue', 'line loads + loop', 'pass 1 line math', 'pass2 windows', 'scan+compaction', 'resolve+fold', 'loc/dot+out', 'lighting+shade+store',
