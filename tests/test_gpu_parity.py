@@ -493,3 +493,43 @@ def test_outputs_can_be_reused_between_calls():
             assert torch.equal(torch.nan_to_num(a.float(), nan=-7.), torch.nan_to_num(b.float(), nan=-7.)), k
     with pytest.raises(RuntimeError, match='same shapes'):
         cuda.render(c.scenery, c.agents, fields=('indices',), out=held_r)
+
+
+def test_steps_replayed_as_a_hip_graph_equal_the_same_steps_launched_one_by_one():
+    """bench.py's headline leg records K physics + render steps into one HIP graph and replays it. Same kernels, same
+    arguments, stream order kept by the graph's edges: the state after the replay and the last frame must be the
+    eager run's, bit for bit."""
+    from megastep_amd import cuda
+    c, _ = _world(96, 4, 64, 130, seed=5)
+    K = 6
+    g = torch.Generator(device='cuda').manual_seed(0)
+    vel = 6*torch.rand((K, 96, 4, 2), device='cuda', generator=g) - 3
+    angvel = 360*torch.rand((K, 96, 4), device='cuda', generator=g) - 180
+    start = [t.clone() for t in (c.agents.angles, c.agents.positions)]
+    inputs = (vel.clone(), angvel.clone())                       # physics zeroes the velocities of agents that collide
+
+    def rewind():
+        c.agents.angles.copy_(start[0]); c.agents.positions.copy_(start[1])
+        vel.copy_(inputs[0]); angvel.copy_(inputs[1])
+    views = [cuda.Agents(c.agents.angles, c.agents.positions, angvel[i], vel[i]) for i in range(K)]
+    state = {}
+
+    def step(i):
+        state['p'] = cuda.physics(c.scenery, views[i], out=state.get('p'))
+        state['r'] = cuda.render(c.scenery, views[i], out=state.get('r'))
+    for i in range(K):
+        step(i)
+    want = [t.clone() for t in (c.agents.angles, c.agents.positions, vel, state['p'].progress, state['r'].indices, state['r'].screen, c.scenery.lines.vals)]
+    assert (want[3] < 1).any() and (want[4] >= 0).any()
+    rewind()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(K):
+            step(i)
+    for _ in range(2):                                           # (capture does not run anything; replay twice from the start state)
+        rewind()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (c.agents.angles, c.agents.positions, vel, state['p'].progress, state['r'].indices, state['r'].screen, c.scenery.lines.vals)
+        for a, b in zip(got, want):
+            assert torch.equal(torch.nan_to_num(a.float(), nan=-7.), torch.nan_to_num(b.float(), nan=-7.))
