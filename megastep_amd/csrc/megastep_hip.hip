@@ -1,22 +1,26 @@
 // megastep_hip.hip -- gfx950 (MI355X / CDNA4) simulation core behind include/megastep_hip.h.
 //
-// Seven kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
+// Nine kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
 //
-//   physics_kernel<MOVE>   one wavefront per env: wall chunks requested up front, lane = agent for the state and
-//                   the agent-agent tests, lane = wall for a reach-box prefilter, compacted (wall, agent) pairs for
-//                   the exact collision test, atomicMin fold, integration epilogue; leaves each agent's sin/cos for
-//                   the renderer.  MOVE = 1 runs the movement modules' velocity update first.
-//                                                            (reference: kernels.cu:179-230, modules.py:24-118)
+//   physics_kernel<MOVE, EXTRA>   one wavefront per env: wall chunks requested up front (buffer loads), lane = agent
+//                   for the state and the agent-agent tests, lane = wall for a reach-box prefilter (the boxes of up to
+//                   four agents in scalar registers), compacted (wall, agent) pairs for the exact collision test,
+//                   atomicMin fold, integration epilogue; leaves each agent's sin/cos for the renderer.  MOVE = 1 runs
+//                   the movement modules' velocity update first, EXTRA = 1 the envs' respawn / lifespan / IMU bookkeeping.
+//                                                            (reference: kernels.cu:179-230, modules.py:24-118,263-366)
 //   render_kernel<IMPL, RW, OBS>   one wavefront per (env, agent, 64-ray group).  Pass 1 (lane = line) turns every
-//                   line into a conservative interval of the wave's rays; pass 2 deals the (line, ray) pairs to the
-//                   lanes, one exact intersection each, merged per ray with 64-bit LDS atomics; the order-dependent
-//                   nearest-hit rule is resolved from the three smallest keys (or a literal fold where it must be);
-//                   rays that landed on an agent are lit through the light grid; shading; optional pooled
-//                   observations.  draw, raycast and shader (three launches + five allocations in the reference)
-//                   are one launch.  IMPL = 0 is the slower literal-order variant kept for A/B runs.
-//                                                            (reference: kernels.cu:297-475)
+//                   line into a conservative interval of the wave's rays and compacts the visible ones into an LDS
+//                   list; pass 2 deals the (line, ray) pairs of the list to the lanes, 64 at a time, one exact
+//                   intersection each, merged per ray with one 64-bit LDS atomic; the order-dependent nearest-hit rule
+//                   is resolved from the three smallest keys (or a literal fold where it must be); rays that landed on
+//                   an agent are lit through the light grid; shading; optional pooled observations, crosshair ids and
+//                   first-sight books.  draw, raycast and shader (three launches + five allocations in the reference)
+//                   are one launch.  IMPL = 2 is the default; 1 (per-chunk pair windows) and 0 (literal order) are kept
+//                   for A/B runs and produce the same bits.     (reference: kernels.cu:297-475)
 //   render_prep_kernel, dynlight_kernel   the renderer's helpers for callers without a heading cache / light grid.
-//   bake_kernel     one workgroup per env, lane = texel, the env's occluders staged once in LDS.
+//   visibility_kernel, bake_sum_kernel    the two-phase bake: per (representative env, light) the walls that can shadow
+//                   each angular bin; per texel the sum over the lights, occluders looked up by bin.
+//   bake_kernel     the one-pass bake: one workgroup per env, lane = texel, the env's occluders staged once in LDS.
 //                                                            (reference: kernels.cu:238-293)
 //   lightgrid_kernel, lightlist_kernel   per (cell, light) LIT / DARK / UNKNOWN verdicts and candidate walls.
 //
