@@ -1666,7 +1666,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const float wf = (float)tex_w;
                 const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
                 const int epoch = out.seen_epoch[n];
-                fresh = atomicExch(&out.seen_stamp[tstart + along], epoch) != epoch;   // exactly one ray per texel sees the old stamp
+                // A look first: most texels in view were stamped frames ago, and an atomic that returns its old value
+                // costs a round trip to the L2 per lane (a launch of nothing but stamped texels: 70 -> 39 us at 4096
+                // envs x 256 rays).  Stamps only ever turn into the epoch during a launch, so a stale read can only
+                // send a ray on to the exchange, where exactly one ray per texel sees the old stamp.
+                if (out.seen_stamp[tstart + along] != epoch)
+                    fresh = atomicExch(&out.seen_stamp[tstart + along], epoch) != epoch;
             }
             const unsigned long long fm = __ballot(fresh);
             if (fm && lane == 0) atomicAdd(&out.seen_count[n], __popcll(fm));

@@ -36,8 +36,10 @@ class SeenTexels:
         self.texel_env = scenery.lines.inverse[scenery.textures.inverse.long()].long()       # texel -> env
         self.epoch = torch.ones(n_envs, dtype=torch.int32, device=device)
         self.stamp = torch.zeros(len(self.texel_env), dtype=torch.int32, device=device)
-        self.tally = torch.zeros(n_envs, dtype=torch.int32, device=device)
-        self._before = torch.zeros_like(self.tally)
+        # per env: texels seen since the last respawn, the same at the last call of gained(), and a spare row the env
+        # keeps its episode length in - one tensor, so that a respawn clears all three with one masked fill
+        self.counters = torch.zeros((3, n_envs), dtype=torch.int32, device=device)
+        self.tally, self._before, self.spare = self.counters
 
     #: what a render call needs to keep the books
     books = property(lambda self: (self.stamp, self.epoch, self.tally))
@@ -46,15 +48,14 @@ class SeenTexels:
 
     def gained(self):
         """How many texels each env saw for the first time since the last call (or its last respawn)."""
-        new = (self.tally - self._before).float()
-        self._before = self.tally.clone()
+        new = self.tally - self._before
+        self._before.copy_(self.tally)
         return new
 
     def forget(self, envs):
         """Envs marked in the bool mask start over."""
-        self.epoch += envs.int()
-        self.tally.masked_fill_(envs, 0)
-        self._before.masked_fill_(envs, 0)
+        self.epoch += envs
+        self.counters.masked_fill_(envs, 0)
 
     def mask(self):
         """Per texel: has its env seen it since the env's last respawn."""
@@ -79,7 +80,7 @@ class Explorer:
         self.obs_space = dotdict.dotdict(rgb=self._rgb.space, d=self._depth.space, imu=self._imu.space)
 
         self._memory = SeenTexels(c.scenery, c.n_envs)
-        self._lengths = torch.zeros(c.n_envs, dtype=torch.int, device=c.device)
+        self._lengths = self._memory.spare                                  # (cleared together with the books)
 
     # what the tests and `state` look at
     _potential = property(lambda self: self._memory.count)
@@ -89,14 +90,13 @@ class Explorer:
     def _restart(self, which):
         self._respawner(which.unsqueeze(-1))
         self._memory.forget(which)
-        self._lengths.masked_fill_(which, 0)
 
     def _world(self, reset):
         # pooled RGB-D straight from the render kernel, which also keeps the books of the texels it sees: no per-ray
         # output is needed at all
         frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=(), seen=self._memory.books)
         pixels = self.core.res//self._rgb.subsample
-        reward = (self._memory.gained()/pixels).masked_fill(reset, 0.)         # nothing for the frame after a respawn
+        reward = (self._memory.gained()/pixels).masked_fill_(reset, 0.)        # nothing for the frame after a respawn
         obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu())
         return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
 
@@ -111,10 +111,9 @@ class Explorer:
         # Who is over does not depend on this step's movement (explorer.py:83-90 moves first, then checks), so it is
         # settled up front and the respawn rides in the physics launch, after the integration - as does the IMU reading.
         self._lengths += 1
-        over = self._lengths >= self._memory.count + EPISODE_SLACK
+        over = self._lengths >= self._memory.tally + EPISODE_SLACK
         self._mover(decision, respawn=self._respawner.draw(over.unsqueeze(-1), after=True), imu=self._imu)
         self._memory.forget(over)
-        self._lengths.masked_fill_(over, 0)
         return self._world(over)
 
     def state(self, e=0):

@@ -33,7 +33,12 @@ def _actionset(core, linear, angular):
     return arrdict.arrdict(velocity=linear/core.fps*velocity, angvelocity=angular/core.fps*angvelocity).to(core.device)
 
 
-def _move(core, actionset, actions, keep, respawn=None, imu=None):
+def _table(actionset):
+    """The action table as cuda.physics' ``movement`` wants it: one (dx, dy, dangle) row per action."""
+    return torch.cat([actionset.velocity, actionset.angvelocity[:, None]], 1).contiguous()
+
+
+def _move(core, actionset, actions, keep, respawn=None, imu=None, table=None):
     """The velocity update of both movement modules, then physics. On the GPU it is part of the physics launch
     (cuda.physics' ``movement``) - as are, when the env hands them over, the respawn of the agents it wants respawned
     (``respawn``: :meth:`RandomSpawns.draw`) and the IMU observation of the new state (``imu``: the :class:`IMU`
@@ -41,7 +46,7 @@ def _move(core, actionset, actions, keep, respawn=None, imu=None):
     reference runs."""
     agents = core.agents
     if agents.angles.is_cuda:
-        table = torch.cat([actionset.velocity, actionset.angvelocity[:, None]], 1).contiguous()
+        table = _table(actionset) if table is None else table
         reading = None if imu is None else (torch.empty(agents.angles.shape + (3,), device=core.device), imu.ang_scale, imu.speed_scale)
         result = cuda.physics(core.scenery, agents, movement=(actions.long().contiguous(), table, keep), respawn=respawn, imu=reading)
         if imu is not None:
@@ -80,12 +85,13 @@ class SimpleMovement:
         (reference: modules.py:24-66)."""
         self.core = core
         self._actionset = _actionset(core, speed, ang_speed)
+        self._table = _table(self._actionset)
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
     def __call__(self, decision, respawn=None, imu=None):
         """Sets the agents' velocities from ``decision.actions`` ((n_env, n_agent) ints in 0..6), then steps physics.
         ``respawn`` / ``imu``: see :func:`_move`."""
-        return _move(self.core, self._actionset, decision.actions, 0., respawn, imu)
+        return _move(self.core, self._actionset, decision.actions, 0., respawn, imu, self._table)
 
 
 class MomentumMovement:
@@ -95,11 +101,12 @@ class MomentumMovement:
         each step (reference: modules.py:68-118)."""
         self.core = core
         self._actionset = _actionset(core, accel, ang_accel)
+        self._table = _table(self._actionset)
         self.decay = decay
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
     def __call__(self, decision, respawn=None, imu=None):
-        return _move(self.core, self._actionset, decision.actions, 1 - self.decay, respawn, imu)
+        return _move(self.core, self._actionset, decision.actions, 1 - self.decay, respawn, imu, self._table)
 
 
 def unpack(d):
