@@ -60,6 +60,8 @@ class Deathmatch:
 
         extents = np.stack([np.asarray(g['masks'].shape)*g['res'] for g in geometries])
         self._bounds = arrdict.torchify(extents).to(c.device)
+        self._upper = self._bounds[:, None] + CLEARANCE      # how far an agent may stray before it bleeds for it
+        self._everyone = torch.arange(c.n_agents, device=c.device)
         self._health = c.agent_full(np.nan)                  # NaN until the first reset
         self._damage = c.agent_full(np.nan)
         self.matchings = torch.zeros((c.n_envs, c.n_agents, c.n_agents), dtype=torch.bool, device=c.device)
@@ -81,13 +83,13 @@ class Deathmatch:
         (``centre`` (n_floorplans, n_agents, 2): the agent seen, or -1)."""
         c = self.core
         if centre is not None:
-            self.matchings = (centre[..., None] == torch.arange(c.n_agents, device=centre.device)).any(-2)
+            self.matchings = (centre[..., None] == self._everyone).any(-2)
         else:
             self.matchings = crosshair_matrix(line_indices, len(c.scenery.model), c.n_agents, self._rgb.subsample)
-        dealt = self.matchings.sum(2).float()                # opponents in my crosshair
-        taken = self.matchings.sum(1).float()                # crosshairs I am in
+        dealt = self.matchings.sum(2, dtype=torch.float32)   # opponents in my crosshair
+        taken = self.matchings.sum(1, dtype=torch.float32)   # crosshairs I am in
         where = c.agents.positions
-        strayed = ((where < -CLEARANCE) | (where > self._bounds[:, None] + CLEARANCE)).any(-1)
+        strayed = ((where < -CLEARANCE) | (where > self._upper)).any(-1)
         self._damage += HIT_DAMAGE*dealt
         self._health -= HIT_DAMAGE*(taken + strayed) + TICK_DAMAGE
         return dealt.reshape(-1)

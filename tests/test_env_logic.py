@@ -67,6 +67,7 @@ def test_exchange_fire_is_the_reference_shoot():
     env._rgb = modules.RGB(env.core, n_agents=1, subsample=sub)
     bounds = rng.uniform(5, 10, (F, 2)).astype(np.float32)
     env._bounds = torch.as_tensor(bounds)
+    env._upper = env._bounds[:, None] + deathmatch.CLEARANCE
     pos = rng.uniform(-2, 12, (F, A, 2)).astype(np.float32)
     env.core.agents.positions[:] = torch.as_tensor(pos)
     health, damage = rng.uniform(0, 1, (F, A)).astype(np.float32), rng.uniform(0, 1, (F, A)).astype(np.float32)
