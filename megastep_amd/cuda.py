@@ -144,7 +144,8 @@ class Agents:
     """Holds the (N, A[, 2]) state tensors of the agents (reference: common.h:157-177, wrappers.cpp:103-120).
     :func:`physics` updates them in place."""
 
-    HEADING_CACHE_MAX_AGENTS = 32768
+    #: ``False`` sends ms_render through its own heading kernel instead of the cache ms_physics leaves (tests, A/B runs)
+    HEADING_CACHE = True
 
     def __init__(self, angles, positions, angvelocity, velocity):
         self._angles = _check(angles, 'angles', torch.float32, 2)
@@ -161,9 +162,8 @@ class Agents:
         self._struct = _lib.MsAgents(*ptrs, self._headings.data_ptr())
         self._plain = _lib.MsAgents(*ptrs, None)
         self._cached = False
-        # Worth it while the batch is small enough for a launch to cost more than the sin/cos do inside physics
-        # (measured: 16 k agents -2 us per step, 64 k agents +4 us)
-        self._use_cache = n*a <= self.HEADING_CACHE_MAX_AGENTS
+        # (measured at 16 k to 262 k agents: one launch and one kernel boundary fewer per step, 1-3 % of the step)
+        self._use_cache = bool(self.HEADING_CACHE)
         devices = {t.device for t in (angles, positions, angvelocity, velocity)}
         self._dev = devices.pop() if len(devices) == 1 else None         # None: tensors on mixed devices
 

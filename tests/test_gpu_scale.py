@@ -179,13 +179,14 @@ def test_walls_with_non_finite_coordinates_go_through_the_exact_test(n_agents):
     assert (prog_ref < 1).any() and (prog_ref == 1).any()
 
 
-def test_worlds_past_the_heading_cache_limit():
-    """More than cuda.Agents.HEADING_CACHE_MAX_AGENTS agents: ms_render runs its own prep kernel and works from the
-    workspace instead of the cache physics leaves. Same results; and no slower per wave than below the limit (a telemetry
-    counter once cost this path a millisecond of same-address atomics)."""
+def test_worlds_without_the_heading_cache(monkeypatch):
+    """Agents without the cache ms_physics leaves (a binding that passes no `headings`): ms_render runs its own prep
+    kernel and works from the workspace. Same results; and no slower per wave than with it (a telemetry counter once cost
+    this path a millisecond of same-address atomics)."""
     from megastep_amd import cuda
+    monkeypatch.setattr(cuda.Agents, 'HEADING_CACHE', False)
     c, _, _ = _big_world(12288, 4, 64, 130, n_distinct=32, fast=True)
-    assert c.n_envs*c.n_agents > cuda.Agents.HEADING_CACHE_MAX_AGENTS and not c.agents._use_cache
+    assert not c.agents._use_cache
     _check_sample(c, [0, 31, 32, 7000, 12287], steps=2)
     rng = np.random.RandomState(0)
     util.random_velocities(c, rng)
