@@ -1660,29 +1660,29 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const float tl0 = tl[0], tl1 = tl[1], tl2 = tl[2], tr0 = tr[0], tr1 = tr[1], tr2 = tr[2];
     if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
     if constexpr (OBS == 1) {
-        if (out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
+        if (late->out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
             bool fresh = false;
             if (is_hit) {
                 const float wf = (float)tex_w;
                 const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
-                const int epoch = out.seen_epoch[n];
+                const int epoch = late->out.seen_epoch[n];
                 // A look first: most texels in view were stamped frames ago, and an atomic that returns its old value
                 // costs a round trip to the L2 per lane (a launch of nothing but stamped texels: 70 -> 39 us at 4096
                 // envs x 256 rays).  Stamps only ever turn into the epoch during a launch, so a stale read can only
                 // send a ray on to the exchange, where exactly one ray per texel sees the old stamp.
-                if (out.seen_stamp[tstart + along] != epoch)
-                    fresh = atomicExch(&out.seen_stamp[tstart + along], epoch) != epoch;
+                if (late->out.seen_stamp[tstart + along] != epoch)
+                    fresh = atomicExch(&late->out.seen_stamp[tstart + along], epoch) != epoch;
             }
             const unsigned long long fm = __ballot(fresh);
-            if (fm && lane == 0) atomicAdd(&out.seen_count[n], __popcll(fm));
+            if (fm && lane == 0) atomicAdd(&late->out.seen_count[n], __popcll(fm));
         }
-        if (out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
-            const int sub = out.obs_subsample, W = R/sub;
+        if (late->out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
+            const int sub = late->out.obs_subsample, W = R/sub;
             const int r1 = (W/2 - 1)*sub + sub/2, r2 = (W/2)*sub + sub/2;
             if ((r == r1) | (r == r2)) {
                 int seen = -1;
                 if ((nearest_idx >= 0) & (nearest_idx < AF)) seen = nearest_idx/sc.n_model;
-                out.obs_centre[((size_t)n*A + a)*2 + (r == r2 ? 1 : 0)] = seen;
+                late->out.obs_centre[((size_t)n*A + a)*2 + (r == r2 ? 1 : 0)] = seen;
             }
         }
     }
@@ -1710,10 +1710,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
     // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
     // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
-    if (OBS && (out.obs_rgb || out.obs_depth)) {
-        const int sub = out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
+    if (OBS && (late->out.obs_rgb || late->out.obs_depth)) {
+        const int sub = late->out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
         float p0 = s0, p1 = s1, p2 = s2;
-        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/out.obs_max_depth, 0.f), 1.f);
+        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
         for (int o2 = 1; o2 < sub; o2 <<= 1) {
             p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE);
             p2 += __shfl_xor(p2, o2, WAVE); pd += __shfl_xor(pd, o2, WAVE);
@@ -1722,12 +1722,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             const float fs = (float)sub;
             const int W = R/sub, px = r/sub;
             const size_t na = (size_t)n*A + a;
-            if (out.obs_rgb) {
-                out.obs_rgb[(na*3 + 0)*W + px] = p0/fs;
-                out.obs_rgb[(na*3 + 1)*W + px] = p1/fs;
-                out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
+            if (late->out.obs_rgb) {
+                late->out.obs_rgb[(na*3 + 0)*W + px] = p0/fs;
+                late->out.obs_rgb[(na*3 + 1)*W + px] = p1/fs;
+                late->out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
             }
-            if (out.obs_depth) out.obs_depth[na*W + px] = pd/fs;
+            if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd/fs;
         }
     }
 }
