@@ -277,26 +277,6 @@ class _Gpu:
             fn()
         return g.replay
 
-    def render_ms(self, scenery, view, n=50):
-        """Average duration of one ms_render launch: n launches recorded as one HIP graph, HIP events on their stream at
-        both ends of a replay. (An event pair around a single launch also times the two event packets - about 4 us on
-        this stack, a tenth of the kernel.)"""
-        from megastep_amd import cuda
-        state = {}
-
-        def launch():
-            state['r'] = cuda.render(scenery, view, out=state.get('r'))
-        launch()                                                           # (buffers are allocated outside the capture)
-        replay = self.graph(lambda: [launch() for _ in range(n)])
-        replay()
-        self.sync()
-        start, end = self.event(), self.event()
-        start.record()
-        replay()
-        end.record()
-        self.sync()
-        return start.elapsed_time(end)/n
-
 
 class _Stub:
     """CPU stand-in for the device (python bench.py --dry-run-cpu, used by tests/test_bench_gloo.py): the world is built
@@ -329,9 +309,6 @@ class _Stub:
 
     def graph(self, fn):
         return fn
-
-    def render_ms(self, scenery, view, n=50):
-        return float('nan')
 
 
 def main(argv=None):
@@ -421,14 +398,7 @@ def main(argv=None):
     eager_s = timed(eager)
     log(f'eager leg: {1e3*eager_s/args.steps:.4f} ms/step')
     step_ms = np.array([e[0].elapsed_time(e[2]) for e in events])
-    render_ms_eager = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
-
-    # ---- the render kernel's own duration (the roofline's denominator)
-    render_ms = dev.render_ms(scenery, views[args.warmup])
-    if not render_ms == render_ms:
-        render_ms = render_ms_eager
-    log(f'render kernel: {1e3*render_ms:.1f} us per launch (HIP events around a graph of 50 launches; {1e3*render_ms_eager:.1f} us between '
-        f'the events of the eager leg)')
+    render_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
 
     # ---- graph: the same K steps as one HIP graph, replayed
     graph_s = None
@@ -471,8 +441,8 @@ def main(argv=None):
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
-            'avg_launch_ms_source': 'HIP events at both ends of 50 ms_render launches replayed as one HIP graph, / 50 '
-                                    '(an event pair around each launch of the eager leg, event packets included: %.4f ms)' % render_ms_eager,
+            'avg_launch_ms_source': 'HIP events on the stream around every ms_render of the eager leg (in place, between the physics '
+                                    'launches; the pair also times its own two event packets, about 1 us)',
             'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9,
             # the raycast meets the fp32 VALU ceiling before the HBM one - the reference's all-pairs work
             # over this kernel's time, against the vector peak (the kernel culls, so this is an equivalent rate)
