@@ -833,6 +833,18 @@ __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int*
 // this pointer THERE: as plain parameters hipcc loads them at the top, runs out of scalar registers, and parks them in
 // vector-register lanes, which costs two memory round trips (a parked value has to have arrived) and ~40 instructions
 // per wave before the first ray is cast.  The asm statement keeps the loads from being hoisted back up.
+// How the per-ray planes are written: as non-temporal stores - nobody in this launch reads them back, and at 512 rays
+// they are 235 MB per launch that would otherwise push the lines and textures out of the L2 (512 rays: 231 -> 212 us,
+// 16384 envs x 64 rays: 149.5 -> 145.5 us, no difference at the headline shape).  (-DMS_NT_STORES=0: A/B knob)
+#ifndef MS_NT_STORES
+#define MS_NT_STORES 1
+#endif
+#if MS_NT_STORES
+#define MS_OUT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define MS_OUT_STORE(v, p) (*(p) = (v))
+#endif
+
 struct RenderArgs { MsScenery sc; MsAgents ag; MsRender out; float agent_radius, half_screen; int R, n_fans; RenderConsts rc; };
 static_assert(offsetof(RenderArgs, ag) == sizeof(MsScenery) && offsetof(RenderArgs, n_fans) + 4 == offsetof(RenderArgs, rc),
               "RenderArgs must mirror render_kernel's parameters");
@@ -1622,10 +1634,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         float* const o_dots = late->out.dots;
         float* const o_distances = late->out.distances;
         if (r < R) {
-            if (!OBS || o_indices) o_indices[o] = nearest_idx;
-            if (!OBS || o_locations) o_locations[o] = loc;
-            if (!OBS || o_dots) o_dots[o] = dt;
-            if (!OBS || o_distances) o_distances[o] = dist;
+            if (!OBS || o_indices) MS_OUT_STORE(nearest_idx, &o_indices[o]);
+            if (!OBS || o_locations) MS_OUT_STORE(loc, &o_locations[o]);
+            if (!OBS || o_dots) MS_OUT_STORE(dt, &o_dots[o]);
+            if (!OBS || o_distances) MS_OUT_STORE(dist, &o_distances[o]);
         }
     }
 
@@ -1705,7 +1717,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         #pragma unroll
         for (int k = 0; k < 3; k++) {
             const int j = lane + k*WAVE;
-            if (j < nfl) scr[j] = s_screen_w[j];
+            if (j < nfl) MS_OUT_STORE(s_screen_w[j], &scr[j]);
         }
     }
     // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
