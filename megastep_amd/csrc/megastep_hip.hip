@@ -1276,16 +1276,20 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         //    end's ray to the edge of the fan on the side it leaves by - the sign of cross(a, b).  (Clipping would
         //    only give less when the crossing is within centimetres of the agent.)
         // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first ray - first pair, line)
-        //               3072 ray (64 x 16 B)    | 4096 best, 4608 second, 5120 third (64 x 8 B each) | 5632 marks (4096 bits)
+        //               3072 ray (64 x 8 B: rx, ry), 3584 near (64 x 4 B) | 4096 best, 4608 second, 5120 third (64 x 8 B each) | 5632 marks (4096 bits)
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = 128, P_CAP = 4096;
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][2048]);
-        float4* const s_ray_w = reinterpret_cast<float4*>(&s_raw[wave][3072]);
+        // (direction and near plane in arrays of their own: at 8 and 4 bytes a ray, a window's reads - one ray per lane, the
+        // rays mostly consecutive - touch every LDS bank once; as one 16-byte record per ray they were two-way conflicts)
+        float2* const s_ray_w = reinterpret_cast<float2*>(&s_raw[wave][3072]);
+        float* const s_near_w = reinterpret_cast<float*>(&s_raw[wave][3584]);
         unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4096]);
         unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4608]);
         unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][5120]);
         unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][5632]);
-        s_ray_w[lane] = make_float4(rx, ry, near, 0.f);
+        s_ray_w[lane] = make_float2(rx, ry);
+        s_near_w[lane] = near;
         s_best_w[lane] = ~0ull;
         s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
         s_second_w[lane] = ~0ull;
@@ -1339,7 +1343,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const int2 info = s_info_w[k];
                 const int rr = (p + info.x) & 63;            // ray of this pair, wave-local (in range as it is for valid pairs)
                 const Cand cd = s_cand_w[k];
-                const float4 ray = s_ray_w[rr];
+                const float2 ray = s_ray_w[rr];
                 const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
                 const float nt = cd.pqx*ray.y - cd.pqy*ray.x;                // cross(PQ, ru)
                 const float ad = fabsf(d);
@@ -1348,7 +1352,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
                 if (hit) {
                     const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
-                    const bool beyond = ray.z < sv;                          // beyond the near plane, kernels.cu:369
+                    const bool beyond = s_near_w[rr] < sv;                          // beyond the near plane, kernels.cu:369
                     if (beyond) {
                         const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)info.y;
                         const unsigned long long old = atomicMin(&s_best_w[rr], key);
