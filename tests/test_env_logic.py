@@ -163,3 +163,47 @@ def test_random_lifespans_follow_the_reference_rules():
     assert flagged > 100
     st = life.state(3)
     assert st.lifespan.shape == (3,) and st.max_lifespans.shape == (3,)
+
+
+# ---- Explorer's books ----------------------------------------------------------------------------------------------
+
+def test_seen_texel_books_follow_the_reference_bookkeeping():
+    """explorer.py:45-58 by other means: the reference re-counts the seen texels of every env each step and rewards the
+    difference; `SeenTexels` keeps a tally the render kernel adds to, a copy of it from the last call, and an epoch per
+    env that a respawn bumps (forgetting every texel at once). Here the kernel's part is played by hand: stamping texels
+    and raising the tally. The third row of `counters` is the env's own (Explorer keeps episode lengths there) and is
+    cleared with the rest."""
+    from megastep_amd import scene, toys
+    from megastep_amd.demo.envs import explorer
+    F = 5
+    sc = scene.scenery(F*[toys.box()], 1, device='cpu', bake=False)
+    books = explorer.SeenTexels(sc, F)
+    T = len(books.texel_env)
+    assert books.counters.shape == (3, F) and books.stamp.shape == (T,) and books.mask().sum() == 0
+    per_env = T//F
+    rng = np.random.RandomState(0)
+    seen = np.zeros((F, per_env), bool)                        # the reference's `_seen`, env by env
+    potential = np.zeros(F)
+    books.spare += 7
+    for step in range(12):
+        look = rng.uniform(size=(F, per_env)) < .1            # texels under this frame's rays
+        respawn = rng.uniform(size=F) < (.25 if step % 3 == 2 else 0.)
+        # reference order (explorer.py:83-95): respawned envs forget, then the frame is looked at
+        books.forget(torch.as_tensor(respawn))
+        seen[respawn] = False
+        potential[respawn] = 0
+        # the kernel: stamp what is in view with the env's epoch, add the texels that did not carry it to the tally
+        stamp = books.stamp.view(F, per_env).numpy()
+        epoch = books.epoch.numpy()
+        fresh = look & (stamp != epoch[:, None])
+        stamp[look] = np.broadcast_to(epoch[:, None], look.shape)[look]
+        books.tally += torch.as_tensor(fresh.sum(1).astype(np.int32))
+        # the reference: potential = seen texels per env, reward = its increase
+        seen |= look
+        new_potential = seen.sum(1)
+        np.testing.assert_array_equal(books.gained().numpy(), new_potential - potential)
+        potential = new_potential
+        np.testing.assert_array_equal(books.count.numpy(), potential)
+        np.testing.assert_array_equal(books.mask().view(F, per_env).numpy(), seen)
+        assert (books.spare.numpy()[respawn] == 0).all() and (books.gained() == 0).all()
+    assert potential.max() > 10
