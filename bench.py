@@ -7,16 +7,20 @@ floorplans, random momentum actions. One *step* = one pass of the hot path over 
 `ms_render`, both through the C-ABI; the step's inputs (velocities produced beforehand by the momentum-movement glue
 from random actions) are resident in HBM and read in place.
 
-The K timed steps are enqueued as ONE HIP graph (2K kernel nodes, recorded once, replayed inside the timed region):
-`value` is that replay's rate - what the kernels can do with the host out of the way. The same K steps launched one by
+The K timed steps are enqueued as ONE HIP graph (2K kernel nodes, recorded once, replayed inside the timed regions):
+`value` is the replays' rate - what the kernels can do with the host out of the way. The same K steps launched one by
 one from Python (`eager`) are timed beside it, with HIP events around every step and every render for the per-step
 spread and the roofline.
 
-With --gpus N>1 the driver launches this file under torch.distributed.run, one rank per GPU. The world holds N x
---envs envs; every rank cuts its slice out of it with `sharding.shard_scenery` (contiguous env slices balanced by
-lines x agents x rays - weak scaling, no collective on the data path: envs are independent); the ranks meet only in a
-gloo barrier around the timed region and a MAX over their times, so RCCL is never initialised. Rank 0 prints one JSON
-line.
+With --gpus N>1 the driver launches this file under torch.distributed.run, one rank per GPU. The job holds N x
+--envs envs; every rank works out the same contiguous cuts (balanced by lines x agents x rays) from the floorplans on
+the host and builds and bakes ITS slice only - weak scaling, no collective on the data path: envs are independent; the
+ranks meet only in a gloo barrier around each timed region and a MAX over their times, so RCCL is never initialised.
+Rank 0 prints one JSON line.
+
+Timing: a timed region is exactly K steps between barrier + synchronize pairs; regions are repeated until they add up
+to a quarter of a second and `value` / `ms_per_step` are the MEDIAN region's (min and max beside it), so that a
+K = 20 run is as repeatable as a K = 200 one.
 
 Besides the contract fields the line carries
   roofline      render kernel (the dominant one): algorithmic bytes per launch / its mean launch time (HIP events
@@ -50,19 +54,37 @@ def log(msg):
         print(f'[bench {time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
-def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False):
-    """The benchmark's world. With world > 1 the whole N x n_envs world is assembled and this rank keeps its slice."""
-    from megastep_amd import core, cubicasa, modules, scene, sharding
-    np.random.seed(seed)
+def world_geometries(n_envs, world, seed, n_unique=512, large=False):
+    """The floorplan of every env of the whole (world x n_envs)-env job: a pool of distinct plans, tiled."""
+    from megastep_amd import cubicasa
     pool = cubicasa.sample(min(n_unique, n_envs), seed=seed + 1, n_unique=max(n_unique, 16), large=large)
-    geometries = [pool[i % len(pool)] for i in range(world*n_envs)]
-    scenery = scene.scenery(geometries, n_agents, device=device, random=np.random.RandomState(seed), bake=bake, fast=fast)
-    if world > 1:
-        cost = sharding.render_cost(scenery, res)
-        start, stop = sharding.env_slice(len(geometries), rank, world, cost)
-        scenery = sharding.shard_scenery(scenery, rank, world, cost=cost)
-        geometries = geometries[start:stop]
+    return [pool[i % len(pool)] for i in range(world*n_envs)]
+
+
+def rank_slice(geometries, n_agents, res, rank, world):
+    """This rank's contiguous [start, stop) of the job's envs, balanced by lines x agents x rays - worked
+    out on the host from the floorplans alone, before anything is built."""
+    from megastep_amd import scene, sharding
+    if world == 1:
+        return 0, len(geometries)
+    af = n_agents*len(scene.agent_model())
+    cost = np.array([af + len(g['walls']) for g in geometries], np.float64)*n_agents*res
+    return sharding.env_slice(len(geometries), rank, world, cost)
+
+
+def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False):
+    """The benchmark's world - this rank's slice of it. With world > 1 the job has world x n_envs envs; every rank works
+    out the same cost-balanced cuts from the floorplans and builds (and bakes) its own slice only: nothing of the other
+    ranks' envs ever reaches this rank's device (reference: common.h:136-144 slices, it does not replicate)."""
+    from megastep_amd import core, modules, scene
+    geometries = world_geometries(n_envs, world, seed, n_unique, large)
+    start, stop = rank_slice(geometries, n_agents, res, rank, world)
+    np.random.seed(seed)
+    scenery = scene.scenery(geometries, n_agents, device=device, random=np.random.RandomState(seed), bake=bake, fast=fast,
+                            envs=(start, stop))
+    geometries = geometries[start:stop]
     c = core.Core(scenery, res=res, fov=fov, fps=10)
+    np.random.seed(seed + 1000*(rank + 1))
     spawner = modules.RandomSpawns(geometries, c, fast=fast)
     torch.manual_seed(seed + rank)
     spawner(c.agent_full(True))
@@ -378,6 +400,7 @@ def main(argv=None):
     views = [cuda.Agents(agents.angles, agents.positions, angvel[i], vel[i]) for i in range(total)]
 
     def timed(run):
+        """One timed region: barrier + synchronize on both sides, the slowest rank's wall time."""
         barrier()
         dev.sync()
         t0 = time.perf_counter()
@@ -386,29 +409,43 @@ def main(argv=None):
         barrier()
         return sharding.max_over_ranks(time.perf_counter() - t0)       # the slowest rank sets the step rate
 
+    def repeated(run, floor_s=0.25, least=5, most=400):
+        """`run` (exactly K steps) timed again and again - every region bracketed as above - until the regions add up to
+        `floor_s` seconds: with the driver's --steps 20 one region lasts a millisecond, too short to be a measurement on
+        its own. All ranks repeat equally often (the count comes from the first region's MAX over ranks)."""
+        first = timed(run)
+        n = int(min(max(np.ceil(floor_s/max(first, 1e-9)), least), most))
+        return np.array([first] + [timed(run) for _ in range(n - 1)])
+
     # ---- eager: K steps launched one by one, events around every step and every render
     for i in range(args.warmup):
         hot(views[i])
-    events = [(dev.event(), dev.event(), dev.event()) for _ in range(args.steps)]
+    events = []
 
     def eager():
+        evs = [(dev.event(), dev.event(), dev.event()) for _ in range(args.steps)]
         for i in range(args.steps):
-            events[i][0].record()
-            hot(views[args.warmup + i], events[i])
-    eager_s = timed(eager)
-    log(f'eager leg: {1e3*eager_s/args.steps:.4f} ms/step')
-    step_ms = np.array([e[0].elapsed_time(e[2]) for e in events])
-    render_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+            evs[i][0].record()
+            hot(views[args.warmup + i], evs[i])
+        events.append(evs)
+    eager_runs = repeated(eager, floor_s=0.1 if args.steps < 100 else 0.)
+    eager_s = float(np.median(eager_runs))
+    log(f'eager leg: {1e3*eager_s/args.steps:.4f} ms/step (median of {len(eager_runs)} regions of {args.steps} steps)')
+    step_ms = np.array([e[0].elapsed_time(e[2]) for evs in events for e in evs])
+    render_each = np.array([e[1].elapsed_time(e[2]) for evs in events for e in evs])
+    render_ms = float(np.median(render_each))
 
     # ---- graph: the same K steps as one HIP graph, replayed
-    graph_s = None
+    graph_s, graph_runs = None, None
     if not args.no_graph:
         replay = dev.graph(lambda: [hot(views[args.warmup + i]) for i in range(args.steps)])
         replay()                                                       # (instantiation / first-launch costs stay outside)
-        graph_s = timed(replay)
-        log(f'graph leg: {1e3*graph_s/args.steps:.4f} ms/step')
+        graph_runs = repeated(replay)
+        graph_s = float(np.median(graph_runs))
+        log(f'graph leg: {1e3*graph_s/args.steps:.4f} ms/step (median of {len(graph_runs)} replays of {args.steps} steps)')
 
     elapsed = graph_s if graph_s is not None else eager_s
+    runs = graph_runs if graph_runs is not None else eager_runs
     n_total = N
     if distributed:
         t = torch.tensor([N], dtype=torch.int64)
@@ -434,15 +471,19 @@ def main(argv=None):
             'lines_per_env': scenery.lines.vals.shape[0]/N, 'lights_per_env': scenery.lights.vals.shape[0]/N,
             'parallelism': f'env-sharded x{world} (contiguous slices balanced by lines x agents x rays), no collectives'},
         'agent_steps_per_sec': value*A,
-        'eager': {'value': n_total*args.steps/eager_s, 'ms_per_step': 1e3*eager_s/args.steps,
+        # `value` is the MEDIAN timed region (each exactly K steps between barrier + synchronize pairs); the spread:
+        'timed_regions': {'count': int(len(runs)), 'ms_per_step_min': 1e3*float(runs.min())/args.steps,
+                          'ms_per_step_median': ms_per_step, 'ms_per_step_max': 1e3*float(runs.max())/args.steps},
+        'eager': {'value': n_total*args.steps/eager_s, 'ms_per_step': 1e3*eager_s/args.steps, 'timed_regions': int(len(eager_runs)),
                   'step_ms_hip_events': {'min': float(step_ms.min()), 'median': float(np.median(step_ms)), 'max': float(step_ms.max())}},
         'roofline': {
             'kernel': 'ms_render = render_kernel<%s,1,0> (headings cached by ms_physics)' % {'pairs': 1, 'seq': 0}.get(os.environ.get('MEGASTEP_RENDER_IMPL', 'v2'), 2), 'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
-            'avg_launch_ms_source': 'HIP events on the stream around every ms_render of the eager leg (in place, between the physics '
-                                    'launches; the pair also times its own two event packets, about 1 us)',
+            'avg_launch_ms_source': 'median over HIP-event pairs on the stream around every ms_render of the eager leg (in place, '
+                                    'between the physics launches; the pair also times its own two event packets, about 1 us)',
+            'launch_ms_min_max': [float(render_each.min()), float(render_each.max())], 'launches_timed': int(len(render_each)),
             'step_algorithmic_bytes': rb + pb, 'step_achieved_GBps': (rb + pb)/(ms_per_step*1e-3)/1e9,
             # the raycast meets the fp32 VALU ceiling before the HBM one - the reference's all-pairs work
             # over this kernel's time, against the vector peak (the kernel culls, so this is an equivalent rate)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 9
+#define MS_ABI_VERSION 10
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -100,6 +100,32 @@ typedef struct MsScenery {
     unsigned long long* bake_vis;
     const long long*    bake_vis_starts;   /* (N,) */
     long long           bake_vis_words;    /* size of bake_vis, for bounds checking */
+    /* Optional wall grid (wg_cells NULL = none; no counterpart in the reference, whose kernels meet every line of an
+     * env for every ray and every agent, kernels.cu:203-205,352-377): a per-floorplan uniform grid whose cells each
+     * hold two lists of static walls (indices among the env's static lines, i.e. line index - n_agents*n_model):
+     *   vis   every wall that can matter to a ray cast from ANY point of the cell: a wall is left out only when one
+     *         other wall provably stands between it and the whole cell - with room to spare for the reference's
+     *         1e-4 hysteresis, its near plane and its rounding - so that the order-dependent nearest-hit fold over
+     *         the listed walls ends exactly where the fold over all of them does;
+     *   near  every wall that comes within wg_reach of the cell: all an agent in the cell whose step reaches no
+     *         farther than that can collide with.
+     * ms_render / ms_physics look the agent's cell up and walk its list instead of the env's lines; agents outside
+     * the grid, or faster than wg_reach allows, meet every line as before.  Filled by ms_wallgrid_scan +
+     * ms_wallgrid_fill (below) from the static walls as they are at that moment: the walls must not move afterwards
+     * (or the grid must be rebuilt / dropped).  Envs that share their walls (env_geom) share their cells.
+     *   wg_cells  (sum cells, 4) uint32: [first vis entry, vis count, first near entry, near count], entries in wg_pool
+     *   wg_starts (N,) first cell of env n;   wg_geom (N, 4) float: grid origin x, y, cells along x, cells along y
+     *             (0 cells: this env has no grid);   wg_cell: cell size in metres
+     *   wg_pool   uint16 wall indices; at least 64 entries longer than the lists need (loads are not clamped)
+     *   wg_near   vis lists hold for near planes (MsConfig.agent_radius) below this and fields of view up to
+     *             MS_WALLGRID_MAX_FOV degrees; ms_render ignores the grid otherwise */
+    const unsigned*       wg_cells;
+    const int*            wg_starts;
+    const float*          wg_geom;
+    float                 wg_cell;
+    float                 wg_reach;
+    float                 wg_near;
+    const unsigned short* wg_pool;
 } MsScenery;
 
 /* Replaces `Agents` (common.h:157-177). Updated IN PLACE by ms_physics. */
@@ -220,6 +246,29 @@ int ms_step_physics(const MsScenery* scenery, const MsAgents* agents, const MsMo
  * draw (rewrites the agent rows of lines_vals) -> raycast -> shade, one fused launch. */
 int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* out,
               const MsConfig* config, void* hip_stream);
+
+/* Builds the wall grid (MsScenery.wg_*) in two launches with a prefix sum by the caller in between.
+ *   ms_wallgrid_scan  for every cell of every env listed in `reps` (the representatives, MsScenery.env_geom; n_reps of
+ *                     them) works out which static walls belong on the cell's vis and near lists: one bit per wall
+ *                     into `bits` - the row of cell c (grid-local) of env n and list k (0 vis, 1 near) starts at word
+ *                     bits_starts[n] + (2 c + k) * ceil(walls(n)/32) - and the two counts into counts[2*(wg_starts[n] + c) + k].
+ *                     Reads wg_starts, wg_geom, wg_cell, wg_reach, wg_near of the scenery; `bits` and `counts` must
+ *                     start zeroed.  max_cells: the most cells any listed env has; max_walls: the most static walls.
+ *   ms_wallgrid_fill  writes the lists: the set bits of each row, in order, to wg_pool from the cell's wg_cells offsets
+ *                     (which the caller has filled in from the counts).
+ * An env with more than 65535 static walls must have a grid of 0 cells. */
+#define MS_WALLGRID_MAX_FOV 165.f
+int ms_wallgrid_scan(const MsScenery* scenery, const int* reps, int n_reps, int max_cells, int max_walls,
+                     const long long* bits_starts, unsigned* bits, unsigned* counts, void* hip_stream);
+int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int max_cells,
+                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, void* hip_stream);
+/* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
+ * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
+int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);
+/* ... and of the scan of one whole cell (c, row-major in a grid of nx x ny cells of size `cell` from (ox, oy)) over
+ * n_walls walls (n_walls x 4 floats, HOST memory): vis[t] / close[t] = 1 where wall t goes on the cell's vis / near list. */
+void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, int nx, int ny, float cell, int c,
+                           float near_plane, float reach, unsigned char* vis, unsigned char* close);
 
 /* Scalar helper exported for tests: sin(pi x), cos(pi x) exactly as the kernels evaluate them. */
 void ms_host_sincospi(float x, float* s, float* c);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -34,7 +34,9 @@ class MsScenery(C.Structure):
         ('n_lines_total', C.c_int), ('n_lights_total', C.c_int), ('n_texels_total', C.c_int),
         ('lg_vals', C.c_void_p), ('lg_starts', C.c_void_p), ('lg_geom', C.c_void_p), ('lg_cell', C.c_float),
         ('lg_max_cells', C.c_int), ('lg_list', C.c_void_p), ('lg_pool', C.c_void_p), ('lg_pool_size', C.c_int),
-        ('env_geom', C.c_void_p), ('bake_vis', C.c_void_p), ('bake_vis_starts', C.c_void_p), ('bake_vis_words', C.c_longlong)]
+        ('env_geom', C.c_void_p), ('bake_vis', C.c_void_p), ('bake_vis_starts', C.c_void_p), ('bake_vis_words', C.c_longlong),
+        ('wg_cells', C.c_void_p), ('wg_starts', C.c_void_p), ('wg_geom', C.c_void_p), ('wg_cell', C.c_float),
+        ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p)]
 
 
 class MsAgents(C.Structure):
@@ -63,7 +65,8 @@ class MsRender(C.Structure):
 #: every symbol include/megastep_hip.h declares
 SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics',
-           'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins')
+           'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
+           'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell')
 
 
 def _source_hash():
@@ -78,7 +81,7 @@ def _source_hash():
 
 def build(force=False):
     """Compiles csrc/megastep_hip.hip for gfx950 with hipcc (cross-compiles without a GPU). The library is stale when
-    the hash of its sources differs from the one recorded next to it at build time (mtimes do not survive copies);
+    the hash of its sources differs from the one the Makefile recorded next to it (mtimes do not survive copies);
     concurrent callers (one rank per GPU) serialise on a lock file."""
     import fcntl
     stamp = LIB_PATH + '.srchash'
@@ -94,8 +97,6 @@ def build(force=False):
                 proc = subprocess.run(['make', '-C', CSRC, '-B', 'libmegastep_hip.so'], capture_output=True, text=True)
                 if proc.returncode != 0:
                     raise RuntimeError(f'hipcc build of libmegastep_hip.so failed:\n{proc.stdout}\n{proc.stderr}')
-                with open(stamp, 'w') as f:
-                    f.write(want)
     return LIB_PATH
 
 
@@ -108,7 +109,16 @@ def lib():
     global _lib
     if _lib is None:
         if not os.environ.get('MEGASTEP_HIP_LIB'):
-            build()                     # a no-op while the in-tree library is newer than its sources
+            try:
+                build()                 # a no-op while the in-tree library matches its sources
+            except (RuntimeError, OSError) as e:
+                # no hipcc on this host, or a read-only tree: a library that is already there is loaded as it is and
+                # the ABI check below decides; without one there is nothing to fall back to
+                if not os.path.exists(LIB_PATH):
+                    raise
+                import warnings
+                warnings.warn(f'{LIB_PATH} could not be rebuilt from the sources next to it ({type(e).__name__}: '
+                              f'{str(e).splitlines()[0] if str(e) else e}); loading it as it is')
         handle = C.CDLL(LIB_PATH)
         missing = [s for s in SYMBOLS if not hasattr(handle, s)]
         if missing:
@@ -130,7 +140,16 @@ def lib():
         handle.ms_host_bake_point_bin.restype = C.c_int
         handle.ms_host_bake_wall_bins.argtypes = [C.c_float]*6 + [_i32p, _i32p]
         handle.ms_host_bake_wall_bins.restype = None
-        for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_step_physics', 'ms_render'):
+        handle.ms_wallgrid_scan.argtypes = [C.POINTER(MsScenery), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        handle.ms_wallgrid_fill.argtypes = [C.POINTER(MsScenery), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
+        handle.ms_host_wall_hidden.argtypes = [C.c_float]*4 + [_f32p, _f32p, C.c_float]
+        handle.ms_host_wall_hidden.restype = C.c_int
+        handle.ms_host_wallgrid_cell.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
+                                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        handle.ms_host_wallgrid_cell.restype = None
+        for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_step_physics', 'ms_render', 'ms_wallgrid_scan', 'ms_wallgrid_fill'):
             getattr(handle, name).restype = C.c_int
         if handle.ms_abi_version() != ABI_VERSION:
             raise ImportError(f'{LIB_PATH} has ABI {handle.ms_abi_version()}, this package needs {ABI_VERSION}; rebuild it')

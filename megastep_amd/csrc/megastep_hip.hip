@@ -194,7 +194,7 @@ __device__ inline int wave_scan_add(int x) {                           // lanes 
     asm volatile(MS_SCAN6("v_add_u32_dpp") : "+v"(x));
     return x;
 }
-__device__ inline int wave_scan_max(int x) {
+[[maybe_unused]] __device__ inline int wave_scan_max(int x) {
     asm volatile(MS_SCAN6("v_max_i32_dpp") : "+v"(x));
     return x;
 }
@@ -215,10 +215,12 @@ struct LineRows {
         : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(base), 0, n_rows*16, 0x00020000)) {}
     __device__ float4 load(int lane_bytes, int first_row) const {
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, first_row*16, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, first_row*16, 0);   // (first_row: 0 from every caller)
         return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
-    __device__ float4 chunk(int lane, int first_row) const { return load(lane*16, first_row); }   // rows first_row + lane
+    // rows first_row + lane.  (The chunk's offset rides in the lane's VGPR offset, which the hardware's bounds check
+    // covers for certain; the scalar offset is added after the check on some generations.)
+    __device__ float4 chunk(int lane, int first_row) const { return load((first_row + lane)*16, 0); }
     __device__ float4 row(int i) const { return load(i*16, 0); }
 };
 
@@ -267,10 +269,17 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     // large maps the stream of walls is what the kernel lasts (asking for the agents first cost 12 % there).
     // (Unconditional loads - behind a branch hipcc waits for every load in flight at the first use of any of them;
     // lanes past the last wall read zeros and are masked by `live` in the sweep.)
+    // (With a wall grid the walls come from the agents' cells instead, and nothing is asked for here: on large maps
+    // this stream is what the kernel used to last.)
     const LineRows rows(ln, L);
+    const bool gridded = sc.wg_cells != nullptr;                         // (the same for every wave of the launch)
     float4 w[PHYS_AHEAD];
     #pragma unroll
-    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = rows.chunk(lane, AF + k*WAVE);
+    for (int k = 0; k < PHYS_AHEAD; k++) w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!gridded) {
+        #pragma unroll
+        for (int k = 0; k < PHYS_AHEAD; k++) w[k] = rows.chunk(lane, AF + k*WAVE);
+    }
     // one lane per agent: its state (kept for the epilogue).  (Behind a guard on purpose: everything requested before it
     // has arrived by the time it is used, which measured no worse at 300 walls and 4 % better at 1000.)
     float2 my_p, my_v;
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         }
     }
     float4 my_box = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);   // (no agent: a box no finite wall touches)
+    float my_reach = 0.f;
     for (int t = lane; t < A; t += WAVE) {
         const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
         const P2 p0 = p2(pp.x, pp.y);
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         if ((vl > 0.f) & (vl < 1e-3f)) reach = INFINITY;
         s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
         const float4 box = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
-        if (t == lane) my_box = box;
+        if (t == lane) { my_box = box; my_reach = (reach == reach) ? reach : INFINITY; }
         s_box[t] = box;
         s_task[t] = make_float4(p0.x, p0.y, v0.x, v0.y);
         s_prog[t] = f_bits(1.f);
@@ -359,6 +369,62 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         }
     }
 
+    // one (wall, agent) pair: the reach cull on the true distance, then the reference's test (kernels.cu:135-171,202-205)
+    auto meet = [&](const float4 u, const int t) {
+        const float4 tk = s_task[t];
+        // squared distance from the agent to the segment, shaved so it is a lower bound
+        const float vx = u.z - u.x, vy = u.w - u.y;
+        const float pqx = u.x - tk.x, pqy = u.y - tk.y;
+        float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+        tc = fminf(fmaxf(tc, 0.f), 1.f);
+        tc = (tc == tc) ? tc : 0.f;
+        const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+        if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {                     // NaNs stay in
+            const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
+            if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
+        }
+    };
+    // With a wall grid (MsScenery.wg_*, wallgrid_scan_kernel): an agent's cell names every wall within wg_reach of it,
+    // which is every wall the agent can touch if its own reach is no longer than that - a dozen or two instead of the
+    // env's hundreds.  Lane = agent for the look-up; then the agents' lists are laid end to end and dealt to the lanes,
+    // one (wall, agent) pair each.  If any agent of the env is outside its grid, or faster than the lists allow (or
+    // crawling: see above), the env takes the sweep over all its walls below.
+    bool swept = true;
+    if (gridded) {
+        unsigned first = 0u;
+        int count = 0;
+        bool ok = A <= WAVE;
+        if (lane < A) {
+            const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+            const float inv_cell = __builtin_amdgcn_rcpf(sc.wg_cell);
+            const float4 me = s_task[lane];
+            const float fx = floorf((me.x - geom.x)*inv_cell), fy = floorf((me.y - geom.y)*inv_cell);
+            const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);   // (NaNs: outside)
+            const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[sc.wg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0)];
+            ok = inside & (my_reach <= sc.wg_reach);
+            first = hdr.z; count = ok ? (int)hdr.w : 0;
+        }
+        if (!__ballot(!ok)) {
+            swept = false;
+            const int incl = wave_scan_add(count);
+            const int excl = incl - count;
+            const int P = __builtin_amdgcn_readlane(incl, 63);
+            for (int p0 = 0; p0 < P; p0 += WAVE) {
+                const int q = p0 + lane;
+                int t = 0;
+                for (int j = 0; j < A - 1; j++) t += (__builtin_amdgcn_readlane(incl, j) <= q) ? 1 : 0;   // whose list is pair q in?
+                const int k = q - __shfl(excl, t, WAVE);
+                const unsigned at = (unsigned)__shfl((int)first, t, WAVE) + (unsigned)k;
+                if (q < P) {
+                    const int e = sc.wg_pool[at];
+                    meet(rows.row(AF + e), t);
+                }
+            }
+        } else {
+            #pragma unroll
+            for (int k = 0; k < PHYS_AHEAD; k++) w[k] = rows.chunk(lane, AF + k*WAVE);
+        }
+    }
     // (wall, agent) pairs collect in an LDS list with room for one agent's worth of a chunk on top of a flush's worth.
     int cnt = 0;
     auto flush = [&]() {
@@ -367,22 +433,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         #pragma unroll 1
         for (int p0 = 0; p0 < cnt; p0 += WAVE) {
-            if (p0 + lane < cnt) {
-                const float4 u = s_wall[p0 + lane];
-                const int t = s_tag[p0 + lane];
-                const float4 tk = s_task[t];
-                // squared distance from the agent to the segment, shaved so it is a lower bound
-                const float vx = u.z - u.x, vy = u.w - u.y;
-                const float pqx = u.x - tk.x, pqy = u.y - tk.y;
-                float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
-                tc = fminf(fmaxf(tc, 0.f), 1.f);
-                tc = (tc == tc) ? tc : 0.f;
-                const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-                if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {             // NaNs stay in
-                    const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
-                    if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
-                }
-            }
+            if (p0 + lane < cnt) meet(s_wall[p0 + lane], s_tag[p0 + lane]);
         }
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
@@ -408,7 +459,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         bx[t][0] = readlane_f(my_box.x, t); bx[t][1] = readlane_f(my_box.y, t);
         bx[t][2] = readlane_f(my_box.z, t); bx[t][3] = readlane_f(my_box.w, t);
     }
-    for (int l0 = AF; l0 < L; l0 += PHYS_AHEAD*WAVE) {
+    for (int l0 = AF; swept && l0 < L; l0 += PHYS_AHEAD*WAVE) {
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) {
             const float4 u = w[k];
@@ -737,6 +788,13 @@ __device__ inline float grid_light_intensity(
 //               atomic + hysteresis flag instead of the three-slot cascade
 //   MS_V2_OPTS  bit 0: IMPL 2 drains its list after every chunk; bit 1: IMPL 2 clips like IMPL 1
 //               (tried and dropped: keys from v_rcp_f32 with the exact quotient once per ray - correct, not faster)
+//   MS_AB_IMPLS 1: the library also holds the two older raycasts (IMPL 1 "pairs": per-chunk pair windows; IMPL 0 "seq":
+//               the reference's fold in its literal order, every line, no lists), selected per call by the environment
+//               variable MEGASTEP_RENDER_IMPL=pairs|seq - `make ab` builds it as libmegastep_hip_ab.so; the product
+//               library holds IMPL 2 alone and reads no environment on its hot path
+#ifndef MS_AB_IMPLS
+#define MS_AB_IMPLS 0
+#endif
 #ifndef MS_V1_OPTS
 #define MS_V1_OPTS 0
 #endif
@@ -962,17 +1020,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
-    // IMPL 2 asks for its first chunks of lines here - right behind the agents' state, which is needed first and, loads
-    // returning in order, would otherwise wait for them: nothing needs the lines until the raycast, and one chunk's work
-    // does not hide the next one's trip (1600 cycles under load) on its own
-    constexpr int AHEAD = 3;                     // chunks in flight
-    float4 w_first[AHEAD];
-    if constexpr (IMPL == 2) {
-        // (unconditional loads: behind a branch hipcc waits for every load in flight at the first use of any of them,
-        // which turns "in flight" into "one at a time"; rows past the end read zeros and are ignored later)
-        #pragma unroll
-        for (int k = 0; k < AHEAD; k++) w_first[k] = rows.chunk(lane, k*WAVE);
-    }
+    constexpr int AHEAD = 3;                     // chunks of lines in flight (IMPL 2)
 
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
     // there is one.  Lanes exchange data in here: call it from wave-uniform control flow only.
@@ -995,16 +1043,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         return w;
     };
     auto agent_line = [&](const int l_) { return agent_line_m(l_, false, make_float4(0.f, 0.f, 0.f, 0.f)); };
-    // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
-    // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
-    // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
-    if (g == 0) {
-        for (int m0 = 0; m0 < sc.n_model; m0 += WAVE) {
-            const float4 w = agent_line_m(a*sc.n_model + m0 + lane, m0 == 0, mdl_draw);
-            if (m0 + lane < sc.n_model) ln[a*sc.n_model + m0 + lane] = w;
-        }
-    }
-    // --- ray setup (kernels.cu:334-344)
+    // --- this wave's agent: heading and position (kernels.cu:334-339)
     float sn, cs;
     float2 pp;
     if (A <= WAVE) {
@@ -1015,6 +1054,35 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         sn = sc_.x; cs = sc_.y;
         pp = reinterpret_cast<const float2*>(ag.positions)[n*A + a];
     }
+    // --- the wall grid (MsScenery.wg_*, wallgrid_scan_kernel): the cell the agent stands in names the walls that can
+    // matter to any ray cast from it; asked for here, as early as the position is known - the draw step and the ray
+    // set-up below run while the answer travels.  No grid, or an agent outside it: every static wall (wg_count < 0).
+    // (ms_render hands over wg_cells only when the grid holds for this call's near plane and field of view.)
+    unsigned wg_first = 0u;
+    int wg_count = -1;
+    if constexpr (IMPL == 2) {
+        if (sc.wg_cells) {                                                  // (the same for every wave of the launch)
+            const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+            const float inv_cell = __builtin_amdgcn_rcpf(sc.wg_cell);       // (cells are grown by a centimetre: an ulp is nothing)
+            const float fx = floorf((pp.x - geom.x)*inv_cell), fy = floorf((pp.y - geom.y)*inv_cell);
+            const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);    // (NaNs, an env without a grid: outside)
+            // every wave reads a header that exists - its cell's, or the row at its env's start (the array is padded by one)
+            const int cell_id = __builtin_amdgcn_readfirstlane(sc.wg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0));
+            const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[cell_id];
+            wg_first = inside ? hdr.x : 0u;
+            wg_count = inside ? (int)hdr.y : -1;
+        }
+    }
+    // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
+    // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
+    // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
+    if (g == 0) {
+        for (int m0 = 0; m0 < sc.n_model; m0 += WAVE) {
+            const float4 w = agent_line_m(a*sc.n_model + m0 + lane, m0 == 0, mdl_draw);
+            if (m0 + lane < sc.n_model) ln[a*sc.n_model + m0 + lane] = w;
+        }
+    }
+    // --- ray setup (kernels.cu:334-344)
     const float Rf = (float)R;
     const float uy = (Rf - 2*(float)r - 1)*half_screen/Rf;            // ray_y, kernels.cu:234-236
     const float rx = cs*1.f - sn*uy, ry = sn*1.f + cs*uy;
@@ -1027,11 +1095,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const float c_a = 0.5f*(Rf - 1.f), c_b = rc.c_b;                      // c_b = R/2/half_screen
     const float x_clip = rc.x_clip;                                        // agent_radius/2/sqrt(1 + half_screen^2)
     const float g0 = (float)(g*WAVE);
-    const int my_group = lane/GSIZE;
+    [[maybe_unused]] const int my_group = lane/GSIZE;
 
     float nearest_s = INFINITY;
     int nearest_idx = -1;
 
+#if MS_AB_IMPLS
     if constexpr (IMPL == 1) {
         // ------------------------------------------------------------------------------------------
         // (line, ray) pairs.  Pass 1 (lane = line) turns each line of the chunk into a conservative
@@ -1255,7 +1324,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             if (ambiguous) { nearest_s = x; nearest_idx = xi; }
         }
-    } else if constexpr (IMPL == 2) {
+    } else
+#endif
+    if constexpr (IMPL == 2) {
         // ------------------------------------------------------------------------------------------
         // (line, ray) pairs, second edition.  Same idea as IMPL 1 - pass 1 (lane = line) gives every line a
         // conservative integer interval of this wave's rays, pass 2 deals the (line, ray) pairs to the lanes - but
@@ -1400,19 +1471,48 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if constexpr ((MS_V2_OPTS & 1) != 0) drain();
         };
 
-        float4 w_next[AHEAD];                                                // the next chunks' lines travel while this one is worked on
+        // The lines this wave meets, as one sequence of items: the AF agent lines (worked out from the agents' state,
+        // never read), then the walls - those on the cell's vis list, in list order, or all of them.  Item i of a chunk
+        // is lane i's; what a lane needs from memory is its list entry (a 16-bit wall index, through a buffer
+        // descriptor over the list: lanes before and past it read zero) and then that wall's row.  AHEAD chunks of rows
+        // are in flight, and the list entries of the AHEAD chunks behind those.  (The chunk loop is unrolled by hand
+        // over the chunks in flight: rotating them through registers would make the moves wait for the loads they
+        // move.  All loads are unconditional: behind a branch hipcc waits for every load in flight at the first use of
+        // any of them, which turns "in flight" into "one at a time".)
+        const bool listed = wg_count >= 0;                                   // (uniform)
+        const int n_walls = listed ? wg_count : max(L - AF, 0);
+        const int n_items = AF + n_walls;
+        const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(sc.wg_pool + wg_first), 0, listed ? 2*n_walls : 0, 0x00020000);
+        const int lane_entry = 2*(lane - AF);
+        auto entry = [&](const int i0) {                                     // list entries of items i0 + lane
+            return (int)__builtin_amdgcn_raw_buffer_load_b16(list_rsrc, lane_entry + 2*i0, 0, 0);
+        };
+        auto line_of = [&](const int i0, const int e) {                      // the env's line behind item i0 + lane
+            const int i = i0 + lane;
+            return (listed & (i >= AF)) ? AF + e : i;
+        };
+        int l_next[AHEAD], e_next[AHEAD];
+        float4 w_next[AHEAD];
         #pragma unroll
-        for (int k = 0; k < AHEAD; k++) w_next[k] = w_first[k];
-        // (the chunk loop is unrolled by hand over the chunks in flight: rotating them through registers would make the
-        // moves wait for the loads they move)
-        for (int c0 = 0; c0 < L; c0 += AHEAD*WAVE) {
+        for (int k = 0; k < AHEAD; k++) e_next[k] = entry(k*WAVE);
+        #pragma unroll
+        for (int k = 0; k < AHEAD; k++) {
+            l_next[k] = line_of(k*WAVE, e_next[k]);
+            w_next[k] = rows.load(l_next[k]*16, 0);
+            e_next[k] = entry((k + AHEAD)*WAVE);
+        }
+        for (int i0 = 0; i0 < n_items; i0 += AHEAD*WAVE) {
             #pragma unroll
             for (int k = 0; k < AHEAD; k++) {
-                const int ck = c0 + k*WAVE;
+                const int ik = i0 + k*WAVE;
                 const float4 w_now = w_next[k];
-                w_next[k] = fetch(ck + AHEAD*WAVE);
-                if (ck >= L) continue;                                       // uniform
-                admit(w_now, ck + lane, ck + lane < L, ck < AF, ck == 0);
+                const int l_now = l_next[k];
+                l_next[k] = line_of(ik + AHEAD*WAVE, e_next[k]);
+                w_next[k] = rows.load(l_next[k]*16, 0);
+                e_next[k] = entry(ik + 2*AHEAD*WAVE);
+                if (ik >= n_items) continue;                                 // uniform
+                admit(w_now, l_now, ik + lane < n_items, ik < AF, ik == 0);
             }
         }
         if (n_pairs) drain();
@@ -1521,7 +1621,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             }
             if (ambiguous) { nearest_s = x; nearest_idx = xi; }
         }
-    } else {
+    }
+#if MS_AB_IMPLS
+    else {
         for (int c0 = 0; c0 < L; c0 += WAVE) {
             // ---- pass 1: lane = line.  Each line of the chunk gets a CONSERVATIVE interval [r_lo, r_hi] of
             // continuous ray indices it can be hit from; a ballot per ray group turns those into one 64-bit
@@ -1603,6 +1705,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
 
     }
+#endif
 
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
     // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
@@ -2433,6 +2536,209 @@ __global__ __launch_bounds__(WG) void lightlist_kernel(const MsScenery sc) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// wall grid: which walls matter to an agent in which cell          (accelerates kernels.cu:203-205,352-377)
+// ------------------------------------------------------------------------------------------------
+// The reference's raycast and its collision test meet every line of an env.  Per floorplan and per cell of a uniform
+// grid over it, wallgrid_scan_kernel works out two sets of static walls:
+//
+// vis: the walls that can matter to a ray cast from anywhere in the cell.  A wall W is left out when ONE other wall O
+// hides all of it from all of the cell:
+//   (1) the cell's four corners lie on one side of O's line, at least WG `near` away from it;
+//   (2) both ends of W lie on the other side;
+//   (3) each of the eight segments corner -> end of W crosses O strictly inside it.
+// For a fixed corner the points behind O as seen from it form a convex set, which holds both ends of W and so all of
+// W; for a fixed point of W the same goes for the cell: every segment from the cell to W crosses O.  So every ray
+// from the cell that hits W has hit O first - a hit the reference registers, since O is beyond the near plane (1) and
+// the ray not parallel to it ((4) below) - and, by (5), computed to be nearer than W's by more than 2e-4: twice the
+// 1e-4 band of the reference's order-dependent nearest-hit rule (kernels.cu:369).  Such a W cannot change the rule's
+// outcome: in line order, when the fold reaches W either O came before, and the state is below s_O + 1e-4 < s_W -
+// 1e-4, so W is not taken; or O comes later, and whatever the state is by then - with W taken or without - it is at
+// least s_W - 1e-4 > s_O + 1e-4, so O is taken in both histories and they are one from there on.  Walls dropped from
+// a set of hits one at a time, farthest first, each while its occluder is still there: the fold over what is left
+// ends where the fold over all of them does.
+//   (4) |V_O| dist(corner, O's line) >= 2e-3 |corner -> end of W|: then |U x V_O| >= 2e-3 for every such ray
+//       (|U| >= 1), clear of the reference's 1e-3 parallelism cut-off (kernels.cu:77);
+//   (5) the ends of W are behind O's line by at least
+//           WG_BAND + 4 (1.2e-7 D^2 + 2.4e-7 C D) (1/h_W + 1/h_O)
+//       D: the largest corner -> end distance, C: the largest coordinate, h_W / h_O: the least distance of a corner
+//       from W's / O's line (W's must have the whole cell on one side too).  The bracket bounds the rounding error
+//       of a hit distance as the reference computes it (a quotient of two cross products that both cancel by a factor
+//       D/h), WG_BAND is 2e-4 in units of the longest ray direction vector the grid is used with (|ru| <= 8: fields
+//       of view up to MS_WALLGRID_MAX_FOV degrees) with a factor 2.5 to spare.
+// Walls shorter than WG_MIN_OCCLUDER are not tried as occluders (half the walls of a floorplan are the 15 cm ends of
+// wall pieces, and leaving them out changes the lists by a percent); NaNs fail every comparison: such walls stay listed
+// and hide nothing.
+//
+// near: the walls that come within wg_reach of the cell (of its centre, + half a diagonal): all that an agent in the
+// cell whose step reaches no farther can touch (physics_kernel's reach cull decides wall by wall from there).
+constexpr float WG_SLACK = 0.01f;          // cells are grown by this on every side: a position's rounding cannot leave them
+constexpr float WG_MIN_OCCLUDER = 0.3f;
+constexpr float WG_BAND = 4e-3f;
+constexpr float WG_MAX_RU2 = 64.f;         // |ru|^2 = 1 + tan^2(fov/2) the vis lists are good for
+
+struct WgCell { float x0, y0, x1, y1; };
+
+__host__ __device__ inline WgCell wg_cell_of(const float4 geom, const float cell, const int c) {
+    const int nx = (int)geom.z;
+    const int ix = c % nx, iy = c / nx;
+    WgCell k;
+    k.x0 = geom.x + ix*cell - WG_SLACK; k.y0 = geom.y + iy*cell - WG_SLACK;
+    k.x1 = k.x0 + cell + 2*WG_SLACK;    k.y1 = k.y0 + cell + 2*WG_SLACK;
+    return k;
+}
+
+// What the test needs of a target wall W and the cell, worked out once per (cell, W)
+struct WgTarget {
+    float qx[2], qy[2];           // ends of W
+    float dx[8], dy[8], dp[8];    // per (corner i, end j) at 2 i + j: D = q_j - p_i, cross(D, p_i)
+    float ms[8];                  // straddle margin x |D|
+    float dmax, a_w, k_w;         // D; WG_BAND + K/h_W; K = 4 (1.2e-7 D^2 + 2.4e-7 C D)
+    bool cullable;
+};
+
+__host__ __device__ inline WgTarget wg_target(const WgCell& k, const float4 w) {
+    WgTarget t;
+    t.qx[0] = w.x; t.qy[0] = w.y; t.qx[1] = w.z; t.qy[1] = w.w;
+    const float px[4] = {k.x0, k.x1, k.x1, k.x0}, py[4] = {k.y0, k.y0, k.y1, k.y1};
+    float d2max = 0.f;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) {
+        const float dx = t.qx[j] - px[i], dy = t.qy[j] - py[i];
+        const float d2 = dx*dx + dy*dy;
+        t.dx[2*i + j] = dx; t.dy[2*i + j] = dy; t.dp[2*i + j] = dx*py[i] - dy*px[i];
+        const float d = sqrtf(d2);
+        t.ms[2*i + j] = (0.01f + 1e-4f*d)*d;
+        d2max = fmaxf(d2max, d2);
+    }
+    t.dmax = sqrtf(d2max);
+    const float cmax = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))) + fmaxf(fabsf(k.x0), fabsf(k.x1)) + fmaxf(fabsf(k.y0), fabsf(k.y1));
+    t.k_w = 4.f*(1.2e-7f*d2max + 2.4e-7f*cmax*t.dmax);
+    // the cell against W's own line: all four corners on one side, the nearest h_W away
+    const float vx = w.z - w.x, vy = w.w - w.y;
+    const float vl = sqrtf(vx*vx + vy*vy);
+    float hmin = INFINITY;
+    bool pos = true, neg = true;
+    for (int i = 0; i < 4; i++) {
+        const float c = vx*(py[i] - w.y) - vy*(px[i] - w.x);
+        pos &= c > 0.f; neg &= c < 0.f;
+        hmin = fminf(hmin, fabsf(c));
+    }
+    const float h_w = hmin/vl;
+    t.cullable = (pos | neg) & (h_w > 0.f) & (t.dmax < INFINITY);      // (NaNs, zero-length walls, a cell on W's line: never culled)
+    t.a_w = WG_BAND + t.k_w/h_w;
+    return t;
+}
+
+// Does wall o = (ax, ay, bx, by) hide the target from the whole cell?  true only when (1)-(5) hold.
+__host__ __device__ inline bool wg_hides(const WgCell& k, const WgTarget& t, const float4 o, const float near_plane) {
+    const float ax = o.x, ay = o.y, vx = o.z - o.x, vy = o.w - o.y;
+    const float vl2 = vx*vx + vy*vy;
+    if (!(vl2 >= WG_MIN_OCCLUDER*WG_MIN_OCCLUDER) || !t.cullable) return false;
+    const float vl = sqrtf(vl2);
+    // (1) the corners: c_i = cross(V, p_i - a) = |V| x signed distance
+    const float c0 = vx*(k.y0 - ay) - vy*(k.x0 - ax), c1 = vx*(k.y0 - ay) - vy*(k.x1 - ax);
+    const float c2 = vx*(k.y1 - ay) - vy*(k.x1 - ax), c3 = vx*(k.y1 - ay) - vy*(k.x0 - ax);
+    const bool pos = (c0 > 0.f) & (c1 > 0.f) & (c2 > 0.f) & (c3 > 0.f), neg = (c0 < 0.f) & (c1 < 0.f) & (c2 < 0.f) & (c3 < 0.f);
+    const float cmin = fminf(fminf(fabsf(c0), fabsf(c1)), fminf(fabsf(c2), fabsf(c3)));
+    if (!((pos | neg) & (cmin >= near_plane*vl))) return false;
+    // (2) the ends of W on the other side, (5) far enough behind
+    const float d0 = vx*(t.qy[0] - ay) - vy*(t.qx[0] - ax), d1 = vx*(t.qy[1] - ay) - vy*(t.qx[1] - ax);
+    const bool behind = pos ? ((d0 < 0.f) & (d1 < 0.f)) : ((d0 > 0.f) & (d1 > 0.f));
+    const float gap = fminf(fabsf(d0), fabsf(d1));                       // x |V|
+    const float need = t.a_w + t.k_w*(vl/cmin);
+    if (!(behind & (gap >= need*vl))) return false;
+    // (4) the reference registers the hit on O
+    if (!(cmin >= 2e-3f*t.dmax)) return false;
+    // (3) a and b strictly on opposite sides of every segment corner -> end
+    const float bx = o.z, by = o.w;
+    bool ok = true;
+    for (int e = 0; e < 8; e++) {
+        const float sa = t.dx[e]*ay - t.dy[e]*ax - t.dp[e];              // cross(D, a - p)
+        const float sb = t.dx[e]*by - t.dy[e]*bx - t.dp[e];
+        ok &= ((sa > t.ms[e]) & (sb < -t.ms[e])) | ((sa < -t.ms[e]) & (sb > t.ms[e]));
+    }
+    return ok;
+}
+
+// Does wall w come within `reach` of the cell?  Distance from the cell's centre to the wall, against reach + half a
+// diagonal; false only when provably not (NaNs stay in: the reference stops an agent at such a wall, kernels.cu:109-118)
+__host__ __device__ inline bool wg_close(const WgCell& k, const float4 w, const float reach) {
+    const float cx = .5f*(k.x0 + k.x1), cy = .5f*(k.y0 + k.y1);
+    const float vx = w.z - w.x, vy = w.w - w.y, pqx = w.x - cx, pqy = w.y - cy;
+    float tc = -(pqx*vx + pqy*vy)/(vx*vx + vy*vy);
+    tc = fminf(fmaxf(tc, 0.f), 1.f);
+    tc = (tc == tc) ? tc : 0.f;
+    const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+    const float rr = reach + .7072f*(k.x1 - k.x0) + 1e-3f + 1e-4f*(fabsf(cx) + fabsf(cy));
+    return !(0.9998f*(qx*qx + qy*qy) > rr*rr);
+}
+
+// One wavefront per (representative env, cell, 64 walls): lane = target wall, the env's walls as occluders one after
+// the other (a uniform address: they arrive through the scalar cache).
+__global__ __launch_bounds__(WG) void wallgrid_scan_kernel(const MsScenery sc, const int* __restrict__ reps, const int max_chunks,
+                                                          const long long* __restrict__ bits_starts, unsigned* __restrict__ bits,
+                                                          unsigned* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int n = reps[blockIdx.y];
+    const long long item = (long long)blockIdx.x*WAVES + (threadIdx.x >> 6);
+    const int c = (int)(item / max_chunks), chunk = (int)(item - (long long)c*max_chunks);
+    const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+    const int ncell = (int)geom.z*(int)geom.w;
+    const int AF = sc.n_agents*sc.n_model;
+    const int n_walls = max(sc.lines_widths[n] - AF, 0);
+    if (c >= ncell || chunk*WAVE >= n_walls) return;                     // (whole waves)
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n] + AF;
+    const WgCell k = wg_cell_of(geom, sc.wg_cell, c);
+    const int t_ = chunk*WAVE + lane;
+    const bool live = t_ < n_walls;
+    const float4 w = ln[min(t_, n_walls - 1)];
+    const WgTarget tg = wg_target(k, w);
+    bool hidden = !live;
+    for (int o = 0; o < n_walls; o++) {
+        if (__all(hidden)) break;
+        const float4 ow = ln[o];                                         // uniform
+        if ((o != t_) && wg_hides(k, tg, ow, sc.wg_near)) hidden = true;
+    }
+    const bool close = live & wg_close(k, w, sc.wg_reach);
+    const unsigned long long vm = __ballot(live & !hidden), nm = __ballot(close);
+    if (lane == 0) {
+        const int W32 = (n_walls + 31) >> 5;
+        unsigned* row = bits + bits_starts[n] + (long long)(2*c)*W32 + 2*chunk;
+        row[0] = (unsigned)vm;
+        if (2*chunk + 1 < W32) row[1] = (unsigned)(vm >> 32);
+        row[W32] = (unsigned)nm;
+        if (2*chunk + 1 < W32) row[W32 + 1] = (unsigned)(nm >> 32);
+        const size_t cell_id = (size_t)sc.wg_starts[n] + c;
+        atomicAdd(&counts[2*cell_id], (unsigned)__popcll(vm));
+        atomicAdd(&counts[2*cell_id + 1], (unsigned)__popcll(nm));
+    }
+}
+
+// One wavefront per (representative env, cell, list): the set bits of the row, in order, into the pool.
+__global__ __launch_bounds__(WG) void wallgrid_fill_kernel(const MsScenery sc, const int* __restrict__ reps,
+                                                          const long long* __restrict__ bits_starts, const unsigned* __restrict__ bits,
+                                                          unsigned short* __restrict__ pool) {
+    const int lane = threadIdx.x & 63;
+    const int n = reps[blockIdx.y];
+    const long long item = (long long)blockIdx.x*WAVES + (threadIdx.x >> 6);
+    const int c = (int)(item >> 1), kind = (int)(item & 1);
+    const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+    if (c >= (int)geom.z*(int)geom.w) return;
+    const int n_walls = max(sc.lines_widths[n] - sc.n_agents*sc.n_model, 0);
+    const int W32 = (n_walls + 31) >> 5;
+    const unsigned* __restrict__ row = bits + bits_starts[n] + (long long)(2*c + kind)*W32;
+    const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[(size_t)sc.wg_starts[n] + c];
+    unsigned at = kind ? hdr.z : hdr.x;
+    for (int w0 = 0; w0 < W32; w0 += WAVE) {                             // lane = word
+        const unsigned m = (w0 + lane < W32) ? row[w0 + lane] : 0u;
+        const int cnt = __popc(m);
+        const int incl = wave_scan_add(cnt);
+        unsigned o = at + (unsigned)(incl - cnt);
+        for (unsigned r = m; r; r &= r - 1) pool[o++] = (unsigned short)(32*(w0 + lane) + __ffs((int)r) - 1);
+        at += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ------------------------------------------------------------------------------------------------
 int hip_fail(hipError_t e) { g_last_hip_error = (int)e; return MS_EHIP; }
@@ -2479,10 +2785,62 @@ void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, fl
     bake_wall_bins(p2(light_x, light_y), ax, ay, bx, by, *first, *count);
 }
 
+int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane) {
+    const WgCell k{x0, y0, x1, y1};
+    const WgTarget t = wg_target(k, make_float4(w[0], w[1], w[2], w[3]));
+    return wg_hides(k, t, make_float4(o[0], o[1], o[2], o[3]), near_plane) ? 1 : 0;
+}
+
+void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, int nx, int ny, float cell, int c,
+                           float near_plane, float reach, unsigned char* vis, unsigned char* close) {
+    const float4* ln = reinterpret_cast<const float4*>(walls);
+    const WgCell k = wg_cell_of(make_float4(ox, oy, (float)nx, (float)ny), cell, c);
+    for (int t = 0; t < n_walls; t++) {
+        const WgTarget tg = wg_target(k, ln[t]);
+        bool hidden = false;
+        for (int o = 0; o < n_walls && !hidden; o++) hidden = (o != t) && wg_hides(k, tg, ln[o], near_plane);
+        vis[t] = hidden ? 0 : 1;
+        close[t] = wg_close(k, ln[t], reach) ? 1 : 0;
+    }
+}
+
+static bool wallgrid_ok(const MsScenery* sc) {
+    return sc->wg_starts && sc->wg_geom && sc->wg_cell > 0.f && sc->wg_reach >= 0.f && sc->wg_near > 0.f && ((uintptr_t)sc->wg_geom % 16 == 0);
+}
+
+int ms_wallgrid_scan(const MsScenery* sc, const int* reps, int n_reps, int max_cells, int max_walls,
+                     const long long* bits_starts, unsigned* bits, unsigned* counts, void* stream) {
+    if (!scenery_ok(sc) || !wallgrid_ok(sc) || !reps || n_reps < 0 || max_cells < 0 || max_walls < 0 || max_walls > 65535 ||
+        !bits_starts || !bits || !counts) return MS_EINVAL;
+    if (n_reps == 0 || max_cells == 0 || max_walls == 0) return MS_OK;
+    const int max_chunks = (max_walls + WAVE - 1)/WAVE;
+    const long long blocks = ((long long)max_cells*max_chunks + WAVES - 1)/WAVES;
+    if (blocks > 0x7fffffffLL || n_reps > 65535) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(wallgrid_scan_kernel, dim3((unsigned)blocks, (unsigned)n_reps), dim3(WG), 0, (hipStream_t)stream,
+                       *sc, reps, max_chunks, bits_starts, bits, counts);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+int ms_wallgrid_fill(const MsScenery* sc, const int* reps, int n_reps, int max_cells,
+                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, void* stream) {
+    if (!scenery_ok(sc) || !wallgrid_ok(sc) || !sc->wg_cells || ((uintptr_t)sc->wg_cells % 16) || !reps || n_reps < 0 || max_cells < 0 ||
+        !bits_starts || !bits || !pool) return MS_EINVAL;
+    if (n_reps == 0 || max_cells == 0) return MS_OK;
+    const long long blocks = (2LL*max_cells + WAVES - 1)/WAVES;
+    if (blocks > 0x7fffffffLL || n_reps > 65535) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(wallgrid_fill_kernel, dim3((unsigned)blocks, (unsigned)n_reps), dim3(WG), 0, (hipStream_t)stream,
+                       *sc, reps, bits_starts, bits, pool);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
 int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, const MsStepExtras* ex, float* progress,
                     const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
     if (mv && (!mv->actions || !mv->table || mv->n_actions < 1 || !(mv->keep == mv->keep))) return MS_EINVAL;
+    if (sc->wg_cells && (!sc->wg_starts || !sc->wg_geom || !sc->wg_pool || !(sc->wg_cell > 0.f) || ((uintptr_t)sc->wg_cells % 16) ||
+                         ((uintptr_t)sc->wg_geom % 16))) return MS_EINVAL;
     if (ex) {
         if (ex->spawn_positions && (!ex->spawn_angles || !ex->respawn_mask || !ex->respawn_choice || ex->n_spawns < 1 ||
                                     ((uintptr_t)ex->spawn_positions % 8))) return MS_EINVAL;
@@ -2535,17 +2893,23 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
     // kernels.cu:22
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
-    // MEGASTEP_RENDER_IMPL=seq selects the slower kernel that folds in the reference's literal order
-    // (kept for A/B verification); both produce the same bits.
-    // MEGASTEP_RENDER_IMPL: "seq" (literal order, slowest), "pairs" (round 1's pair raycast), "v2" (compacted pairs, the
-    // default); all three produce the same bits.  Read per call: tests switch it.
+#if MS_AB_IMPLS
+    // MEGASTEP_RENDER_IMPL: "seq" (literal order, slowest), "pairs" (round 1's pair raycast), anything else the product's
+    // kernel; all three produce the same bits.  Read per call: tests switch it.
     const char* impl_env = getenv("MEGASTEP_RENDER_IMPL");
     const bool seq = impl_env && impl_env[0] == 's';
-    const bool pairs1 = impl_env && impl_env[0] == 'p';                        // default: "v2"
+    const bool pairs1 = impl_env && impl_env[0] == 'p';
+#endif
     // the light grid is all or nothing: render_kernel lights agent-hit rays itself when it is there
     MsScenery scn = *sc;
     const bool grid = sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f;
     if (!grid) scn.lg_vals = nullptr;
+    // ... and so is the wall grid: its vis lists were built for near planes below wg_near and ray direction vectors no
+    // longer than sqrt(WG_MAX_RU2) (wallgrid_scan_kernel); a call outside that meets every wall instead
+    const bool walls_listed = sc->wg_cells && sc->wg_starts && sc->wg_geom && sc->wg_pool && sc->wg_cell > 0.f &&
+                              cfg->agent_radius*1.001f < sc->wg_near && 1.f + half_screen*half_screen <= WG_MAX_RU2;
+    if (!walls_listed) scn.wg_cells = nullptr;
+    else if (((uintptr_t)sc->wg_cells % 16) || ((uintptr_t)sc->wg_geom % 16)) return MS_EINVAL;
     // Headings: from ms_physics' cache when the agents carry one and a single kernel does the whole job (then the
     // workspace is not needed at all); otherwise from render_prep_kernel, which also resets the workspace's counters.
     MsAgents agn = *ag;
@@ -2579,18 +2943,15 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
     const hipStream_t hs = (hipStream_t)stream;
-    if (seq && obs)
-        hipLaunchKernelGGL((render_kernel<0, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
-    else if (seq)
-        hipLaunchKernelGGL((render_kernel<0, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
-    else if (!pairs1 && obs)
-        hipLaunchKernelGGL((render_kernel<2, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
-    else if (!pairs1)
-        hipLaunchKernelGGL((render_kernel<2, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
-    else if (obs)
-        hipLaunchKernelGGL((render_kernel<1, RW, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+#define MS_LAUNCH_RENDER(I, O) \
+    hipLaunchKernelGGL((render_kernel<I, RW, O>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
+#if MS_AB_IMPLS
+    if (seq) { if (obs) MS_LAUNCH_RENDER(0, 1); else MS_LAUNCH_RENDER(0, 0); }
+    else if (pairs1) { if (obs) MS_LAUNCH_RENDER(1, 1); else MS_LAUNCH_RENDER(1, 0); }
     else
-        hipLaunchKernelGGL((render_kernel<1, RW, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+#endif
+    { if (obs) MS_LAUNCH_RENDER(2, 1); else MS_LAUNCH_RENDER(2, 0); }
+#undef MS_LAUNCH_RENDER
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.
     if (!grid && sc->n_agents > 1)

@@ -10,6 +10,7 @@ reference: docs/faq.rst:23-26): calling bake/physics/render on non-GPU tensors r
 """
 import ctypes as C
 import numbers
+import os
 import torch
 from . import _lib
 
@@ -162,6 +163,7 @@ class Agents:
         self._struct = _lib.MsAgents(*ptrs, self._headings.data_ptr())
         self._plain = _lib.MsAgents(*ptrs, None)
         self._cached = False
+        self._epoch = 0             # moved on by every physics call and every respawn (modules.IMU's stale-reading check)
         # (measured at 16 k to 262 k agents: one launch and one kernel boundary fewer per step, 1-3 % of the step)
         self._use_cache = bool(self.HEADING_CACHE)
         devices = {t.device for t in (angles, positions, angvelocity, velocity)}
@@ -208,6 +210,7 @@ class Scenery:
         self._geom = geom
         self._struct = None
         self._lg = None             # the light grid's tensors; made by _as_struct unless sharding carried one over
+        self._wg = None             # the wall grid's tensors (cells, starts, geom, cell, reach, near, pool); made by bake()
         self._dev = None
 
     n_agents = property(lambda self: self._n_agents)
@@ -237,15 +240,7 @@ class Scenery:
         ln = self._lines
         dev = ln.vals.device
         n_envs, cell = len(ln), self.LIGHT_GRID_CELL
-        env = ln.inverse.long()
-        static = (torch.arange(ln.vals.shape[0], device=dev) - ln.starts.long()[env]) >= self._n_agents*self._model.shape[0]
-        env, pts = env[static], ln.vals[static]              # the walls; agent rows move
-        big = torch.finfo(torch.float32).max
-        idx = env[:, None].expand(-1, 2)
-        lo = torch.full((n_envs, 2), big, device=dev).scatter_reduce_(0, idx, pts.amin(1), 'amin')
-        hi = torch.full((n_envs, 2), -big, device=dev).scatter_reduce_(0, idx, pts.amax(1), 'amax')
-        empty = lo[:, 0] > hi[:, 0]                          # an env without walls gets a 1 x 1 grid
-        lo[empty], hi[empty] = 0., 0.
+        lo, hi = self._wall_bounds()
         origin = torch.floor(lo) - .5
         dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
         cells = (dims[:, 0]*dims[:, 1]).long()
@@ -258,6 +253,23 @@ class Scenery:
         lists = torch.zeros((total, 2), dtype=torch.int32, device=dev)
         pool = torch.zeros(min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1), dtype=torch.int32, device=dev)
         return vals, starts.contiguous(), geom, cell, int(cells.max()), lists, pool
+
+    def _wall_bounds(self):
+        """(n_envs, 2) lower and upper corner of each env's static walls (finite coordinates only; 0, 0 without any)."""
+        ln = self._lines
+        dev = ln.vals.device
+        n_envs = len(ln)
+        env = ln.inverse.long()
+        static = (torch.arange(ln.vals.shape[0], device=dev) - ln.starts.long()[env]) >= self._n_agents*self._model.shape[0]
+        env, pts = env[static], ln.vals[static]              # the walls; agent rows move
+        big = torch.finfo(torch.float32).max
+        fin = torch.isfinite(pts)
+        idx = env[:, None].expand(-1, 2)
+        lo = torch.full((n_envs, 2), big, device=dev).scatter_reduce_(0, idx, torch.where(fin, pts, big).amin(1), 'amin')
+        hi = torch.full((n_envs, 2), -big, device=dev).scatter_reduce_(0, idx, torch.where(fin, pts, -big).amax(1), 'amax')
+        empty = (lo > hi).any(1)                             # an env without (finite) walls gets a 1 x 1 grid at the origin
+        lo[empty], hi[empty] = 0., 0.
+        return lo, hi
 
     def _as_struct(self):
         if self._struct is None:
@@ -278,8 +290,113 @@ class Scenery:
                 ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0],
                 *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4],
                 *(t.data_ptr() if t is not None else None for t in lg[5:7]), lg[6].shape[0] if lg[6] is not None else 0,
-                self._geom.data_ptr() if self._geom is not None else None, None, None, 0)
+                self._geom.data_ptr() if self._geom is not None else None, None, None, 0,
+                *self._wall_grid_fields())
         return self._struct
+
+    def _wall_grid_fields(self):
+        wg = self._wg
+        if wg is None:
+            return (None, None, None, 0., 0., 0., None)
+        cells, starts, geom, cell, reach, near, pool = wg
+        return (cells.data_ptr(), starts.data_ptr(), geom.data_ptr(), cell, reach, near, pool.data_ptr())
+
+    #: the wall grid (include/megastep_hip.h, MsScenery.wg_*): cell size in metres, the step length its collision lists
+    #: cover (both movement modules' defaults stay below it at 10 fps), the near plane its visibility lists allow for,
+    #: and how much memory it may take - beyond that the cells are doubled in size, twice at most, then it is left out
+    WALL_GRID = os.environ.get('MEGASTEP_WALL_GRID', '1') != '0'       # (the environment switch is for A/B runs)
+    WALL_GRID_CELL = .25
+    WALL_GRID_REACH = 1.3
+    WALL_GRID_NEAR = .12
+    WALL_GRID_BYTES = 8 << 30
+    WALL_GRID_MAX_CELLS = 1 << 18       # per floorplan
+    WALL_GRID_SCRATCH = 1 << 30         # bytes of bitmaps in flight while it is built
+
+    def _build_wall_grid(self):
+        """Builds the wall grid from the static walls as they are now (called by :func:`bake`): per floorplan a uniform
+        grid, per cell the walls a ray from the cell can be decided by and the walls an agent in it can run into.
+        Two launches per group of floorplans with a prefix sum in between; returns nothing, installs ``_wg``."""
+        self._wg, self._struct = None, None
+        if not self.WALL_GRID:
+            return
+        dev = self._device()
+        ln = self._lines
+        n_envs = len(ln)
+        af = self._n_agents*self._model.shape[0]
+        walls = (ln.widths.long() - af).clamp(min=0)
+        if n_envs == 0 or int(walls.max()) == 0:
+            return
+        arange = torch.arange(n_envs, device=dev)
+        rep = arange if self._geom is None else self._geom.long()
+        is_rep = rep == arange
+        lo, hi = self._wall_bounds()
+        h = _lib.lib()
+        for cell in (self.WALL_GRID_CELL, 2*self.WALL_GRID_CELL, 4*self.WALL_GRID_CELL):
+            origin = torch.floor(lo) - .5
+            dims = torch.ceil((hi + .5 - origin)/cell).clamp(min=1)
+            cells = (dims[:, 0]*dims[:, 1])
+            ok = (cells <= self.WALL_GRID_MAX_CELLS) & (walls > 0) & (walls <= 65535)
+            dims = torch.where(ok[:, None], dims, torch.zeros_like(dims))
+            cells = torch.where(ok, cells, torch.zeros_like(cells)).long()
+            own = cells*is_rep                                             # members own no cells
+            starts = (own.cumsum(0) - own)[rep].to(torch.int32).contiguous()
+            geom = torch.cat([origin, dims], 1).float()[rep].contiguous()
+            total = int(own.sum())
+            if total == 0:
+                return
+            w32 = (walls + 31)//32
+            row_words = 2*own*w32                                          # bitmap words per representative
+            reps = torch.nonzero(own > 0).flatten()
+            struct = _lib.MsScenery.from_buffer_copy(self._as_struct())
+            struct.wg_starts, struct.wg_geom = starts.data_ptr(), geom.data_ptr()
+            struct.wg_cell, struct.wg_reach, struct.wg_near = cell, self.WALL_GRID_REACH, self.WALL_GRID_NEAR
+            counts = torch.zeros((total, 2), dtype=torch.int32, device=dev)
+            # groups of representatives whose bitmaps fit the scratch budget (and a launch's grid)
+            words = row_words[reps]
+            group = ((words.cumsum(0) - words)*4//self.WALL_GRID_SCRATCH)
+            group = torch.maximum(group, torch.arange(len(reps), device=dev)//60000)
+            bounds = [0] + (torch.nonzero(group[1:] != group[:-1]).flatten() + 1).tolist() + [len(reps)]
+            pools, cell_rows, base, fits = [], torch.zeros((total, 4), dtype=torch.int64, device=dev), 0, True
+            with _on(dev):
+                for g0, g1 in zip(bounds[:-1], bounds[1:]):
+                    r = reps[g0:g1]
+                    r32 = r.to(torch.int32).contiguous()
+                    gw = row_words[r]
+                    bits_starts = torch.zeros(n_envs, dtype=torch.int64, device=dev)
+                    bits_starts[r] = gw.cumsum(0) - gw
+                    bits = torch.zeros(max(int(gw.sum()), 1), dtype=torch.int32, device=dev)
+                    mc, mw = int(cells[r].max()), int(walls[r].max())
+                    _lib.check(h.ms_wallgrid_scan(C.byref(struct), r32.data_ptr(), len(r), mc, mw, bits_starts.data_ptr(),
+                                                  bits.data_ptr(), counts.data_ptr(), _stream(dev)))
+                    # the cells of this group, in storage order, and their lists' places in the group's pool
+                    first = starts[r].long()
+                    span = own[r]
+                    rows = torch.repeat_interleave(first - (span.cumsum(0) - span), span) + torch.arange(int(span.sum()), device=dev)
+                    cnt = counts[rows].long()                              # (cells, 2)
+                    flat = cnt.flatten()
+                    off = flat.cumsum(0) - flat
+                    n_entries = int(flat.sum())
+                    if 2*(base + n_entries) > self.WALL_GRID_BYTES or base + n_entries >= 2**32 - 64:
+                        fits = False
+                        break
+                    off = (off + base).view(-1, 2)
+                    cell_rows[rows] = torch.stack([off[:, 0], cnt[:, 0], off[:, 1], cnt[:, 1]], 1)
+                    hdr = _as_u32(cell_rows)
+                    pool = torch.zeros(n_entries + 64, dtype=torch.int16, device=dev)
+                    struct.wg_cells = hdr.data_ptr()
+                    # the fill kernel writes at the header's offsets: hand it the group's pool displaced by `base`
+                    _lib.check(h.ms_wallgrid_fill(C.byref(struct), r32.data_ptr(), len(r), mc, bits_starts.data_ptr(),
+                                                  bits.data_ptr(), C.c_void_p(pool.data_ptr() - 2*base), _stream(dev)))
+                    torch.cuda.current_stream(dev).synchronize()           # (hdr / bits / pool of this group are done with)
+                    pools.append(pool[:n_entries])
+                    base += n_entries
+            if fits:
+                pool = torch.cat(pools + [torch.zeros(64, dtype=torch.int16, device=dev)])
+                hdr = _as_u32(torch.cat([cell_rows, torch.zeros((1, 4), dtype=torch.int64, device=dev)]))   # (+ the row agents outside the last grid read)
+                self._wg = (hdr, starts, geom, float(cell), float(self.WALL_GRID_REACH), float(self.WALL_GRID_NEAR), pool)
+                self._struct = None
+                return
+
 
     def _bake_plan(self):
         """Scratch for the two-phase bake (MsScenery.bake_vis): for each representative env, lights x ceil(texels/64)
@@ -342,6 +459,11 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def _as_u32(t):
+    """An int64 tensor of values below 2^32 as the int32 tensor whose bits are those values as uint32."""
+    return torch.where(t >= 2**31, t - 2**32, t).to(torch.int32).contiguous()
+
+
 class _on:
     """Makes ``dev`` the current HIP device for the launch if it is not already."""
 
@@ -364,10 +486,13 @@ def _agents_on(agents, dev):
         raise RuntimeError(f'all tensors must live on one device; got {agents._dev} and {dev}')
 
 
-def bake(scenery, scratch=True):
+def bake(scenery, scratch=True, wall_grid=True):
     """Pre-computes the static lighting of every texel into ``scenery.baked`` (reference: wrappers.cpp:61,
     kernels.cu:270-293). ``scratch=False`` selects the library's self-contained one-pass kernel (no temporary
-    allocation, no sharing between envs; same result)."""
+    allocation, no sharing between envs; same result). Baking also (re)builds the scenery's wall grid - the per-cell
+    lists of walls that :func:`render` and :func:`physics` walk instead of every line of the env (include/megastep_hip.h,
+    ``MsScenery.wg_*``) - from the walls as they are now: like the baked light it goes stale if static walls are moved
+    afterwards (bake again, or pass ``wall_grid=False`` to go without)."""
     dev = scenery._device()
     # bake uses none of the initialize() constants (kernels.cu:238-293), and scene.scenery() calls it before any Core
     # exists, so the config is optional here
@@ -379,6 +504,8 @@ def bake(scenery, scratch=True):
         struct.bake_vis, struct.bake_vis_starts, struct.bake_vis_words = vis.data_ptr(), starts.data_ptr(), vis.shape[0]
     with _on(dev):
         _lib.check(_lib.lib().ms_bake(C.byref(struct), cfg, _stream(dev)))
+    if wall_grid:
+        scenery._build_wall_grid()
 
 
 def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None):
@@ -451,6 +578,7 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
         _lib.check(_lib.lib().ms_step_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
                                               mv, ex, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
     agents._cached = agents._use_cache
+    agents._epoch += 1
     return Physics(progress) if out is None else out
 
 

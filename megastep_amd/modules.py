@@ -50,7 +50,7 @@ def _move(core, actionset, actions, keep, respawn=None, imu=None, table=None):
         reading = None if imu is None else (torch.empty(agents.angles.shape + (3,), device=core.device), imu.ang_scale, imu.speed_scale)
         result = cuda.physics(core.scenery, agents, movement=(actions.long().contiguous(), table, keep), respawn=respawn, imu=reading)
         if imu is not None:
-            imu._pending = reading[0]
+            imu._pending = (reading[0], agents._epoch)          # valid until somebody else touches the agents
         return result
     if respawn is not None and not respawn['after']:
         _respawn(agents, respawn)
@@ -76,6 +76,7 @@ def _respawn(agents, request):
     agents.positions[:] = torch.where(reset[..., None], positions, agents.positions)
     agents.velocity[:] = torch.where(reset[..., None], torch.zeros_like(agents.velocity), agents.velocity)
     agents.angvelocity[:] = torch.where(reset, torch.zeros_like(agents.angvelocity), agents.angvelocity)
+    agents._epoch += 1                  # (a reading an IMU module holds of the state before this is stale now)
 
 
 class SimpleMovement:
@@ -207,13 +208,17 @@ class IMU:
         self.space = spaces.MultiVector(n_agents or core.n_agents, 3)
         self.speed_scale = speed_scale
         self.ang_scale = ang_scale
-        self._pending = None        # a reading the physics launch has already taken of the current state (see _move)
+        # a reading the physics launch has already taken (see _move), with the agents' epoch at that moment: every
+        # physics call and every respawn through this module's helpers moves the epoch on, and a reading from an earlier
+        # epoch is dropped (state changed behind the modules' back - writes straight into the tensors - is not seen)
+        self._pending = None
 
     def __call__(self):
-        if self._pending is not None:
-            reading, self._pending = self._pending, None
-            return reading
         agents = self.core.agents
+        if self._pending is not None:
+            (reading, epoch), self._pending = self._pending, None
+            if epoch == agents._epoch:
+                return reading
         return torch.cat([
             agents.angvelocity[..., None]/self.ang_scale,
             to_local_frame(agents.angles, agents.velocity)/self.speed_scale], -1)
@@ -228,12 +233,16 @@ def random_empty_positions(geometries, n_agents, n_points):
     for e, g in enumerate(geometries):
         free = free_cells.get(id(g))
         if free is None:
-            free = free_cells[id(g)] = np.stack((g['masks'] > 0).nonzero(), -1)
-        n_possible = min(len(free)//n_agents, n_points)
-        sample = free[np.random.choice(np.arange(len(free)), (n_possible, n_agents), replace=True)]
-        sample = np.concatenate([sample]*int(n_points/len(sample) + 1))[-n_points:]
-        sample = np.random.permutation(sample)
-        points[e] = geometry.centers(sample, g['masks'].shape, g['res']).transpose(1, 0, 2)
+            free = free_cells[id(g)] = np.argwhere(g['masks'] > 0)           # (row, col) of every free cell
+        # two draws from the global stream per env, as the reference makes them: which cells (one row of the table per
+        # agent-tuple, at most as many rows as the plan has room for), then the order the table is served in
+        rows = max(min(len(free)//n_agents, n_points), 0)
+        picks = np.random.choice(np.arange(len(free)), (rows, n_agents), replace=True)
+        # a plan too small for n_points distinct rows repeats its table; the last n_points rows are the ones kept
+        repeats = int(n_points/rows + 1)
+        table = np.tile(free[picks], (repeats, 1, 1))[-n_points:]
+        table = table[np.random.permutation(len(table))]
+        points[e] = np.swapaxes(geometry.centers(table, g['masks'].shape, g['res']), 0, 1)
     return points
 
 

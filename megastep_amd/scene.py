@@ -149,9 +149,14 @@ def _device_pattern(n_texels, starts, lengths, device, l=.5):
 
 
 @torch.no_grad()
-def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, fast=False):
+def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, fast=False, envs=None):
     """One env per geometry (dicts with ``walls`` (W, 2, 2) and ``lights`` (I, 2)), ``n_agents`` agents in each, on
     ``device``, lighting baked. ``bake=False`` skips the GPU bake, for host-only plumbing.
+
+    ``envs=(start, stop)`` builds only that contiguous slice of the world ``geometries`` describes - what one GPU of
+    several owns (reference: common.h:136-144 slices, it does not replicate) - and nothing of the rest reaches the
+    device; the random streams are still advanced past the envs before ``start``, so the slice holds exactly the rows
+    the whole build would (``tests/test_bench_gloo.py``). With ``fast=True`` there is no stream to keep in step.
 
     Light intensities and wall patterns come from the reference's random streams in the reference's order (per env:
     intensities from the global ``np.random``, then the pattern's ``choice`` and ``normal`` from ``random``), so a
@@ -163,6 +168,10 @@ def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, 
     agentlines, agentcolors = np.tile(model, (n_agents, 1, 1)), np.tile(agent_colors(), (n_agents, 1))
     distinct, which = _distinct(geometries)
     lines_u, counts_u, colours_u, n_lines_u, lights_u, n_lights_u = _floorplan_tables(distinct, agentlines, agentcolors)
+    start, stop = (0, len(geometries)) if envs is None else (int(envs[0]), int(envs[1]))
+    if not (0 <= start <= stop <= len(geometries)):
+        raise ValueError(f'envs={envs} is not a slice of {len(geometries)} geometries')
+    which_all, which = which, which[start:stop]
 
     # lines and texel counts of every env: gathers from the distinct tables
     line_widths, line_src = _expand(n_lines_u, which, device)
@@ -175,6 +184,7 @@ def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, 
     texels_u = texel_ends_u[line_ends_u] - texel_ends_u[line_ends_u - n_lines_u]
     n_texels, n_lights = texels_u[which], n_lights_u[which]
     agent_texels = int(resolutions(agentlines).sum())
+    n_envs = stop - start
 
     # the per-env random part
     if fast:
@@ -182,6 +192,9 @@ def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, 
         brightness = None
     else:
         intensity, brightness = np.empty(n_lights.sum()), np.empty(n_texels.sum())
+        for u in which_all[:start]:                                     # the envs before the slice: their draws, thrown away
+            np.random.uniform(.5, 2., (n_lights_u[u], 1))
+            wall_pattern(texels_u[u], random=random)
         i0 = t0 = 0
         for ni, nt in zip(n_lights, n_texels):
             intensity[i0:i0 + ni] = np.random.uniform(.5, 2., (ni, 1))[:, 0]   # GLOBAL np.random, as scene.py:82 does
@@ -201,7 +214,7 @@ def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, 
     colours = torch.as_tensor(colours_u, device=device)
     texel_ends = np.concatenate([[0], n_texels.cumsum()])
     e0 = 0
-    while e0 < len(geometries):
+    while e0 < n_envs:
         e1 = max(int(np.searchsorted(texel_ends, texel_ends[e0] + _TEXEL_CHUNK, 'right')) - 1, e0 + 1)
         t0, t1 = int(texel_ends[e0]), int(texel_ends[e1])
         if brightness is None:
@@ -217,9 +230,9 @@ def scenery(geometries, n_agents=1, device='cuda', random=np.random, bake=True, 
         e0 = e1
 
     geom = None
-    if len(distinct) < len(geometries):
-        first_env = np.full(len(distinct), len(geometries), np.int64)
-        np.minimum.at(first_env, which, np.arange(len(geometries)))
+    if len(np.unique(which)) < n_envs:
+        first_env = np.full(len(distinct), n_envs, np.int64)
+        np.minimum.at(first_env, which, np.arange(n_envs))
         geom = torch.as_tensor(first_env[which], device=device).to(torch.int32)
     result = cuda.Scenery(n_agents=n_agents, lights=lights, lines=lines, textures=textures,
                           model=arrdict.torchify(model).to(device), geom=geom)

@@ -69,6 +69,9 @@ def shard_scenery(scenery, rank, world_size, device=None, cost=None):
     parent = getattr(scenery, '_lg', None)
     if parent is not None and parent[0] is not None and out.model.is_cuda:
         out._lg = _shard_light_grid(parent, start, stop, device, geom)
+    # the wall grid (per floorplan, too) is rebuilt from the shard's own walls: two launches
+    if getattr(scenery, '_wg', None) is not None and out.model.is_cuda:
+        out._build_wall_grid()
     return out
 
 

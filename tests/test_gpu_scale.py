@@ -168,6 +168,7 @@ def test_walls_with_non_finite_coordinates_go_through_the_exact_test(n_agents):
         lines[e, wall, coord] = bad[e % 3]
         if e % 5 == 0:
             lines[e, wall, (coord + 2) % 4] = bad[(e + 1) % 3]
+    cuda.bake(sc)                                             # walls were moved: the wall grid (and the baked light) start over
     c.agents.positions[:] = torch.as_tensor(rng.uniform(1.2, 4.8, (48, n_agents, 2)).astype(np.float32), device='cuda')
     util.random_velocities(c, rng, speed=6.)
     ref = util.OracleWorld(c)

@@ -1,0 +1,159 @@
+"""The wall grid's two promises, checked on the CPU against the oracle (include/megastep_hip.h, MsScenery.wg_*;
+DESIGN.md section 3.9): the library's host instantiation of its scan (the very functions the gfx950 kernel is compiled
+from) decides which walls go on a cell's lists, the plain-C oracle - which knows nothing of any list - says what the
+reference's raycast sees.
+
+  vis   the oracle's render of a world reduced to a cell's vis list equals its render of the whole world, ray for ray
+        and bit for bit, from poses all over the cell: the order-dependent nearest-hit fold (kernels.cu:352-377) ends
+        where it would have;
+  near  no wall within reach of a point of the cell is missing from the cell's near list.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+from megastep_amd import _lib, cubicasa, scene, toys, core
+
+CELL, NEAR, REACH = .25, .12, 1.3
+
+
+def scan_cell(walls, origin, dims, c, cell=CELL):
+    """vis, close (bool arrays over the walls) of cell c, from the library's host instantiation of its scan."""
+    w = np.ascontiguousarray(walls.reshape(-1, 4), np.float32)
+    vis, close = np.zeros(len(w), np.uint8), np.zeros(len(w), np.uint8)
+    _lib.lib().ms_host_wallgrid_cell(w.ctypes.data, len(w), float(origin[0]), float(origin[1]), int(dims[0]), int(dims[1]),
+                                     cell, int(c), NEAR, REACH, vis.ctypes.data, close.ctypes.data)
+    return vis.astype(bool), close.astype(bool)
+
+
+def grid_of(walls, cell=CELL):
+    """Origin and dims as cuda.Scenery._build_wall_grid lays them out."""
+    fin = walls[np.isfinite(walls).all((1, 2))]
+    lo, hi = fin.reshape(-1, 2).min(0), fin.reshape(-1, 2).max(0)
+    origin = np.floor(lo) - .5
+    dims = np.maximum(np.ceil((hi + .5 - origin)/cell), 1).astype(int)
+    return origin.astype(np.float32), dims
+
+
+def worlds(oracle, walls, poses, keep=None, fov=130., res=64):
+    """The oracle's render of one single-agent env per pose (x, y, angle): every env holds the agent's model and the
+    walls `keep[i]` selects for pose i (all of them without). Returns the render and, per env, the original wall
+    behind each of its static lines."""
+    model = scene.agent_model().astype(np.float32)
+    M = len(model)
+    lines, widths, origin = [], [], []
+    for i in range(len(poses)):
+        sel = np.arange(len(walls)) if keep is None else np.nonzero(keep[i])[0]
+        lines.append(np.concatenate([model, walls[sel]]))
+        widths.append(M + len(sel))
+        origin.append(sel)
+    n_lines = sum(widths)
+    sc = oracle.Scene(dict(
+        n_agents=1, model=model, lights_vals=np.zeros((0, 3), np.float32), lights_widths=np.zeros(len(poses), np.int32),
+        lines_vals=np.concatenate(lines).astype(np.float32), lines_widths=np.array(widths, np.int32),
+        textures_vals=np.full((n_lines, 3), .5, np.float32), textures_widths=np.ones(n_lines, np.int32)))
+    poses = np.asarray(poses, np.float32)
+    agents = dict(angles=poses[:, None, 2], positions=poses[:, None, :2], angvelocity=np.zeros((len(poses), 1), np.float32),
+                  velocity=np.zeros((len(poses), 1, 2), np.float32))
+    r = oracle.render(sc, agents, oracle.config(core.AGENT_RADIUS, res, fov, 10.))
+    # hit indices in terms of the ORIGINAL walls: agent lines stay 0..M-1, wall k of the env becomes M + its number
+    idx = r['indices'][:, 0]
+    orig = np.full_like(idx, -1)
+    for i in range(len(poses)):
+        table = np.concatenate([np.arange(M), M + origin[i]])
+        orig[i] = np.where(idx[i] >= 0, table[np.maximum(idx[i], 0)], -1)
+    return orig, r
+
+
+def mutated(walls, rng):
+    """Walls moved onto each other, collapsed to points, poisoned - the cases the hysteresis rule is sensitive to."""
+    w = walls.copy()
+    n = len(w)
+    pick = rng.choice(n, max(n//8, 4), replace=False)
+    w[pick[0::4]] = w[rng.choice(n, len(pick[0::4]))]                  # exact duplicates (coincident walls)
+    w[pick[1::4], 1] = w[pick[1::4], 0]                                # zero length
+    w[pick[2::4]] += rng.normal(0, 2e-5, w[pick[2::4]].shape).astype(np.float32)   # nearly coincident
+    w[pick[3]] = np.nan
+    return w
+
+
+CASES = ['plan0', 'plan1', 'plan2_mutated', 'plan3_mutated', 'large', 'box', 'column']
+
+
+def case_walls(name):
+    rng = np.random.RandomState(abs(hash(name)) % 2**31)
+    if name.startswith('plan'):
+        g = cubicasa.sample(4, n_unique=16)[int(name[4])]
+        w = g.walls.astype(np.float32)
+        return mutated(w, rng) if name.endswith('mutated') else w
+    if name == 'large':
+        return cubicasa.sample(1, n_unique=16, large=True)[0].walls.astype(np.float32)
+    return (toys.box() if name == 'box' else toys.column()).walls.astype(np.float32)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_vis_lists_leave_the_fold_where_it_was(oracle, name):
+    walls = case_walls(name)
+    rng = np.random.RandomState(1)
+    origin, dims = grid_of(walls)
+    n_cells = 10 if name == 'large' else 24
+    cells = rng.choice(dims[0]*dims[1], n_cells, replace=False)
+    poses, keep = [], []
+    listed = []
+    for c in cells:
+        vis, _ = scan_cell(walls, origin, dims, c)
+        listed.append(vis.mean())
+        x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
+        for k in range(6):
+            # all over the cell, its very edges included
+            u = rng.uniform(0, 1, 2) if k < 4 else rng.choice([0., 1.], 2)
+            poses.append((x0 + u[0]*CELL, y0 + u[1]*CELL, rng.uniform(-180, 180)))
+            keep.append(vis)
+    for fov in (130., 164.):
+        full, rf = worlds(oracle, walls, poses, fov=fov)
+        part, rp = worlds(oracle, walls, poses, keep, fov=fov)
+        np.testing.assert_array_equal(part, full, err_msg=f'{name}: hit lines differ at fov {fov}')
+        for k in ('distances', 'locations', 'dots'):
+            np.testing.assert_array_equal(rp[k], rf[k], err_msg=f'{name}: {k} differ at fov {fov}')
+    if name.startswith('plan') or name == 'large':
+        assert np.mean(listed) < .6, f'the lists hold {np.mean(listed):.2f} of the walls: nothing is being culled'
+
+
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'box'])
+def test_near_lists_hold_every_wall_within_reach(name):
+    walls = case_walls(name)
+    rng = np.random.RandomState(2)
+    origin, dims = grid_of(walls)
+    a, b = walls[:, 0].astype(np.float64), walls[:, 1].astype(np.float64)
+    for c in rng.choice(dims[0]*dims[1], 40, replace=False):
+        _, close = scan_cell(walls, origin, dims, c)
+        x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
+        for u in np.concatenate([rng.uniform(0, 1, (8, 2)), [[0, 0], [1, 0], [0, 1], [1, 1]]]):
+            p = np.array([x0 + u[0]*CELL, y0 + u[1]*CELL])
+            v = b - a
+            with np.errstate(all='ignore'):
+                t = np.clip(((p - a)*v).sum(1)/(v*v).sum(1), 0, 1)
+            t = np.where(np.isfinite(t), t, 0.)
+            d = np.linalg.norm(a + t[:, None]*v - p, axis=1)
+            must = ~(d > REACH)                                        # NaN walls: the reference stops agents at them
+            assert not (must & ~close).any(), f'{name}: cell {c} misses walls within reach'
+        assert close.sum() < len(walls) or len(walls) < 20
+
+
+def test_one_wall_hides_another_only_when_it_really_does():
+    hidden = lambda cell, o, w, near=NEAR: bool(_lib.lib().ms_host_wall_hidden(
+        *map(float, cell), (C.c_float*4)(*o), (C.c_float*4)(*w), near))
+    cell = (0., 0., .27, .27)
+    wide, target = (2., -3., 2., 3.), (4., -.5, 4., .5)
+    assert hidden(cell, wide, target)
+    assert hidden(cell, wide[2:] + wide[:2], target)                    # either orientation
+    assert not hidden(cell, (2., -3., 2., .2), target)                  # a gap the target shows through
+    assert not hidden(cell, (2., -.1, 2., .1), target)                  # too short to try
+    assert not hidden(cell, target, wide)                               # the other way round
+    assert not hidden(cell, wide, (1., -.5, 1., .5))                    # in front of the occluder
+    assert not hidden(cell, wide, (2.001, -.5, 2.001, .5))              # behind it, but inside the hysteresis margin
+    assert not hidden((1.8, 0., 2.07, .27), wide, target)               # the cell reaches the occluder's near side
+    assert not hidden((1.75, 0., 1.9, .27), wide, target)               # ... or sits inside the near plane
+    assert not hidden(cell, wide, (4., .135, 9., .135))                 # the cell straddles the target's own line
+    nan = float('nan')
+    assert not hidden(cell, (2., nan, 2., 3.), target) and not hidden(cell, wide, (4., nan, 4., .5))
+    assert not hidden(cell, wide, (4., -.5, 4., -.5 + 1e-30))
