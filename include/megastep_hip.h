@@ -126,6 +126,10 @@ typedef struct MsScenery {
     float                 wg_reach;
     float                 wg_near;
     const unsigned short* wg_pool;
+    /* Optional: the largest distance of a point of `model` from the agent's origin, 0 = not known.  When it is below
+     * the near plane (MsConfig.agent_radius, as in the reference: core.py:14, scene.py:25-33), no ray of an agent can
+     * hit the agent's own outline (kernels.cu:369) and ms_render does not try. */
+    float model_radius;
 } MsScenery;
 
 /* Replaces `Agents` (common.h:157-177). Updated IN PLACE by ms_physics. */

@@ -36,7 +36,7 @@ class MsScenery(C.Structure):
         ('lg_max_cells', C.c_int), ('lg_list', C.c_void_p), ('lg_pool', C.c_void_p), ('lg_pool_size', C.c_int),
         ('env_geom', C.c_void_p), ('bake_vis', C.c_void_p), ('bake_vis_starts', C.c_void_p), ('bake_vis_words', C.c_longlong),
         ('wg_cells', C.c_void_p), ('wg_starts', C.c_void_p), ('wg_geom', C.c_void_p), ('wg_cell', C.c_float),
-        ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p)]
+        ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p), ('model_radius', C.c_float)]
 
 
 class MsAgents(C.Structure):

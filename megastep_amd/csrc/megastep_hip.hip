@@ -45,6 +45,45 @@ constexpr int WAVES = WG/WAVE;
 
 thread_local int g_last_hip_error = 0;
 
+// -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
+// time stamps (s_memtime at its start, at a few points where something it waited for has arrived, at its end) and of
+// the SIMD it ran on, for a picture of how a launch fills and drains the chip.  Compiled out of the product library.
+#ifndef MS_PROBE
+#define MS_PROBE 0
+#endif
+#if MS_PROBE
+constexpr int PROBE_STAMPS = 8;        // a record: 8 stamps (low 32 bits of s_memtime), then where the wave ran
+__device__ unsigned* g_probe = nullptr;                // one record per wave, indexed by the wave's number in its launch
+__device__ long long g_probe_cap = 0;
+// (one VGPR: lane k holds stamp k, the low 32 bits of s_memtime - a wave's record costs the kernel one register and no
+// traffic until its end; records are indexed by wave, not drawn from a cursor: thousands of atomics on one address
+// would be the slowest thing in the launch)
+struct Probe {
+    unsigned t = 0u, real0 = (unsigned)wall_clock64();
+    __device__ void done(const int lane, const long long wave) {
+        if (g_probe && wave < g_probe_cap) {
+            unsigned v = t;
+            if (lane == PROBE_STAMPS) v = ((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) | ((unsigned)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) << 16);   // HW_ID, XCC_ID
+            if (lane == PROBE_STAMPS + 1) v = real0;                    // s_memtime counts per XCD; the 100 MHz real-time counter is the chip's
+            if (lane == PROBE_STAMPS + 2) v = (unsigned)wall_clock64();
+            if (lane <= PROBE_STAMPS + 2) g_probe[wave*(PROBE_STAMPS + 3) + lane] = v;
+        }
+    }
+};
+#define PROBE_STAMP(k) { const unsigned c_ = (unsigned)clock64(); asm volatile("v_writelane_b32 %0, %1, " #k : "+v"(probe_.t) : "s"(c_)); }
+#define PROBE_INIT Probe probe_; PROBE_STAMP(0)
+// a stamp once `v` (a float or an int the wave has been waiting for) is in a register
+#define PROBE_AT(i, v) { asm volatile("" :: "v"(v)); PROBE_STAMP(i) }
+#define PROBE_DONE(wave) { PROBE_STAMP(7) probe_.done(lane, (long long)(wave)); }
+// a (wave-uniform) number instead of a time in slot k
+#define PROBE_VAL(k, x) { const unsigned c_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(x)); asm volatile("v_writelane_b32 %0, %1, " #k : "+v"(probe_.t) : "s"(c_)); }
+#else
+#define PROBE_INIT
+#define PROBE_AT(i, v)
+#define PROBE_DONE(tag)
+#define PROBE_VAL(k, x)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Scalar math shared by the kernels (device) and ms_host_sincospi (host).
 // ------------------------------------------------------------------------------------------------
@@ -250,6 +289,7 @@ template <int MOVE, int EXTRA>
 __global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
         const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex) {
+    PROBE_INIT
     extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
     __shared__ float4 s_wall[PHYS_PAIRS];        // walls near ...
     __shared__ int s_tag[PHYS_PAIRS];            // ... this agent
@@ -359,6 +399,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PROBE_AT(1, my_box.x)                                                // agent state has arrived
     // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane
     for (int i = lane; i < A*A; i += WAVE) {
         const int t = i / A, d1 = i - t*A;
@@ -404,11 +445,13 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             ok = inside & (my_reach <= sc.wg_reach);
             first = hdr.z; count = ok ? (int)hdr.w : 0;
         }
+        PROBE_AT(2, count)                                                   // ... the cells' headers
         if (!__ballot(!ok)) {
             swept = false;
             const int incl = wave_scan_add(count);
             const int excl = incl - count;
             const int P = __builtin_amdgcn_readlane(incl, 63);
+            PROBE_VAL(4, P)
             for (int p0 = 0; p0 < P; p0 += WAVE) {
                 const int q = p0 + lane;
                 int t = 0;
@@ -495,6 +538,9 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     }
     if (cnt) flush();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PROBE_VAL(5, swept ? 1 : 0)
+    PROBE_VAL(6, __popcll(__ballot((lane < A) && (bits_f(s_prog[min(lane, A - 1)]) < 1.f))))
+    PROBE_AT(3, s_prog[min(lane, A - 1)])                                // every wall has been met
     // epilogue, kernels.cu:224-227
     float2* pos2w = reinterpret_cast<float2*>(ag.positions);
     float2* vel2w = reinterpret_cast<float2*>(ag.velocity);
@@ -538,6 +584,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             }
         }
     }
+    PROBE_DONE(n)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -863,6 +910,7 @@ struct Divisor { unsigned mul, sh1, sh2; };
 struct RenderConsts {
     float x_clip, c_b;
     Divisor by_f, by_g, by_m;
+    int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
 };
 __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     unsigned s = 0;
@@ -970,6 +1018,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     //   3840 mark   (64 x 4 B)   pair window: which line starts here
     //   4096 screen (192 x 4 B)  RGB staging
     // IMPL 2 lays its block out differently (see there): 6144 B
+    PROBE_INIT
     constexpr int LDS_PER_WAVE = IMPL == 2 ? 6144 : 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
@@ -1054,6 +1103,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         sn = sc_.x; cs = sc_.y;
         pp = reinterpret_cast<const float2*>(ag.positions)[n*A + a];
     }
+    PROBE_AT(1, pp.x)                                                    // the agents' state has arrived
     // --- the wall grid (MsScenery.wg_*, wallgrid_scan_kernel): the cell the agent stands in names the walls that can
     // matter to any ray cast from it; asked for here, as early as the position is known - the draw step and the ray
     // set-up below run while the answer travels.  No grid, or an agent outside it: every static wall (wg_count < 0).
@@ -1154,7 +1204,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             line_setup(c0, lo, len);
             const int incl = wave_scan_add(len);
             const int first = incl - len;                                    // this line's first pair
-            const int P = __builtin_amdgcn_readlane(incl, 63);               // pairs in this chunk
+            const int P = __builtin_amdgcn_readlane(incl, 63);
+            PROBE_VAL(4, P)               // pairs in this chunk
             s_info_w[lane] = (first << 6) | (lo & 63);
             n_pairs_total += P; n_windows += (P + WAVE - 1)/WAVE;
             int carry = -1;
@@ -1479,18 +1530,24 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         // over the chunks in flight: rotating them through registers would make the moves wait for the loads they
         // move.  All loads are unconditional: behind a branch hipcc waits for every load in flight at the first use of
         // any of them, which turns "in flight" into "one at a time".)
+        // (The agent's own model lines are left out when the host has checked that the whole model lies inside the near
+        // plane - MsScenery.model_radius - as the reference's does: a hit on them is never `beyond`, kernels.cu:369, and
+        // seen from their middle they span half the fan - a quarter of all the (line, ray) pairs a wave would test.)
         const bool listed = wg_count >= 0;                                   // (uniform)
         const int n_walls = listed ? wg_count : max(L - AF, 0);
-        const int n_items = AF + n_walls;
+        const int own0 = a*sc.n_model, own = rc.skip_own ? sc.n_model : 0;
+        const int AL = AF - own;                                             // agent lines among the items
+        const int n_items = AL + n_walls;
         const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned short*>(sc.wg_pool + wg_first), 0, listed ? 2*n_walls : 0, 0x00020000);
-        const int lane_entry = 2*(lane - AF);
+        const int lane_entry = 2*(lane - AL);
         auto entry = [&](const int i0) {                                     // list entries of items i0 + lane
             return (int)__builtin_amdgcn_raw_buffer_load_b16(list_rsrc, lane_entry + 2*i0, 0, 0);
         };
         auto line_of = [&](const int i0, const int e) {                      // the env's line behind item i0 + lane
             const int i = i0 + lane;
-            return (listed & (i >= AF)) ? AF + e : i;
+            if (i < AL) return i + (i >= own0 ? own : 0);
+            return AF + (listed ? e : i - AL);
         };
         int l_next[AHEAD], e_next[AHEAD];
         float4 w_next[AHEAD];
@@ -1502,6 +1559,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             w_next[k] = rows.load(l_next[k]*16, 0);
             e_next[k] = entry((k + AHEAD)*WAVE);
         }
+        PROBE_AT(2, n_items)                                                 // ... the cell's header
+        PROBE_AT(3, w_next[0].x)                                             // ... the first chunk of rows
         for (int i0 = 0; i0 < n_items; i0 += AHEAD*WAVE) {
             #pragma unroll
             for (int k = 0; k < AHEAD; k++) {
@@ -1512,7 +1571,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 w_next[k] = rows.load(l_next[k]*16, 0);
                 e_next[k] = entry(ik + 2*AHEAD*WAVE);
                 if (ik >= n_items) continue;                                 // uniform
-                admit(w_now, l_now, ik + lane < n_items, ik < AF, ik == 0);
+                admit(w_now, l_now, ik + lane < n_items, ik < AL, ik == 0);
             }
         }
         if (n_pairs) drain();
@@ -1707,6 +1766,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
 #endif
 
+    PROBE_AT(4, nearest_idx)                                             // the raycast is over
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
     // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
     // asked for here, for every lane, from a row that exists (the env's first for a miss): unconditional loads are
@@ -1772,6 +1832,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
     // env's first line and throws the result away)
+    PROBE_AT(5, tex_w)                                                   // the winner's line and texel row have arrived
     const Filt f = tex_filter(is_hit ? loc : 0.f, tex_w);
     const float bk_l = l_baked[tstart + f.l], bk_r = l_baked[tstart + f.r];
     const float* __restrict__ tl = l_tex_vals + 3*(size_t)(tstart + f.l);
@@ -1806,6 +1867,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
     }
 
+    PROBE_AT(6, tl0)                                                     // ... its texels
     if (is_hit) {
         const float dn = 1 - dt*dt;
         s0 = dn*intensity*(f.lw*tl0 + f.rw*tr0);
@@ -1849,6 +1911,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd/fs;
         }
     }
+    PROBE_DONE(fan)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2785,6 +2848,16 @@ void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, fl
     bake_wall_bins(p2(light_x, light_y), ax, ay, bx, by, *first, *count);
 }
 
+#if MS_PROBE
+// (probe builds only, not part of the ABI) buf: device memory of capacity records of 11 32-bit words (8 stamps, HW_ID |
+// XCC_ID << 16, the real-time counter at the wave's start and end), or NULL to stop recording
+int ms_debug_probe(unsigned* buf, long long capacity) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe), &buf, sizeof buf) != hipSuccess) return hip_fail(hipGetLastError());
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe_cap), &capacity, sizeof capacity) != hipSuccess) return hip_fail(hipGetLastError());
+    return MS_OK;
+}
+#endif
+
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane) {
     const WgCell k{x0, y0, x1, y1};
     const WgTarget t = wg_target(k, make_float4(w[0], w[1], w[2], w[3]));
@@ -2939,6 +3012,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_f = divisor_of((unsigned)(sc->n_agents*G));
     rc.by_g = divisor_of((unsigned)G);
     rc.by_m = divisor_of((unsigned)sc->n_model);
+    rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);

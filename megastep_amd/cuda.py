@@ -200,6 +200,10 @@ class Scenery:
         self._n_agents = int(n_agents)
         self._lights, self._lines, self._textures, self._model = lights, lines, textures, model
         self._baked = Ragged1D(torch.ones_like(textures.vals[:, 0]).contiguous(), textures.widths)
+        # how far the agent's outline reaches from its origin (MsScenery.model_radius): inside the near plane, as the
+        # reference's is, an agent's rays cannot hit its own outline and the renderer does not try
+        radius = float(model.reshape(-1, 2).norm(dim=1).max()) if model.numel() else 0.
+        self._model_radius = radius if radius == radius and radius < float('inf') else 0.
         # Beyond the reference: `geom` (n_envs,) int32 names, for every env, the first env with bit-identical walls
         # and light positions (see MsScenery.env_geom). bake() then does the expensive part once per distinct
         # floorplan, and such envs share one light grid. None: every env stands alone.
@@ -291,7 +295,7 @@ class Scenery:
                 *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4],
                 *(t.data_ptr() if t is not None else None for t in lg[5:7]), lg[6].shape[0] if lg[6] is not None else 0,
                 self._geom.data_ptr() if self._geom is not None else None, None, None, 0,
-                *self._wall_grid_fields())
+                *self._wall_grid_fields(), self._model_radius)
         return self._struct
 
     def _wall_grid_fields(self):

@@ -1,0 +1,98 @@
+"""How a launch of physics_kernel / render_kernel fills and drains the chip: every wave's time stamps from the probe
+build (`make -C megastep_amd/csrc probe`; s_memtime ticks once per shader clock, 2.4 GHz on MI355X), on the benchmark world.
+
+    python tools/probe_waves.py [--envs 4096 --agents 4 --res 64 [--large --unique 64]]
+
+Prints, per kernel: the launch's span, when waves start (the dispatch ramp) and how long they live, how many are
+resident over time, and the mean time between a wave's stamps (what it waited for)."""
+import argparse, ctypes as C, os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+os.environ['MEGASTEP_HIP_LIB'] = f'{root}/megastep_amd/csrc/libmegastep_hip_probe.so'
+import numpy as np, torch, bench                                        # noqa: E402
+from megastep_amd import _lib, cuda, modules                             # noqa: E402
+
+WORDS, STAMPS = 11, 8
+NAMES = {'physics': ['start', 'agent state in', 'cell headers in', 'walls met', '', '', '', 'end'],
+         'render': ['start', 'agent state in', 'cell header in', 'first rows in', 'raycast done', 'winner row + texel row in', 'texels in', 'end']}
+
+
+def analyse(name, rec, tick_ns, kernel_us):
+    rec = rec[rec[:, STAMPS - 1] != 0]                                   # (waves that wrote a record)
+    where = rec[:, STAMPS]
+    xcc = (where >> 16) & 0xf
+    t = rec[:, :STAMPS].astype(np.int64)
+    # s_memtime (the stamps) counts per XCD: sections and lives come from it; the launch's time line from the 100 MHz
+    # real-time counter the waves read at their start and end (32-bit words: differences modulo 2^32)
+    t = ((t - t[:, :1]).astype(np.int32))*tick_ns/1e3
+    r0, r1 = rec[:, STAMPS + 1].astype(np.int64), rec[:, STAMPS + 2].astype(np.int64)
+    base = r0[np.argmin((r0 - r0[0]).astype(np.int32))]
+    start, end = (r0 - base).astype(np.int32)/100., (r1 - base).astype(np.int32)/100.
+    life = t[:, STAMPS - 1]
+    print(f'== {name}: kernel {kernel_us:.1f} us by events; {len(rec)} waves, span {end.max():.1f} us; starts: p50 {np.median(start):.1f} p90 {np.quantile(start, .9):.1f} '
+          f'last {start.max():.1f} us; life: mean {life.mean():.2f} p50 {np.median(life):.2f} p90 {np.quantile(life, .9):.2f} p99 {np.quantile(life, .99):.2f} max {life.max():.2f} us')
+    edges = np.linspace(0, end.max(), 25)[:-1]
+    print(f'   resident waves every {edges[1]:.2f} us:', [(int(((start <= a) & (end > a)).sum())) for a in edges])
+    print(f'   per XCD: last end', [round(float(end[xcc == x].max()), 1) for x in np.unique(xcc)], 'waves', [int((xcc == x).sum()) for x in np.unique(xcc)])
+    used = [i for i in range(STAMPS) if NAMES[name][i]]
+    for a, b in zip(used[:-1], used[1:]):
+        d = t[:, b] - t[:, a]
+        print(f'   {NAMES[name][a]:>26s} -> {NAMES[name][b]:<26s} mean {d.mean():6.2f}  p50 {np.median(d):6.2f}  p90 {np.quantile(d, .9):6.2f} us')
+    simd = xcc*65536 + (where & 0xfff0)                                   # xcc | se, sh, cu, simd (wave slot masked off)
+    per = np.unique(simd, return_counts=True)[1]
+    print(f'   SIMDs used {len(per)}; waves per SIMD: min {per.min()} mean {per.mean():.1f} max {per.max()}')
+    if name == 'physics':                                                  # slots 4..6: pairs dealt, swept instead, agents stopped
+        extra = rec[:, 4:7]
+        order = np.argsort(-life)
+        print('   (pairs, swept, stopped, life) of the 12 slowest waves:', [tuple(int(v) for v in extra[i]) + (round(float(life[i]), 1),) for i in order[:12]])
+        for lo_, hi_ in ((0, 1), (1, 2), (2, 9)):
+            m = (extra[:, 2] >= lo_) & (extra[:, 2] < hi_)
+            if m.any():
+                print(f'   waves with {lo_}..{hi_ - 1} stopped agents: {int(m.sum())}, life mean {life[m].mean():.2f} p99 {np.quantile(life[m], .99):.2f}; pairs mean {extra[m, 0].mean():.1f} max {extra[m, 0].max()}; swept {int(extra[m, 1].sum())}')
+    slowest = np.argsort(-life)[:len(life)//100 + 1]
+    print(f'   the slowest 1 %: starts at {np.median(start[slowest]):.1f} us (median), ' + ', '.join(
+        f'{NAMES[name][a]}->{NAMES[name][b]} {np.mean(t[slowest, b] - t[slowest, a]):.2f}' for a, b in zip(used[:-1], used[1:])))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=4096); ap.add_argument('--agents', type=int, default=4)
+    ap.add_argument('--res', type=int, default=64); ap.add_argument('--large', action='store_true')
+    ap.add_argument('--unique', type=int, default=512); ap.add_argument('--fast-build', action='store_true')
+    ap.add_argument('--tick-ns', type=float, default=1/2.4, help='one s_memtime tick in ns')
+    args = ap.parse_args()
+    h = _lib.lib()
+    h.ms_debug_probe.argtypes = [C.c_void_p, C.c_longlong]
+    core, _ = bench.build_world(args.envs, args.agents, args.res, 130., torch.device('cuda'), seed=1, n_unique=args.unique,
+                                large=args.large, fast=args.fast_build)
+    N, A = core.n_envs, core.n_agents
+    mover = modules.MomentumMovement(core)
+    cap = N*A*((args.res + 63)//64)
+    buf = torch.zeros(cap*WORDS, dtype=torch.int32, device='cuda')
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for i in range(12):
+        actions = torch.randint(0, 7, (N, A), device='cuda')
+        delta = mover._actionset[actions]
+        core.agents.angvelocity[:] = .875*core.agents.angvelocity + delta.angvelocity
+        core.agents.velocity[:] = .875*core.agents.velocity + modules.to_global_frame(core.agents.angles, delta.velocity)
+        for name in ('physics', 'render'):
+            record = i == 11
+            torch.cuda.synchronize()
+            if record:
+                buf.zero_()
+                torch.cuda.synchronize()
+                _lib.check(h.ms_debug_probe(buf.data_ptr(), cap))
+            ev[0].record()
+            (cuda.physics if name == 'physics' else cuda.render)(core.scenery, core.agents)
+            ev[1].record()
+            torch.cuda.synchronize()
+            if record:
+                _lib.check(h.ms_debug_probe(None, 0))
+                n = N if name == 'physics' else cap
+                rec = buf[:n*WORDS].view(n, WORDS).cpu().numpy().view(np.uint32).astype(np.int64)
+                analyse(name, rec, args.tick_ns, 1e3*ev[0].elapsed_time(ev[1]))
+    print('done', flush=True)
+
+
+if __name__ == '__main__':
+    main()
