@@ -113,19 +113,23 @@ typedef struct MsScenery {
      * the grid, or faster than wg_reach allows, meet every line as before.  Filled by ms_wallgrid_scan +
      * ms_wallgrid_fill (below) from the static walls as they are at that moment: the walls must not move afterwards
      * (or the grid must be rebuilt / dropped).  Envs that share their walls (env_geom) share their cells.
-     *   wg_cells  (sum cells, 4) uint32: [first vis entry, vis count, first near entry, near count], entries in wg_pool
+     *   wg_cells  (sum cells + 1, 4) uint32: [first vis entry (in wg_pool), vis count, first near entry (in
+     *             wg_near_rows), near count within wg_reach_lo | near count in all << 16]
      *   wg_starts (N,) first cell of env n;   wg_geom (N, 4) float: grid origin x, y, cells along x, cells along y
      *             (0 cells: this env has no grid);   wg_cell: cell size in metres
-     *   wg_pool   uint16 wall indices; at least 64 entries longer than the lists need (loads are not clamped)
+     *   wg_pool   uint16 wall indices, the vis lists; at least 64 entries longer than the lists need
+     *   wg_near_rows  (., 4) float: the near lists as copies of the walls' rows (ax, ay, bx, by), per cell the walls
+     *             within wg_reach_lo of it first, then those within wg_reach
      *   wg_near   vis lists hold for near planes (MsConfig.agent_radius) below this and fields of view up to
      *             MS_WALLGRID_MAX_FOV degrees; ms_render ignores the grid otherwise */
     const unsigned*       wg_cells;
     const int*            wg_starts;
     const float*          wg_geom;
     float                 wg_cell;
-    float                 wg_reach;
+    float                 wg_reach_lo, wg_reach;
     float                 wg_near;
     const unsigned short* wg_pool;
+    const float*          wg_near_rows;
     /* Optional: the largest distance of a point of `model` from the agent's origin, 0 = not known.  When it is below
      * the near plane (MsConfig.agent_radius, as in the reference: core.py:14, scene.py:25-33), no ray of an agent can
      * hit the agent's own outline (kernels.cu:369) and ms_render does not try. */
@@ -251,28 +255,38 @@ int ms_step_physics(const MsScenery* scenery, const MsAgents* agents, const MsMo
 int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* out,
               const MsConfig* config, void* hip_stream);
 
-/* Builds the wall grid (MsScenery.wg_*) in two launches with a prefix sum by the caller in between.
+/* Builds the wall grid (MsScenery.wg_*): per level of cells two launches with a prefix sum by the caller in between.
  *   ms_wallgrid_scan  for every cell of every env listed in `reps` (the representatives, MsScenery.env_geom; n_reps of
- *                     them) works out which static walls belong on the cell's vis and near lists: one bit per wall
- *                     into `bits` - the row of cell c (grid-local) of env n and list k (0 vis, 1 near) starts at word
- *                     bits_starts[n] + (2 c + k) * ceil(walls(n)/32) - and the two counts into counts[2*(wg_starts[n] + c) + k].
- *                     Reads wg_starts, wg_geom, wg_cell, wg_reach, wg_near of the scenery; `bits` and `counts` must
- *                     start zeroed.  max_cells: the most cells any listed env has; max_walls: the most static walls.
- *   ms_wallgrid_fill  writes the lists: the set bits of each row, in order, to wg_pool from the cell's wg_cells offsets
- *                     (which the caller has filled in from the counts).
+ *                     them) works out which static walls belong on the cell's lists: one bit per wall into `bits` - the
+ *                     row of cell c (grid-local) of env n and kind k (0 vis, 1 near within wg_reach_lo, 2 near beyond that)
+ *                     starts at word bits_starts[n] + (3 c + k) * ceil(walls(n)/32) - and the three counts into
+ *                     counts[3*(wg_starts[n] + c) + k].  Reads wg_starts, wg_geom, wg_cell, wg_reach_lo, wg_reach, wg_near
+ *                     of the scenery; `bits` and `counts` must start zeroed.
+ *                     `parent`: a coarser grid over the same envs, scanned and filled before (same origin, cells a whole
+ *                     multiple of wg_cell in size, near lists as indices): only what is on a parent cell's lists is looked
+ *                     at for the cells inside it - exact (a wall hidden from, or out of reach of, the larger cell is so for
+ *                     every cell within) and an order of magnitude less work on large floorplans.  NULL: every wall.
+ *                     max_groups: with a parent the most parent cells any listed env has, without ceil(most cells / 4).
+ *   ms_wallgrid_fill  writes the lists: the set bits of each row, in order, from the cell's wg_cells offsets (which the
+ *                     caller has filled in from the counts) - vis lists as indices into `pool`, near lists as rows into
+ *                     `near_rows`, or as indices into `pool` as well when near_rows is NULL (a parent level).
  * An env with more than 65535 static walls must have a grid of 0 cells. */
 #define MS_WALLGRID_MAX_FOV 165.f
-int ms_wallgrid_scan(const MsScenery* scenery, const int* reps, int n_reps, int max_cells, int max_walls,
+typedef struct MsWallGridParent {
+    const unsigned* cells; const int* starts; const float* geom; float cell; const unsigned short* pool;
+} MsWallGridParent;
+int ms_wallgrid_scan(const MsScenery* scenery, const MsWallGridParent* parent, const int* reps, int n_reps, int max_groups,
                      const long long* bits_starts, unsigned* bits, unsigned* counts, void* hip_stream);
 int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int max_cells,
-                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, void* hip_stream);
+                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, float* near_rows, void* hip_stream);
 /* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
  * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);
 /* ... and of the scan of one whole cell (c, row-major in a grid of nx x ny cells of size `cell` from (ox, oy)) over
- * n_walls walls (n_walls x 4 floats, HOST memory): vis[t] / close[t] = 1 where wall t goes on the cell's vis / near list. */
+ * n_walls walls (n_walls x 4 floats, HOST memory): vis[t] = 1 where wall t goes on the cell's vis list, close[t] = 2 / 1
+ * where it is within reach_lo / reach of the cell. */
 void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, int nx, int ny, float cell, int c,
-                           float near_plane, float reach, unsigned char* vis, unsigned char* close);
+                           float near_plane, float reach_lo, float reach, unsigned char* vis, unsigned char* close);
 
 /* Scalar helper exported for tests: sin(pi x), cos(pi x) exactly as the kernels evaluate them. */
 void ms_host_sincospi(float x, float* s, float* c);

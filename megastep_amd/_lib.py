@@ -36,7 +36,12 @@ class MsScenery(C.Structure):
         ('lg_max_cells', C.c_int), ('lg_list', C.c_void_p), ('lg_pool', C.c_void_p), ('lg_pool_size', C.c_int),
         ('env_geom', C.c_void_p), ('bake_vis', C.c_void_p), ('bake_vis_starts', C.c_void_p), ('bake_vis_words', C.c_longlong),
         ('wg_cells', C.c_void_p), ('wg_starts', C.c_void_p), ('wg_geom', C.c_void_p), ('wg_cell', C.c_float),
-        ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p), ('model_radius', C.c_float)]
+        ('wg_reach_lo', C.c_float), ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p), ('wg_near_rows', C.c_void_p),
+        ('model_radius', C.c_float)]
+
+
+class MsWallGridParent(C.Structure):
+    _fields_ = [('cells', C.c_void_p), ('starts', C.c_void_p), ('geom', C.c_void_p), ('cell', C.c_float), ('pool', C.c_void_p)]
 
 
 class MsAgents(C.Structure):
@@ -140,14 +145,14 @@ def lib():
         handle.ms_host_bake_point_bin.restype = C.c_int
         handle.ms_host_bake_wall_bins.argtypes = [C.c_float]*6 + [_i32p, _i32p]
         handle.ms_host_bake_wall_bins.restype = None
-        handle.ms_wallgrid_scan.argtypes = [C.POINTER(MsScenery), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_void_p]
+        handle.ms_wallgrid_scan.argtypes = [C.POINTER(MsScenery), C.POINTER(MsWallGridParent), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
         handle.ms_wallgrid_fill.argtypes = [C.POINTER(MsScenery), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p]
+                                            C.c_void_p, C.c_void_p]
         handle.ms_host_wall_hidden.argtypes = [C.c_float]*4 + [_f32p, _f32p, C.c_float]
         handle.ms_host_wall_hidden.restype = C.c_int
         handle.ms_host_wallgrid_cell.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
-                                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+                                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         handle.ms_host_wallgrid_cell.restype = None
         for name in ('ms_bake', 'ms_physics', 'ms_move_physics', 'ms_step_physics', 'ms_render', 'ms_wallgrid_scan', 'ms_wallgrid_fill'):
             getattr(handle, name).restype = C.c_int

@@ -384,11 +384,17 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         const P2 p0 = p2(pp.x, pp.y);
         const P2 v0 = p2(mm.x, mm.y)/fps;
         const float vl = len(v0);
-        float reach = 1.02f*vl + 2.f*(1.001f*agent_radius) + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
-        // A crawling agent sees every wall: project() divides by (|v| + 1e-6), so below |v| ~ 1e-6 the reference's
-        // distances shrink until far-away endpoints pass `d < r` and stop the agent (x = 0).  Rare (a velocity that
-        // has decayed for a hundred steps), so those agents simply meet all the walls.
-        if ((vl > 0.f) & (vl < 1e-3f)) reach = INFINITY;
+        // How far a wall can be and still matter: the crossing and side tests need it within |v| + r of p; an endpoint
+        // test (kernels.cu:147-160) needs d = D |sin| |v|/(|v| + 1e-6) < r and s - backoff = D cos |v|/(|v| + 1e-6)^2 -
+        // sqrt(r^2 - d^2)/|v| below 1/0.99 (beyond that the 0.99 margin clamps x to 1), which bounds the endpoint's
+        // distance D by k^2 (1.0102 |v| + r) + k r with k = 1 + 1e-6/|v|.  At everyday speeds k is 1 and that is the
+        // familiar |v| + 2 r; it is project()'s "+ 1e-6" that lets a CRAWLING agent - a momentum velocity that has decayed
+        // for a hundred steps - be stopped by walls metres away, and k says exactly how many (reach 1.3 m at 6e-7 m a
+        // step, every wall of the map below 1e-8).  2 % and a millimetre are added for the rounding.
+        const float r1 = 1.001f*agent_radius;
+        const float kq = 1.f + 1e-6f/vl;                                   // (|v| = 0: inf, unused)
+        float reach = (vl > 0.f) ? 1.02f*(kq*kq*(1.0102f*vl + r1) + kq*r1) : 2.04f*r1;
+        reach += 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
         s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
         const float4 box = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
         if (t == lane) { my_box = box; my_reach = (reach == reach) ? reach : INFINITY; }
@@ -420,7 +426,9 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         tc = fminf(fmaxf(tc, 0.f), 1.f);
         tc = (tc == tc) ? tc : 0.f;
         const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-        if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t])) {                     // NaNs stay in
+        // (walls shorter than a tenth of a millimetre are met whatever their distance: project()'s "+ 1e-6" on the WALL's
+        // length stretches the side test's reach for them, kernels.cu:91-107,163-168)
+        if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t]) | !(vx*vx + vy*vy >= 1e-8f)) {   // NaNs stay in
             const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
             if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
         }
@@ -443,7 +451,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);   // (NaNs: outside)
             const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[sc.wg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0)];
             ok = inside & (my_reach <= sc.wg_reach);
-            first = hdr.z; count = ok ? (int)hdr.w : 0;
+            first = hdr.z;
+            count = ok ? (int)((my_reach <= sc.wg_reach_lo) ? (hdr.w & 0xffffu) : (hdr.w >> 16)) : 0;
         }
         PROBE_AT(2, count)                                                   // ... the cells' headers
         if (!__ballot(!ok)) {
@@ -458,10 +467,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
                 for (int j = 0; j < A - 1; j++) t += (__builtin_amdgcn_readlane(incl, j) <= q) ? 1 : 0;   // whose list is pair q in?
                 const int k = q - __shfl(excl, t, WAVE);
                 const unsigned at = (unsigned)__shfl((int)first, t, WAVE) + (unsigned)k;
-                if (q < P) {
-                    const int e = sc.wg_pool[at];
-                    meet(rows.row(AF + e), t);
-                }
+                if (q < P) meet(reinterpret_cast<const float4*>(sc.wg_near_rows)[at], t);
             }
         } else {
             #pragma unroll
@@ -511,8 +517,10 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             const unsigned long long live = __ballot(l0 + k*WAVE + lane < L);
             const float x0 = fminf(u.x, u.z), x1 = fmaxf(u.x, u.z), y0 = fminf(u.y, u.w), y1 = fmaxf(u.y, u.w);
             // walls with a NaN or an infinity among their coordinates are kept whatever the boxes say
+            // ... and so are walls too short for the reach argument (see meet())
             const unsigned long long odd = __ballot(!(fabsf(u.x) < INFINITY)) | __ballot(!(fabsf(u.y) < INFINITY))
-                                         | __ballot(!(fabsf(u.z) < INFINITY)) | __ballot(!(fabsf(u.w) < INFINITY));
+                                         | __ballot(!(fabsf(u.z) < INFINITY)) | __ballot(!(fabsf(u.w) < INFINITY))
+                                         | __ballot(!((u.z - u.x)*(u.z - u.x) + (u.w - u.y)*(u.w - u.y) >= 1e-8f));
             if (few & !odd) {
                 unsigned long long in[PHYS_FEW], any = 0ull;            // all the verdicts first, one branch for the lot
                 #pragma unroll
@@ -2633,7 +2641,8 @@ __global__ __launch_bounds__(WG) void lightlist_kernel(const MsScenery sc) {
 // and hide nothing.
 //
 // near: the walls that come within wg_reach of the cell (of its centre, + half a diagonal): all that an agent in the
-// cell whose step reaches no farther can touch (physics_kernel's reach cull decides wall by wall from there).
+// cell whose step reaches no farther can touch (physics_kernel's reach cull decides wall by wall from there) - those
+// within wg_reach_lo first, which is as far as an agent at an everyday speed needs to look.
 constexpr float WG_SLACK = 0.01f;          // cells are grown by this on every side: a position's rounding cannot leave them
 constexpr float WG_MIN_OCCLUDER = 0.3f;
 constexpr float WG_BAND = 4e-3f;
@@ -2732,72 +2741,153 @@ __host__ __device__ inline bool wg_close(const WgCell& k, const float4 w, const 
     tc = (tc == tc) ? tc : 0.f;
     const float qx = pqx + tc*vx, qy = pqy + tc*vy;
     const float rr = reach + .7072f*(k.x1 - k.x0) + 1e-3f + 1e-4f*(fabsf(cx) + fabsf(cy));
-    return !(0.9998f*(qx*qx + qy*qy) > rr*rr);
+    return !(0.9998f*(qx*qx + qy*qy) > rr*rr) | !(vx*vx + vy*vy >= 1e-8f);   // (walls too short for the reach argument: physics_kernel's meet())
 }
 
-// One wavefront per (representative env, cell, 64 walls): lane = target wall, the env's walls as occluders one after
-// the other (a uniform address: they arrive through the scalar cache).
-__global__ __launch_bounds__(WG) void wallgrid_scan_kernel(const MsScenery sc, const int* __restrict__ reps, const int max_chunks,
+// The scan, one workgroup per GROUP of cells that share their candidates:
+//   * with a parent grid (coarser cells, scanned before): the cells inside one parent cell.  A wall hidden from the
+//     parent cell is hidden from every cell inside it - by the same occluder - so only the parent's vis list needs looking
+//     at, as targets and as occluders (an occluder that is itself hidden from the parent cell has one in front of it that
+//     hides whatever it hides: one is always on the list); and a wall within reach of a cell is within reach of its
+//     parent (whose half diagonal covers the distance between the centres).  Two levels cut the work of a 1000-wall
+//     floorplan by an order of magnitude.
+//   * without one: WG_GROUP consecutive cells, every wall a candidate.
+// The group's occluders (candidates long enough to be tried, WG_STAGE at most - beyond that the rest are not tried, which
+// only lengthens lists) are staged in LDS once; then lane = candidate wall, one (cell, 64 candidates) item per wave at a
+// time, results OR-ed into the cells' bitmaps (one bit per wall; rows: vis, near within wg_reach_lo, near beyond that)
+// and counted once the group is through.
+constexpr int WG_GROUP = 4, WG_STAGE = 2048, WG_ROWS = 3;
+
+struct WgParent { const unsigned* cells; const int* starts; const float* geom; float cell; const unsigned short* pool; };
+
+__global__ __launch_bounds__(WG) void wallgrid_scan_kernel(const MsScenery sc, const WgParent parent, const int* __restrict__ reps,
                                                           const long long* __restrict__ bits_starts, unsigned* __restrict__ bits,
                                                           unsigned* __restrict__ counts) {
-    const int lane = threadIdx.x & 63;
+    __shared__ float4 s_occ[WG_STAGE];
+    __shared__ unsigned short s_occ_id[WG_STAGE];
+    __shared__ int s_n_occ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = reps[blockIdx.y];
-    const long long item = (long long)blockIdx.x*WAVES + (threadIdx.x >> 6);
-    const int c = (int)(item / max_chunks), chunk = (int)(item - (long long)c*max_chunks);
     const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
-    const int ncell = (int)geom.z*(int)geom.w;
+    const int ncx = (int)geom.z, ncy = (int)geom.w, ncell = ncx*ncy;
     const int AF = sc.n_agents*sc.n_model;
     const int n_walls = max(sc.lines_widths[n] - AF, 0);
-    if (c >= ncell || chunk*WAVE >= n_walls) return;                     // (whole waves)
+    if (ncell == 0 || n_walls == 0) return;
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n] + AF;
-    const WgCell k = wg_cell_of(geom, sc.wg_cell, c);
-    const int t_ = chunk*WAVE + lane;
-    const bool live = t_ < n_walls;
-    const float4 w = ln[min(t_, n_walls - 1)];
-    const WgTarget tg = wg_target(k, w);
-    bool hidden = !live;
-    for (int o = 0; o < n_walls; o++) {
-        if (__all(hidden)) break;
-        const float4 ow = ln[o];                                         // uniform
-        if ((o != t_) && wg_hides(k, tg, ow, sc.wg_near)) hidden = true;
+    // the group's cells (a rectangle of gw x gh cells from (gx0, gy0), or a run of the row-major order) and candidates
+    int gx0 = 0, gy0 = 0, gw = 0, n_group = 0, first_cell = 0;
+    const unsigned short* cand_vis = nullptr;                            // NULL: every wall
+    const unsigned short* cand_near = nullptr;
+    int n_vis = n_walls, n_near = n_walls;
+    if (parent.cells) {
+        const float4 pgeom = reinterpret_cast<const float4*>(parent.geom)[n];
+        const int pcx = (int)pgeom.z, P = blockIdx.x;
+        if (P >= pcx*(int)pgeom.w) return;
+        const int ratio = (int)rintf(parent.cell/sc.wg_cell);
+        gx0 = (P % pcx)*ratio; gy0 = (P/pcx)*ratio;
+        gw = min(ratio, ncx - gx0);
+        const int gh = min(ratio, ncy - gy0);
+        if (gw <= 0 || gh <= 0) return;
+        n_group = gw*gh;
+        const uint4 hdr = reinterpret_cast<const uint4*>(parent.cells)[(size_t)parent.starts[n] + P];
+        cand_vis = parent.pool + hdr.x; n_vis = (int)hdr.y;
+        cand_near = parent.pool + hdr.z; n_near = (int)(hdr.w >> 16);
+    } else {
+        first_cell = blockIdx.x*WG_GROUP;
+        if (first_cell >= ncell) return;
+        n_group = min(WG_GROUP, ncell - first_cell);
     }
-    const bool close = live & wg_close(k, w, sc.wg_reach);
-    const unsigned long long vm = __ballot(live & !hidden), nm = __ballot(close);
-    if (lane == 0) {
-        const int W32 = (n_walls + 31) >> 5;
-        unsigned* row = bits + bits_starts[n] + (long long)(2*c)*W32 + 2*chunk;
-        row[0] = (unsigned)vm;
-        if (2*chunk + 1 < W32) row[1] = (unsigned)(vm >> 32);
-        row[W32] = (unsigned)nm;
-        if (2*chunk + 1 < W32) row[W32 + 1] = (unsigned)(nm >> 32);
-        const size_t cell_id = (size_t)sc.wg_starts[n] + c;
-        atomicAdd(&counts[2*cell_id], (unsigned)__popcll(vm));
-        atomicAdd(&counts[2*cell_id + 1], (unsigned)__popcll(nm));
+    auto cell_of = [&](const int j) { return parent.cells ? (gy0 + j/gw)*ncx + gx0 + j % gw : first_cell + j; };
+    // stage the occluders: candidates of WG_MIN_OCCLUDER and more (in no particular order)
+    if (tid == 0) s_n_occ = 0;
+    __syncthreads();
+    for (int i = tid; i < n_vis; i += WG) {
+        const int id = cand_vis ? (int)cand_vis[i] : i;
+        const float4 w = ln[id];
+        const float vx = w.z - w.x, vy = w.w - w.y;
+        if (vx*vx + vy*vy >= WG_MIN_OCCLUDER*WG_MIN_OCCLUDER) {
+            const int at = atomicAdd(&s_n_occ, 1);
+            if (at < WG_STAGE) { s_occ[at] = w; s_occ_id[at] = (unsigned short)id; }
+        }
+    }
+    __syncthreads();
+    const int n_occ = min(s_n_occ, WG_STAGE);
+    const int W32 = (n_walls + 31) >> 5;
+    unsigned* __restrict__ rows = bits + bits_starts[n];
+    // vis: lane = candidate, every staged occluder in turn (uniform LDS reads)
+    const int vis_chunks = (n_vis + WAVE - 1)/WAVE;
+    for (int item = wave; item < n_group*vis_chunks; item += WAVES) {
+        const int j = item/vis_chunks, i = (item - j*vis_chunks)*WAVE + lane;
+        const int c = cell_of(j);
+        const bool live = i < n_vis;
+        const int id = cand_vis ? (int)cand_vis[min(i, n_vis - 1)] : min(i, n_vis - 1);
+        const WgCell k = wg_cell_of(geom, sc.wg_cell, c);
+        const WgTarget tg = wg_target(k, ln[id]);
+        bool hidden = !live;
+        for (int o = 0; o < n_occ; o++) {
+            if (__all(hidden)) break;
+            if (((int)s_occ_id[o] != id) && wg_hides(k, tg, s_occ[o], sc.wg_near)) hidden = true;
+        }
+        if (!hidden) atomicOr(&rows[(long long)(WG_ROWS*c)*W32 + (id >> 5)], 1u << (id & 31));
+    }
+    // near: lane = candidate
+    const int near_chunks = (n_near + WAVE - 1)/WAVE;
+    for (int item = wave; item < n_group*near_chunks; item += WAVES) {
+        const int j = item/near_chunks, i = (item - j*near_chunks)*WAVE + lane;
+        const int c = cell_of(j);
+        if (i < n_near) {
+            const int id = cand_near ? (int)cand_near[i] : i;
+            const WgCell k = wg_cell_of(geom, sc.wg_cell, c);
+            const float4 w = ln[id];
+            if (wg_close(k, w, sc.wg_reach)) {
+                const int row = wg_close(k, w, sc.wg_reach_lo) ? 1 : 2;
+                atomicOr(&rows[(long long)(WG_ROWS*c + row)*W32 + (id >> 5)], 1u << (id & 31));
+            }
+        }
+    }
+    // count the group's bitmaps (atomics read what the group's other waves left in the L2)
+    __syncthreads();
+    for (int i = tid; i < n_group*WG_ROWS*W32; i += WG) {
+        const int j = i/(WG_ROWS*W32), r = (i - j*WG_ROWS*W32)/W32, wd = i - (j*WG_ROWS + r)*W32;
+        const int c = cell_of(j);
+        const unsigned m = atomicOr(&rows[(long long)(WG_ROWS*c + r)*W32 + wd], 0u);
+        if (m) atomicAdd(&counts[WG_ROWS*((size_t)sc.wg_starts[n] + c) + r], (unsigned)__popc(m));
     }
 }
 
-// One wavefront per (representative env, cell, list): the set bits of the row, in order, into the pool.
+// One wavefront per (representative env, cell, list): the set bits of the cell's rows, in order, into the pools - the vis
+// list as wall indices; the near list (the walls within wg_reach_lo first, then the others) as the walls' rows themselves
+// (physics_kernel wants nothing else of them, and saves a round trip), or as indices too when near_rows is NULL (a parent
+// level for the next scan).
 __global__ __launch_bounds__(WG) void wallgrid_fill_kernel(const MsScenery sc, const int* __restrict__ reps,
                                                           const long long* __restrict__ bits_starts, const unsigned* __restrict__ bits,
-                                                          unsigned short* __restrict__ pool) {
+                                                          unsigned short* __restrict__ pool, float4* __restrict__ near_rows) {
     const int lane = threadIdx.x & 63;
     const int n = reps[blockIdx.y];
     const long long item = (long long)blockIdx.x*WAVES + (threadIdx.x >> 6);
     const int c = (int)(item >> 1), kind = (int)(item & 1);
     const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
     if (c >= (int)geom.z*(int)geom.w) return;
-    const int n_walls = max(sc.lines_widths[n] - sc.n_agents*sc.n_model, 0);
+    const int AF = sc.n_agents*sc.n_model;
+    const int n_walls = max(sc.lines_widths[n] - AF, 0);
+    const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n] + AF;
     const int W32 = (n_walls + 31) >> 5;
-    const unsigned* __restrict__ row = bits + bits_starts[n] + (long long)(2*c + kind)*W32;
     const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[(size_t)sc.wg_starts[n] + c];
     unsigned at = kind ? hdr.z : hdr.x;
-    for (int w0 = 0; w0 < W32; w0 += WAVE) {                             // lane = word
-        const unsigned m = (w0 + lane < W32) ? row[w0 + lane] : 0u;
-        const int cnt = __popc(m);
-        const int incl = wave_scan_add(cnt);
-        unsigned o = at + (unsigned)(incl - cnt);
-        for (unsigned r = m; r; r &= r - 1) pool[o++] = (unsigned short)(32*(w0 + lane) + __ffs((int)r) - 1);
-        at += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+    for (int r = kind; r < (kind ? WG_ROWS : 1); r++) {
+        const unsigned* __restrict__ row = bits + bits_starts[n] + (long long)(WG_ROWS*c + r)*W32;
+        for (int w0 = 0; w0 < W32; w0 += WAVE) {                         // lane = word
+            const unsigned m = (w0 + lane < W32) ? row[w0 + lane] : 0u;
+            const int cnt = __popc(m);
+            const int incl = wave_scan_add(cnt);
+            unsigned o = at + (unsigned)(incl - cnt);
+            for (unsigned rest = m; rest; rest &= rest - 1) {
+                const int id = 32*(w0 + lane) + __ffs((int)rest) - 1;
+                if (kind && near_rows) near_rows[o++] = ln[id];
+                else pool[o++] = (unsigned short)id;
+            }
+            at += (unsigned)__builtin_amdgcn_readlane(incl, 63);
+        }
     }
 }
 
@@ -2865,7 +2955,7 @@ int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, 
 }
 
 void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, int nx, int ny, float cell, int c,
-                           float near_plane, float reach, unsigned char* vis, unsigned char* close) {
+                           float near_plane, float reach_lo, float reach, unsigned char* vis, unsigned char* close) {
     const float4* ln = reinterpret_cast<const float4*>(walls);
     const WgCell k = wg_cell_of(make_float4(ox, oy, (float)nx, (float)ny), cell, c);
     for (int t = 0; t < n_walls; t++) {
@@ -2873,37 +2963,41 @@ void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, 
         bool hidden = false;
         for (int o = 0; o < n_walls && !hidden; o++) hidden = (o != t) && wg_hides(k, tg, ln[o], near_plane);
         vis[t] = hidden ? 0 : 1;
-        close[t] = wg_close(k, ln[t], reach) ? 1 : 0;
+        close[t] = wg_close(k, ln[t], reach) ? (wg_close(k, ln[t], reach_lo) ? 2 : 1) : 0;
     }
 }
 
 static bool wallgrid_ok(const MsScenery* sc) {
-    return sc->wg_starts && sc->wg_geom && sc->wg_cell > 0.f && sc->wg_reach >= 0.f && sc->wg_near > 0.f && ((uintptr_t)sc->wg_geom % 16 == 0);
+    return sc->wg_starts && sc->wg_geom && sc->wg_cell > 0.f && sc->wg_reach_lo >= 0.f && sc->wg_reach >= sc->wg_reach_lo &&
+           sc->wg_near > 0.f && ((uintptr_t)sc->wg_geom % 16 == 0);
 }
 
-int ms_wallgrid_scan(const MsScenery* sc, const int* reps, int n_reps, int max_cells, int max_walls,
+int ms_wallgrid_scan(const MsScenery* sc, const MsWallGridParent* parent, const int* reps, int n_reps, int max_groups,
                      const long long* bits_starts, unsigned* bits, unsigned* counts, void* stream) {
-    if (!scenery_ok(sc) || !wallgrid_ok(sc) || !reps || n_reps < 0 || max_cells < 0 || max_walls < 0 || max_walls > 65535 ||
-        !bits_starts || !bits || !counts) return MS_EINVAL;
-    if (n_reps == 0 || max_cells == 0 || max_walls == 0) return MS_OK;
-    const int max_chunks = (max_walls + WAVE - 1)/WAVE;
-    const long long blocks = ((long long)max_cells*max_chunks + WAVES - 1)/WAVES;
-    if (blocks > 0x7fffffffLL || n_reps > 65535) return MS_EUNSUPPORTED;
-    hipLaunchKernelGGL(wallgrid_scan_kernel, dim3((unsigned)blocks, (unsigned)n_reps), dim3(WG), 0, (hipStream_t)stream,
-                       *sc, reps, max_chunks, bits_starts, bits, counts);
+    if (!scenery_ok(sc) || !wallgrid_ok(sc) || !reps || n_reps < 0 || max_groups < 0 || !bits_starts || !bits || !counts) return MS_EINVAL;
+    WgParent par{nullptr, nullptr, nullptr, 0.f, nullptr};
+    if (parent) {
+        if (!parent->cells || !parent->starts || !parent->geom || !parent->pool || !(parent->cell >= sc->wg_cell) ||
+            ((uintptr_t)parent->cells % 16) || ((uintptr_t)parent->geom % 16)) return MS_EINVAL;
+        par = WgParent{parent->cells, parent->starts, parent->geom, parent->cell, parent->pool};
+    }
+    if (n_reps == 0 || max_groups == 0) return MS_OK;
+    if (n_reps > 65535) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(wallgrid_scan_kernel, dim3((unsigned)max_groups, (unsigned)n_reps), dim3(WG), 0, (hipStream_t)stream,
+                       *sc, par, reps, bits_starts, bits, counts);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
 
 int ms_wallgrid_fill(const MsScenery* sc, const int* reps, int n_reps, int max_cells,
-                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, void* stream) {
+                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, float* near_rows, void* stream) {
     if (!scenery_ok(sc) || !wallgrid_ok(sc) || !sc->wg_cells || ((uintptr_t)sc->wg_cells % 16) || !reps || n_reps < 0 || max_cells < 0 ||
-        !bits_starts || !bits || !pool) return MS_EINVAL;
+        !bits_starts || !bits || !pool || ((uintptr_t)near_rows % 16)) return MS_EINVAL;
     if (n_reps == 0 || max_cells == 0) return MS_OK;
     const long long blocks = (2LL*max_cells + WAVES - 1)/WAVES;
     if (blocks > 0x7fffffffLL || n_reps > 65535) return MS_EUNSUPPORTED;
     hipLaunchKernelGGL(wallgrid_fill_kernel, dim3((unsigned)blocks, (unsigned)n_reps), dim3(WG), 0, (hipStream_t)stream,
-                       *sc, reps, bits_starts, bits, pool);
+                       *sc, reps, bits_starts, bits, pool, reinterpret_cast<float4*>(near_rows));
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
@@ -2912,8 +3006,8 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
                     const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
     if (mv && (!mv->actions || !mv->table || mv->n_actions < 1 || !(mv->keep == mv->keep))) return MS_EINVAL;
-    if (sc->wg_cells && (!sc->wg_starts || !sc->wg_geom || !sc->wg_pool || !(sc->wg_cell > 0.f) || ((uintptr_t)sc->wg_cells % 16) ||
-                         ((uintptr_t)sc->wg_geom % 16))) return MS_EINVAL;
+    if (sc->wg_cells && (!sc->wg_starts || !sc->wg_geom || !sc->wg_near_rows || !(sc->wg_cell > 0.f) || ((uintptr_t)sc->wg_cells % 16) ||
+                         ((uintptr_t)sc->wg_geom % 16) || ((uintptr_t)sc->wg_near_rows % 16))) return MS_EINVAL;
     if (ex) {
         if (ex->spawn_positions && (!ex->spawn_angles || !ex->respawn_mask || !ex->respawn_choice || ex->n_spawns < 1 ||
                                     ((uintptr_t)ex->spawn_positions % 8))) return MS_EINVAL;

@@ -301,106 +301,142 @@ class Scenery:
     def _wall_grid_fields(self):
         wg = self._wg
         if wg is None:
-            return (None, None, None, 0., 0., 0., None)
-        cells, starts, geom, cell, reach, near, pool = wg
-        return (cells.data_ptr(), starts.data_ptr(), geom.data_ptr(), cell, reach, near, pool.data_ptr())
+            return (None, None, None, 0., 0., 0., 0., None, None)
+        cells, starts, geom, cell, reach_lo, reach, near, pool, rows = wg
+        return (cells.data_ptr(), starts.data_ptr(), geom.data_ptr(), cell, reach_lo, reach, near, pool.data_ptr(), rows.data_ptr())
 
-    #: the wall grid (include/megastep_hip.h, MsScenery.wg_*): cell size in metres, the step length its collision lists
-    #: cover (both movement modules' defaults stay below it at 10 fps), the near plane its visibility lists allow for,
-    #: and how much memory it may take - beyond that the cells are doubled in size, twice at most, then it is left out
+    #: the wall grid (include/megastep_hip.h, MsScenery.wg_*): cell size in metres; the step lengths its collision lists
+    #: cover (0.7 m: the momentum module at its defaults never reaches farther; 1.3 m: nor does the simple one at 10 fps);
+    #: the near plane its visibility lists allow for; how much memory it may take - beyond that the cells are doubled in
+    #: size, twice at most, then it is left out
     WALL_GRID = os.environ.get('MEGASTEP_WALL_GRID', '1') != '0'       # (the environment switch is for A/B runs)
     WALL_GRID_CELL = .25
-    WALL_GRID_REACH = 1.3
+    WALL_GRID_REACH = (.7, 1.3)
     WALL_GRID_NEAR = .12
     WALL_GRID_BYTES = 8 << 30
     WALL_GRID_MAX_CELLS = 1 << 18       # per floorplan
     WALL_GRID_SCRATCH = 1 << 30         # bytes of bitmaps in flight while it is built
+    WALL_GRID_COARSE = 4                # the parent level's cells, in cells (None: one level, every wall a candidate)
 
-    def _build_wall_grid(self):
-        """Builds the wall grid from the static walls as they are now (called by :func:`bake`): per floorplan a uniform
-        grid, per cell the walls a ray from the cell can be decided by and the walls an agent in it can run into.
-        Two launches per group of floorplans with a prefix sum in between; returns nothing, installs ``_wg``."""
-        self._wg, self._struct = None, None
-        if not self.WALL_GRID:
-            return
+    def _scan_level(self, cell, parent, final, usable):
+        """One level of the wall grid: cells of size `cell` over every representative floorplan, scanned (against the
+        parent level's lists, if there is one) and filled. Returns (hdr (cells + 1, 4) int32 holding uint32s, starts, geom,
+        pool int16, near rows float32 or None, bytes) - or None where there is nothing to build / the budget is exceeded."""
         dev = self._device()
         ln = self._lines
         n_envs = len(ln)
         af = self._n_agents*self._model.shape[0]
         walls = (ln.widths.long() - af).clamp(min=0)
-        if n_envs == 0 or int(walls.max()) == 0:
-            return
         arange = torch.arange(n_envs, device=dev)
         rep = arange if self._geom is None else self._geom.long()
         is_rep = rep == arange
         lo, hi = self._wall_bounds()
         h = _lib.lib()
+        origin = torch.floor(lo) - .5
+        dims = torch.ceil((hi + .5 - origin)/self.WALL_GRID_CELL).clamp(min=1)      # in the finest cells ...
+        scale = round(cell/self.WALL_GRID_CELL)
+        dims = torch.ceil(dims/scale)                                               # ... so that every level covers the same ground
+        cells = (dims[:, 0]*dims[:, 1])
+        dims = torch.where(usable[:, None], dims, torch.zeros_like(dims))           # (the same envs at every level)
+        cells = torch.where(usable, cells, torch.zeros_like(cells)).long()
+        own = cells*is_rep                                             # members own no cells
+        starts = (own.cumsum(0) - own)[rep].to(torch.int32).contiguous()
+        geom = torch.cat([origin, dims], 1).float()[rep].contiguous()
+        total = int(own.sum())
+        if total == 0:
+            return None
+        w32 = (walls + 31)//32
+        row_words = 3*own*w32                                          # bitmap words per representative
+        reps = torch.nonzero(own > 0).flatten()
+        struct = _lib.MsScenery.from_buffer_copy(self._as_struct())
+        struct.wg_starts, struct.wg_geom, struct.wg_cell = starts.data_ptr(), geom.data_ptr(), cell
+        struct.wg_reach_lo, struct.wg_reach, struct.wg_near = *self.WALL_GRID_REACH, self.WALL_GRID_NEAR
+        par = None
+        if parent is not None:
+            par = _lib.MsWallGridParent(parent[0].data_ptr(), parent[1].data_ptr(), parent[2].data_ptr(), parent[3], parent[4].data_ptr())
+        counts = torch.zeros((total, 3), dtype=torch.int32, device=dev)
+        # groups of representatives whose bitmaps fit the scratch budget (and a launch's grid)
+        words = row_words[reps]
+        group = torch.maximum((words.cumsum(0) - words)*4//self.WALL_GRID_SCRATCH, torch.arange(len(reps), device=dev)//60000)
+        bounds = [0] + (torch.nonzero(group[1:] != group[:-1]).flatten() + 1).tolist() + [len(reps)]
+        pools, nears = [], []
+        cell_rows = torch.zeros((total + 1, 4), dtype=torch.int64, device=dev)     # (+ the row agents outside the last grid read)
+        base_p = base_n = 0
+        with _on(dev):
+            for g0, g1 in zip(bounds[:-1], bounds[1:]):
+                r = reps[g0:g1]
+                r32 = r.to(torch.int32).contiguous()
+                gw = row_words[r]
+                bits_starts = torch.zeros(n_envs, dtype=torch.int64, device=dev)
+                bits_starts[r] = gw.cumsum(0) - gw
+                bits = torch.zeros(max(int(gw.sum()), 1), dtype=torch.int32, device=dev)
+                mc = int(cells[r].max())
+                groups = int(parent[5][r].max()) if parent is not None else (mc + 3)//4
+                _lib.check(h.ms_wallgrid_scan(C.byref(struct), C.byref(par) if par is not None else None, r32.data_ptr(), len(r), groups,
+                                              bits_starts.data_ptr(), bits.data_ptr(), counts.data_ptr(), _stream(dev)))
+                # the cells of this group, in storage order, and their lists' places in the pools
+                span = own[r]
+                rows = torch.repeat_interleave(starts[r].long() - (span.cumsum(0) - span), span) + torch.arange(int(span.sum()), device=dev)
+                cnt = counts[rows].long()                              # (cells, 3): vis, near within the short reach, near beyond
+                n_vis, n_near = cnt[:, 0], cnt[:, 1] + cnt[:, 2]
+                if final:                                              # vis -> pool (indices), near -> rows
+                    off_v, off_n = n_vis.cumsum(0) - n_vis + base_p, n_near.cumsum(0) - n_near + base_n
+                    add_p, add_n = int(n_vis.sum()), int(n_near.sum())
+                else:                                                  # both lists as indices, back to back
+                    both = torch.stack([n_vis, n_near], 1).flatten()
+                    off = (both.cumsum(0) - both + base_p).view(-1, 2)
+                    off_v, off_n = off[:, 0], off[:, 1]
+                    add_p, add_n = int(both.sum()), 0
+                if 2*(base_p + add_p) + 16*(base_n + add_n) > self.WALL_GRID_BYTES or base_p + add_p >= 2**32 - 64 or base_n + add_n >= 2**32 \
+                        or int(n_near.max()) > 65535:
+                    return None
+                cell_rows[rows] = torch.stack([off_v, n_vis, off_n, cnt[:, 1] + (n_near << 16)], 1)
+                hdr = _as_u32(cell_rows)
+                pool = torch.zeros(add_p + 64, dtype=torch.int16, device=dev)
+                near = torch.zeros((max(add_n, 1), 4), dtype=torch.float32, device=dev) if final else None
+                struct.wg_cells = hdr.data_ptr()
+                # the fill kernel writes at the headers' offsets: hand it this group's pools displaced by what came before
+                _lib.check(h.ms_wallgrid_fill(C.byref(struct), r32.data_ptr(), len(r), mc, bits_starts.data_ptr(), bits.data_ptr(),
+                                              C.c_void_p(pool.data_ptr() - 2*base_p),
+                                              C.c_void_p(near.data_ptr() - 16*base_n) if final else None, _stream(dev)))
+                torch.cuda.current_stream(dev).synchronize()           # (hdr / bits / pools of this group are done with)
+                pools.append(pool[:add_p])
+                if final:
+                    nears.append(near[:add_n])
+                base_p, base_n = base_p + add_p, base_n + add_n
+        pool = torch.cat(pools + [torch.zeros(64, dtype=torch.int16, device=dev)])
+        near = torch.cat(nears + [torch.zeros((1, 4), dtype=torch.float32, device=dev)]) if final else None
+        return _as_u32(cell_rows), starts, geom, pool, near, cells.to(torch.int32)
+
+    def _build_wall_grid(self):
+        """Builds the wall grid from the static walls as they are now (called by :func:`bake`): per floorplan a uniform
+        grid, per cell the walls a ray from the cell can be decided by and the walls an agent in it can run into - first
+        for cells WALL_GRID_COARSE times the size, whose lists are all that the cells proper then look at. Installs ``_wg``."""
+        self._wg, self._struct = None, None
+        if not self.WALL_GRID:
+            return
+        ln = self._lines
+        if len(ln) == 0 or int((ln.widths.long() - self._n_agents*self._model.shape[0]).max()) <= 0:
+            return
+        lo, hi = self._wall_bounds()
+        walls = (ln.widths.long() - self._n_agents*self._model.shape[0]).clamp(min=0)
         for cell in (self.WALL_GRID_CELL, 2*self.WALL_GRID_CELL, 4*self.WALL_GRID_CELL):
-            origin = torch.floor(lo) - .5
-            dims = torch.ceil((hi + .5 - origin)/cell).clamp(min=1)
-            cells = (dims[:, 0]*dims[:, 1])
-            ok = (cells <= self.WALL_GRID_MAX_CELLS) & (walls > 0) & (walls <= 65535)
-            dims = torch.where(ok[:, None], dims, torch.zeros_like(dims))
-            cells = torch.where(ok, cells, torch.zeros_like(cells)).long()
-            own = cells*is_rep                                             # members own no cells
-            starts = (own.cumsum(0) - own)[rep].to(torch.int32).contiguous()
-            geom = torch.cat([origin, dims], 1).float()[rep].contiguous()
-            total = int(own.sum())
-            if total == 0:
-                return
-            w32 = (walls + 31)//32
-            row_words = 2*own*w32                                          # bitmap words per representative
-            reps = torch.nonzero(own > 0).flatten()
-            struct = _lib.MsScenery.from_buffer_copy(self._as_struct())
-            struct.wg_starts, struct.wg_geom = starts.data_ptr(), geom.data_ptr()
-            struct.wg_cell, struct.wg_reach, struct.wg_near = cell, self.WALL_GRID_REACH, self.WALL_GRID_NEAR
-            counts = torch.zeros((total, 2), dtype=torch.int32, device=dev)
-            # groups of representatives whose bitmaps fit the scratch budget (and a launch's grid)
-            words = row_words[reps]
-            group = ((words.cumsum(0) - words)*4//self.WALL_GRID_SCRATCH)
-            group = torch.maximum(group, torch.arange(len(reps), device=dev)//60000)
-            bounds = [0] + (torch.nonzero(group[1:] != group[:-1]).flatten() + 1).tolist() + [len(reps)]
-            pools, cell_rows, base, fits = [], torch.zeros((total, 4), dtype=torch.int64, device=dev), 0, True
-            with _on(dev):
-                for g0, g1 in zip(bounds[:-1], bounds[1:]):
-                    r = reps[g0:g1]
-                    r32 = r.to(torch.int32).contiguous()
-                    gw = row_words[r]
-                    bits_starts = torch.zeros(n_envs, dtype=torch.int64, device=dev)
-                    bits_starts[r] = gw.cumsum(0) - gw
-                    bits = torch.zeros(max(int(gw.sum()), 1), dtype=torch.int32, device=dev)
-                    mc, mw = int(cells[r].max()), int(walls[r].max())
-                    _lib.check(h.ms_wallgrid_scan(C.byref(struct), r32.data_ptr(), len(r), mc, mw, bits_starts.data_ptr(),
-                                                  bits.data_ptr(), counts.data_ptr(), _stream(dev)))
-                    # the cells of this group, in storage order, and their lists' places in the group's pool
-                    first = starts[r].long()
-                    span = own[r]
-                    rows = torch.repeat_interleave(first - (span.cumsum(0) - span), span) + torch.arange(int(span.sum()), device=dev)
-                    cnt = counts[rows].long()                              # (cells, 2)
-                    flat = cnt.flatten()
-                    off = flat.cumsum(0) - flat
-                    n_entries = int(flat.sum())
-                    if 2*(base + n_entries) > self.WALL_GRID_BYTES or base + n_entries >= 2**32 - 64:
-                        fits = False
-                        break
-                    off = (off + base).view(-1, 2)
-                    cell_rows[rows] = torch.stack([off[:, 0], cnt[:, 0], off[:, 1], cnt[:, 1]], 1)
-                    hdr = _as_u32(cell_rows)
-                    pool = torch.zeros(n_entries + 64, dtype=torch.int16, device=dev)
-                    struct.wg_cells = hdr.data_ptr()
-                    # the fill kernel writes at the header's offsets: hand it the group's pool displaced by `base`
-                    _lib.check(h.ms_wallgrid_fill(C.byref(struct), r32.data_ptr(), len(r), mc, bits_starts.data_ptr(),
-                                                  bits.data_ptr(), C.c_void_p(pool.data_ptr() - 2*base), _stream(dev)))
-                    torch.cuda.current_stream(dev).synchronize()           # (hdr / bits / pool of this group are done with)
-                    pools.append(pool[:n_entries])
-                    base += n_entries
-            if fits:
-                pool = torch.cat(pools + [torch.zeros(64, dtype=torch.int16, device=dev)])
-                hdr = _as_u32(torch.cat([cell_rows, torch.zeros((1, 4), dtype=torch.int64, device=dev)]))   # (+ the row agents outside the last grid read)
-                self._wg = (hdr, starts, geom, float(cell), float(self.WALL_GRID_REACH), float(self.WALL_GRID_NEAR), pool)
+            # which envs get a grid at all: some walls, not too many for 16-bit indices, not too large an area
+            extent = torch.ceil((hi - lo + 1.5)/cell).clamp(min=1)
+            usable = (extent[:, 0]*extent[:, 1] <= self.WALL_GRID_MAX_CELLS) & (walls > 0) & (walls <= 65535)
+            parent = None
+            if self.WALL_GRID_COARSE:
+                level = self._scan_level(cell*self.WALL_GRID_COARSE, None, False, usable)
+                if level is not None:
+                    hdr, starts, geom, pool, _, cells = level
+                    parent = (hdr, starts, geom, float(cell*self.WALL_GRID_COARSE), pool, cells)
+            level = self._scan_level(cell, parent, True, usable)
+            if level is not None:
+                hdr, starts, geom, pool, near, _ = level
+                self._wg = (hdr, starts, geom, float(cell), float(self.WALL_GRID_REACH[0]), float(self.WALL_GRID_REACH[1]),
+                            float(self.WALL_GRID_NEAR), pool, near)
                 self._struct = None
                 return
-
 
     def _bake_plan(self):
         """Scratch for the two-phase bake (MsScenery.bake_vis): for each representative env, lights x ceil(texels/64)

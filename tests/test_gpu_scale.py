@@ -156,7 +156,7 @@ def test_walls_with_non_finite_coordinates_go_through_the_exact_test(n_agents):
     the exact test for every agent (with four agents or fewer and with more - the two sweeps), like the reference, which
     tests every wall. The progress must come out as the oracle's, whatever that is."""
     from megastep_amd import core, cuda, scene, toys
-    sc = scene.scenery(48*[toys.box()], n_agents, device='cuda')
+    sc = scene.scenery([toys.box() for _ in range(48)], n_agents, device='cuda')     # (48 floorplans of their own: their walls are about to differ)
     c = core.Core(sc, res=8, fps=10)
     rng = np.random.RandomState(1)
     AF = n_agents*sc.model.shape[0]

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests import util
-from tests.test_wallgrid import scan_cell, NEAR, REACH
+from tests.test_wallgrid import scan_cell, NEAR, REACH, REACH_LO
 
 pytestmark = pytest.mark.gpu
 
@@ -28,26 +28,32 @@ def test_lists_built_on_the_gpu_are_the_host_scans():
     c, geometries = _world(12, 2, n_unique=5)
     sc = c.scenery
     assert sc._wg is not None
-    cells, starts, geom, cell, reach, near, pool = sc._wg
-    assert (reach, near) == (REACH, NEAR)
+    cells, starts, geom, cell, reach_lo, reach, near, pool, rows = sc._wg
+    assert (reach_lo, reach, near) == tuple(np.float32([REACH_LO, REACH, NEAR]).astype(float)) or (reach_lo, reach, near) == (REACH_LO, REACH, NEAR)
     cells = cells.cpu().numpy().view(np.uint32)
-    starts, geom, pool = starts.cpu().numpy(), geom.cpu().numpy(), pool.cpu().numpy().view(np.uint16)
+    starts, geom, pool, rows = starts.cpu().numpy(), geom.cpu().numpy(), pool.cpu().numpy().view(np.uint16), rows.cpu().numpy()
     AF = sc.n_agents*sc.model.shape[0]
     rng = np.random.RandomState(0)
     # envs of one floorplan share their cells
     assert starts[0] == starts[5] == starts[10] and starts[1] == starts[6] and len(set(starts[:5])) == 5
-    fractions = []
+    fractions, excess = [], []
     for n in (0, 3, 7):
         walls = sc.lines[n].cpu().numpy()[AF:]
         origin, dims = geom[n, :2], geom[n, 2:].astype(int)
         for c_ in rng.choice(dims[0]*dims[1], 30, replace=False):
             vis, close = scan_cell(walls, origin, dims, c_, cell)
             v0, vn, n0, nn = cells[starts[n] + c_]
-            got_vis, got_near = pool[v0:v0 + vn], pool[n0:n0 + nn]
-            np.testing.assert_array_equal(got_vis, np.nonzero(vis)[0])
-            np.testing.assert_array_equal(got_near, np.nonzero(close)[0])
+            n_lo, n_all = nn & 0xffff, nn >> 16
+            # built through the coarse level: nothing the one-level scan lists may be missing, and next to nothing more
+            # (an occluder the coarse cell's list lacks has a stand-in on it, which the thresholds may judge differently)
+            got = pool[v0:v0 + vn]
+            assert set(np.nonzero(vis)[0]) <= set(got) and len(got) <= 1.03*vis.sum() + 2 and (np.diff(got.astype(int)) > 0).all()
+            excess.append(len(got) - vis.sum())
+            want = np.concatenate([walls[close == 2], walls[close == 1]]).reshape(-1, 4)
+            assert (n_lo, n_all) == ((close == 2).sum(), (close > 0).sum())
+            np.testing.assert_array_equal(rows[n0:n0 + n_all], want)
             fractions.append(vn/len(walls))
-    print('mean listed fraction:', np.mean(fractions))
+    print('mean listed fraction:', np.mean(fractions), 'walls listed beyond the one-level scan:', np.sum(excess))
     assert np.mean(fractions) < .6
 
 
@@ -104,7 +110,7 @@ def test_where_the_lists_do_not_apply_every_wall_is_met():
 def test_a_grid_too_big_for_its_budget_is_coarsened_or_left_out(monkeypatch):
     from megastep_amd import cuda
     c, _ = _world(4, 1, n_unique=2)
-    needed = 2*c.scenery._wg[6].numel()
+    needed = 2*c.scenery._wg[7].numel() + 4*c.scenery._wg[8].numel()
     monkeypatch.setattr(cuda.Scenery, 'WALL_GRID_BYTES', needed//2)
     c, _ = _world(4, 1, n_unique=2)
     assert c.scenery._wg is not None and c.scenery._wg[3] > cuda.Scenery.WALL_GRID_CELL

@@ -13,16 +13,17 @@ import numpy as np
 import pytest
 from megastep_amd import _lib, cubicasa, scene, toys, core
 
-CELL, NEAR, REACH = .25, .12, 1.3
+CELL, NEAR, REACH_LO, REACH = .25, .12, .7, 1.3
 
 
 def scan_cell(walls, origin, dims, c, cell=CELL):
-    """vis, close (bool arrays over the walls) of cell c, from the library's host instantiation of its scan."""
+    """vis (bool) and close (2 within the short reach, 1 within the long one, else 0) over the walls of cell c, from the
+    library's host instantiation of its scan."""
     w = np.ascontiguousarray(walls.reshape(-1, 4), np.float32)
     vis, close = np.zeros(len(w), np.uint8), np.zeros(len(w), np.uint8)
     _lib.lib().ms_host_wallgrid_cell(w.ctypes.data, len(w), float(origin[0]), float(origin[1]), int(dims[0]), int(dims[1]),
-                                     cell, int(c), NEAR, REACH, vis.ctypes.data, close.ctypes.data)
-    return vis.astype(bool), close.astype(bool)
+                                     cell, int(c), NEAR, REACH_LO, REACH, vis.ctypes.data, close.ctypes.data)
+    return vis.astype(bool), close
 
 
 def grid_of(walls, cell=CELL):
@@ -134,9 +135,10 @@ def test_near_lists_hold_every_wall_within_reach(name):
                 t = np.clip(((p - a)*v).sum(1)/(v*v).sum(1), 0, 1)
             t = np.where(np.isfinite(t), t, 0.)
             d = np.linalg.norm(a + t[:, None]*v - p, axis=1)
-            must = ~(d > REACH)                                        # NaN walls: the reference stops agents at them
-            assert not (must & ~close).any(), f'{name}: cell {c} misses walls within reach'
-        assert close.sum() < len(walls) or len(walls) < 20
+            for reach, level in ((REACH, 1), (REACH_LO, 2)):
+                must = ~(d > reach)                                    # NaN walls: the reference stops agents at them
+                assert not (must & (close < level)).any(), f'{name}: cell {c} misses walls within {reach} m'
+        assert (close > 0).sum() < len(walls) or len(walls) < 20
 
 
 def test_one_wall_hides_another_only_when_it_really_does():
