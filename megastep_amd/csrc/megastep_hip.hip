@@ -636,13 +636,20 @@ struct LightScene {                   // what grid_light_intensity reads of an M
     const unsigned* lg_list; const unsigned* lg_pool;
 };
 
+// An env with more lights than the grid holds (it has no cells for such an env) is worked through group after group of
+// 64 lights, in the lights' order - the loop below, which everyone else passes once: per group every wall is met through
+// the corridor sweep, and the reference's running sum (kernels.cu:261-264) carries over from group to group.
 __device__ inline float grid_light_intensity(
         const LightScene sc, const MsAgents& ag, const int n, const int lane, const bool dynamic, const int nearest_idx,
         const float cx_l, const float cy_l, const int L, const float4* __restrict__ ln,
         LightPair* s_pair, unsigned* s_shadow) {
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int ni = sc.lights_widths[n];          // <= 64, guaranteed by whoever set lg_vals
-    const float* __restrict__ lights = sc.lights_vals + 3*(size_t)sc.lights_starts[n];
+    const int n_lights = sc.lights_widths[n];
+    const bool MANY = n_lights > WAVE;                                   // (uniform)
+    float acc_in = AMBIENT;
+    for (int first_light = 0; ; first_light += WAVE) {
+    const int ni = min(WAVE, n_lights - first_light);
+    const float* __restrict__ lights = sc.lights_vals + 3*((size_t)sc.lights_starts[n] + first_light);
     const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
     float Ix = 0.f, Iy = 0.f, Ii = 0.f;          // lane i holds light i
     if (lane < ni) { Ix = lights[3*lane]; Iy = lights[3*lane + 1]; Ii = lights[3*lane + 2]; }
@@ -651,7 +658,7 @@ __device__ inline float grid_light_intensity(
     // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
     uint4 st = make_uint4(0u, 0u, 0u, 0u);
     uint2 lst = make_uint2(0u, 0u);              // the cell's candidate list: first pool word, 0x80000000 | count
-    {
+    if (!MANY) {
         // (every lane reads a cell that exists - its own, or the env's first: loads without a guard overlap)
         const float fx = floorf((cx_l - geom.x)/sc.lg_cell), fy = floorf((cy_l - geom.y)/sc.lg_cell);
         const bool inside = dynamic & (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);
@@ -663,11 +670,11 @@ __device__ inline float grid_light_intensity(
         st.x = inside ? st_.x : 0u; st.y = inside ? st_.y : 0u; st.z = inside ? st_.z : 0u; st.w = inside ? st_.w : 0u;
         lst.x = inside ? lst_.x : 0u; lst.y = inside ? lst_.y : 0u;
     }
-    const bool shortcut = __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
+    const bool shortcut = !MANY && __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
     // ---- the sum over the lights the grid proves unblocked, in light order.  Rays around one target mostly share
     // a cell, so: one pass per distinct verdict word set, scalar loop over its LIT bits (01 in the 2-bit fields)
     float part = AMBIENT;
-    for (unsigned long long rem = __ballot(dynamic); rem; ) {
+    for (unsigned long long rem = MANY ? 0ull : __ballot(dynamic); rem; ) {
         const int j = __ffsll((long long)rem) - 1;
         const unsigned sw[4] = {(unsigned)__builtin_amdgcn_readlane((int)st.x, j), (unsigned)__builtin_amdgcn_readlane((int)st.y, j),
                                 (unsigned)__builtin_amdgcn_readlane((int)st.z, j), (unsigned)__builtin_amdgcn_readlane((int)st.w, j)};
@@ -697,7 +704,7 @@ __device__ inline float grid_light_intensity(
     const bool saturated = dynamic & shortcut & (part >= 1.001f);
     const bool need = dynamic & !saturated & has_unk;
     // Everyone else is done: with no light left open the reference's in-order sum over the unblocked lights IS `part`
-    if (!__ballot(need)) return saturated ? 1.f : ms_min(part, 1.f);
+    if (!__ballot(need)) return MANY ? acc_in : (saturated ? 1.f : ms_min(part, 1.f));
 
     // ---- the rest is the rare path: rays with lights the grid leaves open
     auto status = [&](int i) {                   // light i's 2-bit verdict for this ray's cell; i is wave-uniform
@@ -820,7 +827,7 @@ __device__ inline float grid_light_intensity(
         __builtin_amdgcn_wave_barrier();
     }
     // (3) the reference's sum (kernels.cu:261-267) in light order: the grid's verdict where it has one, else the walls'
-    float acc = AMBIENT;
+    float acc = MANY ? acc_in : AMBIENT;
     for (int i = 0; i < ni; i++) {
         const unsigned s2 = status(i);
         const bool unblocked = (s2 == 1u) | ((s2 == 0u) & !((shadow >> i) & 1ull));
@@ -828,8 +835,15 @@ __device__ inline float grid_light_intensity(
         const float d2 = len2(I - p2(cx_l, cy_l));
         if (need & unblocked) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
     }
+    if (MANY) {
+        if (first_light + WAVE >= n_lights) return ms_min(acc, 1.f);
+        acc_in = acc;
+        __builtin_amdgcn_wave_barrier();
+        continue;
+    }
     const float intensity = saturated ? 1.f : ms_min(need ? acc : part, 1.f);
     return intensity;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -864,6 +878,12 @@ constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair
 constexpr int MS_TELEMETRY_MAGIC = 0x7e1e7e1e;   // in workspace[5]: the caller wants the pair counters (workspace[3], [4])
 
 struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
+#ifndef MS_PERSISTENT
+#define MS_PERSISTENT 0
+#endif
+#if MS_PERSISTENT
+__device__ int g_cursor[8];
+#endif
 
 // The drawn (world-frame) model line `l` of env n: draw_kernel, kernels.cu:297-318.
 // sin/cos of a heading where it is not worth a copy of the code: (sin(pi x), cos(pi x)), as sincospi_f gives them
@@ -1038,12 +1058,25 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
     // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
     // logical blocks so the fans of one env (and its lines) stay behind one L2.
+#if MS_PERSISTENT
+    // (-DMS_PERSISTENT=1, an experiment: as many one-wave workgroups as the chip holds at once, each taking fan after
+    // fan of its XCD's run from a cursor)
+    const int nb = n_fans, xcd = blockIdx.x & 7;
+    const int q8 = nb >> 3, r8 = nb & 7;
+    const int run0 = xcd < r8 ? xcd*(q8 + 1) : r8*(q8 + 1) + (xcd - r8)*q8, run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
+    for (;;) {
+    const int lb = run0 + __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(&g_cursor[xcd], 1) : 0);
+    if (lb >= run1) break;
+    __builtin_amdgcn_wave_barrier();
+    const int fan = lb;
+#else
     const int nb = gridDim.x, b = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
     const int lb = (xcd < r8 ? xcd*(q8 + 1) : r8*(q8 + 1) + (xcd - r8)*q8) + ix;
 
     const int fan = lb*RW + wave;
     if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
+#endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
     const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
@@ -1920,6 +1953,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
     }
     PROBE_DONE(fan)
+#if MS_PERSISTENT
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2377,7 +2415,11 @@ __global__ __launch_bounds__(WG) void bake_sum_kernel(const MsScenery sc) {
     // kernels.cu:434) but the reference bakes them where the agents happen to stand, so they are worked out here,
     // per env, against every wall - the agents of a group's envs need not stand in the same place.
     const bool agent_line = l0 - base < AF;
-    const unsigned long long* __restrict__ vis = sc.bake_vis + sc.bake_vis_starts[n];
+    // (the rows this env's lights take must lie inside the scratch: visibility_kernel skipped them otherwise, and
+    // reading on would be reading someone else's memory - such a texel keeps the ones it was initialised with)
+    const long long vis_row0 = sc.bake_vis_starts[n];
+    if (!agent_line && (vis_row0 < 0 || vis_row0 + (long long)num_i*TB > sc.bake_vis_words)) return;
+    const unsigned long long* __restrict__ vis = sc.bake_vis + vis_row0;
     float acc = AMBIENT;
     for (int i = 0; i < num_i; i++) {                                    // kernels.cu:261-264, in light order
         const P2 I = p2(lights[3*i], lights[3*i + 1]);
@@ -3108,7 +3150,15 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_m = divisor_of((unsigned)sc->n_model);
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
     constexpr int RW = 1;
+#if MS_PERSISTENT
+    static int* cursor = nullptr;
+    if (!cursor && hipGetSymbolAddress((void**)&cursor, HIP_SYMBOL(g_cursor)) != hipSuccess) return hip_fail(hipGetLastError());
+    if (hipMemsetAsync(cursor, 0, 8*sizeof(int), (hipStream_t)stream) != hipSuccess) return hip_fail(hipGetLastError());
+    const char* pw = getenv("MEGASTEP_PERSISTENT_WAVES");
+    const int rblocks = (int)(n_fans < (pw ? atoi(pw) : 6144) ? n_fans : (pw ? atoi(pw) : 6144));
+#else
     const int rblocks = (int)((n_fans + RW - 1)/RW);
+#endif
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
     const hipStream_t hs = (hipStream_t)stream;
 #define MS_LAUNCH_RENDER(I, O) \

@@ -231,6 +231,7 @@ class Scenery:
         return dotdict.dotdict(n_agents=self._n_agents, lights=self._lights[e], lines=self._lines[e],
                                textures=self._textures[s:t], model=self._model, baked=self._baked[s:t])
 
+    LIGHT_GRID = True           # False: no light grid (ms_render's two-kernel path; tests)
     LIGHT_GRID_CELL = .25
     LIGHT_GRID_POOL = 12        # pool words per cell (4 bytes each) for the candidate lists
 
@@ -247,16 +248,19 @@ class Scenery:
         lo, hi = self._wall_bounds()
         origin = torch.floor(lo) - .5
         dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
+        # the grid holds 64 lights per env: an env with more gets no cells, and the renderer meets every wall for the
+        # rays that land on an agent there (the other envs keep their grids, and the launch stays one kernel)
+        dims = torch.where((self._lights.widths <= 64)[:, None], dims, torch.zeros_like(dims))
         cells = (dims[:, 0]*dims[:, 1]).long()
         rep = torch.arange(n_envs, device=dev) if self._geom is None else self._geom.long()
         own = cells*(rep == torch.arange(n_envs, device=dev))          # members own no cells
         starts = (own.cumsum(0) - own)[rep].to(torch.int32)
         geom = torch.cat([origin, dims], 1).float()[rep].contiguous()
         total = int(own.sum())
-        vals = torch.zeros((total, 4), dtype=torch.int32, device=dev)
-        lists = torch.zeros((total, 2), dtype=torch.int32, device=dev)
+        vals = torch.zeros((total + 1, 4), dtype=torch.int32, device=dev)     # (+ a row for rays outside the last env's grid to read)
+        lists = torch.zeros((total + 1, 2), dtype=torch.int32, device=dev)
         pool = torch.zeros(min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1), dtype=torch.int32, device=dev)
-        return vals, starts.contiguous(), geom, cell, int(cells.max()), lists, pool
+        return vals, starts.contiguous(), geom, cell, max(int(cells.max()), 1), lists, pool
 
     def _wall_bounds(self):
         """(n_envs, 2) lower and upper corner of each env's static walls (finite coordinates only; 0, 0 without any)."""
@@ -278,11 +282,9 @@ class Scenery:
     def _as_struct(self):
         if self._struct is None:
             li, ln, tx = self._lights, self._lines, self._textures
-            # the grid holds 64 lights per env; sceneries beyond that go without
-            few_lights = len(li.widths) == 0 or int(li.widths.max()) <= 64
             if self._lg is None:
                 # (one agent per env: no ray ever lands on an agent line, so nothing would consult the grid)
-                wanted = few_lights and self._n_agents > 1
+                wanted = self._n_agents > 1 and self.LIGHT_GRID
                 self._lg = self._light_grid() if wanted else (None, None, None, 0., 0, None, None)
             lg = self._lg
             self._struct = _lib.MsScenery(
@@ -450,7 +452,8 @@ class Scenery:
         rep = torch.arange(n_envs, device=dev) if self._geom is None else self._geom.long()
         own = words*(rep == torch.arange(n_envs, device=dev))
         starts = (own.cumsum(0) - own)[rep].contiguous()
-        return torch.empty(max(int(own.sum()), 1), dtype=torch.int64, device=dev), starts
+        # (zeroed: a row that visibility_kernel's bounds check skipped reads as 'nothing blocks', never as garbage)
+        return torch.zeros(max(int(own.sum()), 1), dtype=torch.int64, device=dev), starts
 
     def _device(self):
         """The GPU all of this scenery's tensors live on (checked once; the tensors cannot be swapped out)."""
@@ -652,6 +655,9 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
                 or epoch.shape != (n,) or count.shape != (n,):
             raise RuntimeError('seen must be contiguous int32 tensors (stamp per texel, epoch per env, count per env)')
         _require_gpu(*seen)
+    if seen is not None and a > 1 and scenery._as_struct().lg_vals is None:
+        raise RuntimeError('first-sight bookkeeping (seen=) rides in the one-kernel renderer, which needs the light grid that this '
+                           'multi-agent scenery was built without (Scenery.LIGHT_GRID = False)')
     key = (n, a, cfg.res, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), dev,
            None if seen is None else tuple(t.data_ptr() for t in seen))
     if out is not None:
@@ -680,7 +686,7 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
         raise RuntimeError(f'fields must be among {FIELDS}')
     scenery._as_struct()
     if a > 1 and scenery._lg[0] is None:
-        # no light grid (an env with more than 64 lights): agent hits are lit by a second launch that reads all five
+        # no light grid (Scenery.LIGHT_GRID switched off): agent hits are lit by a second launch that reads all five
         # planes back and patches `screen` - after any pooling. All planes then, and the caller pools.
         want, pooled = FIELDS, None
     sub, max_depth, w = 1, 1., r

@@ -97,8 +97,9 @@ def _shard_light_grid(lg, start, stop, device, geom=None):
     take = rows[cell_of, 0] + (torch.arange(int(count.sum()), device=dev) - first[cell_of])
     sub_pool = torch.cat([count.sum()[None].to(pool.dtype), pool[take]])
     sub_lists = torch.stack([torch.where(rows[:, 1] != 0, first + 1, torch.zeros_like(first)), rows[:, 1]], 1).to(torch.int32)
-    return (vals[src].to(device).contiguous().clone(), new_starts[rep].to(torch.int32).to(device).contiguous(),
-            sub_geom.to(device).contiguous().clone(), cell, int(cells.max()), sub_lists.to(device).contiguous(),
+    pad = lambda t: torch.cat([t, torch.zeros_like(t[:1])])               # (the row rays outside the last env's grid read)
+    return (pad(vals[src]).to(device).contiguous().clone(), new_starts[rep].to(torch.int32).to(device).contiguous(),
+            sub_geom.to(device).contiguous().clone(), cell, max(int(cells.max()), 1), pad(sub_lists).to(device).contiguous(),
             sub_pool.to(device).contiguous())
 
 

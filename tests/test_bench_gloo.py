@@ -42,3 +42,43 @@ def test_bench_line_single_rank():
     out = _run(1, ('--no-graph',))
     assert out['n_gpus'] == 1 and out['config']['envs_total'] == 24 and out['config']['envs_this_rank'] == 24
     assert 'eager' in out['config']['launch']
+
+
+def test_every_rank_builds_its_own_slice_and_the_slices_make_the_world(monkeypatch):
+    """bench.build_world with world > 1 (reference: common.h:136-144 slices, it does not replicate): what reaches a rank's
+    device is its slice and nothing else, the cuts are the cost-balanced ones every rank works out alike from the
+    floorplans, and the slices laid end to end are the single-rank build of the same job bit for bit."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from megastep_amd import scene, sharding
+    built = []
+    real = scene.scenery
+
+    def spy(geometries, *args, **kwargs):
+        result = real(geometries, *args, **kwargs)
+        built.append((len(geometries), kwargs.get('envs'), len(result.lines), result.lines.vals.shape[0], result.textures.vals.shape[0]))
+        return result
+    monkeypatch.setattr(scene, 'scenery', spy)
+    kw = dict(n_agents=2, res=16, fov=130., device=torch.device('cpu'), seed=1, n_unique=16, bake=False)
+    world = 3
+    whole, geometries = bench.build_world(3*24, world=1, **kw)            # the same 72-env job on one rank
+    parts = [bench.build_world(24, rank=r, world=world, **kw) for r in range(world)]
+    cuts = [bench.rank_slice(geometries, 2, 16, r, world) for r in range(world)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == 72 and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    # balanced by lines x agents x rays, not by env count: each rank's share of the cost within one env of a third
+    cost = np.array([2*8 + len(g['walls']) for g in geometries], float)
+    for (a, b) in cuts:
+        assert abs(cost[a:b].sum() - cost.sum()/world) <= cost.max()
+    for (n_geoms, envs, n_envs, n_lines, n_texels), (core, geoms), (a, b) in zip(built[1:], parts, cuts):
+        # the build was handed the whole job's floorplans but made tensors for its slice only
+        assert n_geoms == 72 and tuple(envs) == (a, b) and n_envs == b - a == core.n_envs == len(geoms)
+        assert n_lines == int(whole.scenery.lines.widths[a:b].sum()) < whole.scenery.lines.vals.shape[0]
+        assert n_texels < whole.scenery.textures.vals.shape[0]
+    for k in ('lines', 'lights', 'textures'):
+        for f in ('vals', 'widths'):
+            assert torch.equal(torch.cat([getattr(getattr(c.scenery, k), f) for c, _ in parts]), getattr(getattr(whole.scenery, k), f)), (k, f)
+    # the same cuts as sharding a built world by its measured cost would make
+    for r in range(world):
+        assert sharding.env_slice(72, r, world, sharding.render_cost(whole.scenery, 16)) == cuts[r]

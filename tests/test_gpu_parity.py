@@ -344,7 +344,7 @@ def test_unbaked_scenery_and_shards_render_exactly():
         util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())
     full = scene.scenery(gs, 3, device='cuda', random=np.random.RandomState(0))
     shard = sharding.shard_scenery(full, 1, 2)
-    assert torch.equal(shard._lg[0], full._lg[0][int(full._lg[1][3]):]) and shard._lg[0].any()
+    assert torch.equal(shard._lg[0][:-1], full._lg[0][int(full._lg[1][3]):-1]) and shard._lg[0].any()     # (both end in a padding row)
     c = core.Core(shard, res=64, fov=130)
     util.spawn(c, gs[3:], seed=2)
     c.agents.positions[:, 2] = c.agents.positions[:, 0] + torch.tensor([.1, .45], device=c.device)
@@ -353,27 +353,44 @@ def test_unbaked_scenery_and_shards_render_exactly():
     util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())
 
 
-def test_more_than_64_lights_and_agents():
-    """Past the light grid's 64 lights per env the grid-less lighting kernel takes over (two light groups);
-    past 64 agents per env the per-wave agent cache is bypassed."""
-    from megastep_amd import arrdict, core, cuda, scene, toys
+def test_more_than_64_lights_and_agents(monkeypatch):
+    """An env with more lights than the light grid holds per env (64) gets no cells of it, and the rays that land on an
+    agent there meet the walls group of 64 lights after group of 64 - inside the render kernel, next to envs that do have
+    their grids: one launch, pooled observations and all (reference: kernels.cu:245-267 has no such limit). Without any
+    grid the separate lighting kernel does the same. Past 64 agents per env the per-wave agent cache is bypassed."""
+    from megastep_amd import arrdict, core, cuda, modules, scene, toys
     rng = np.random.RandomState(0)
     box = toys.box()
     pillars = np.concatenate([np.array([[[x, y], [x + .2, y]], [[x + .2, y], [x + .2, y + .2]], [[x + .2, y + .2], [x, y + .2]],
                                         [[x, y + .2], [x, y]]]) for x, y in rng.uniform(1.5, 5.3, (6, 2))])
-    geom = arrdict.arrdict(walls=np.concatenate([box.walls, pillars]), lights=rng.uniform(1.2, 5.8, (70, 2)), masks=box.masks, res=.2)
-    np.random.seed(0)
-    sc = scene.scenery([geom, geom], 3, device='cuda', random=np.random.RandomState(0))
-    assert sc._as_struct().lg_vals is None                      # no grid for this scenery
-    c = core.Core(sc, res=64, fov=130)
-    c.agents.positions[:] = torch.as_tensor(rng.uniform(2.5, 4.5, (2, 3, 2)).astype(np.float32), device=c.device)
-    c.agents.angles[:] = torch.as_tensor(rng.uniform(-180, 180, (2, 3)).astype(np.float32), device=c.device)
-    ref = util.OracleWorld(c)
-    np.testing.assert_allclose(sc.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
-    ref.pull_baked(c); ref.pull_agents(c)
-    r = cuda.render(c.scenery, c.agents)
-    assert ((r.indices >= 0) & (r.indices < 24)).any()
-    util.assert_render_matches(c, r, ref.render())
+    walls = np.concatenate([box.walls, pillars])
+    geoms = [arrdict.arrdict(walls=walls, lights=rng.uniform(1.2, 5.8, (k, 2)), masks=box.masks, res=.2) for k in (70, 9, 150, 64)]
+    for grid in (True, False):
+        monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID', grid)
+        np.random.seed(0)
+        sc = scene.scenery(geoms, 3, device='cuda', random=np.random.RandomState(0))
+        assert (sc._as_struct().lg_vals is not None) == grid
+        if grid:                                                    # cells for the envs the grid can hold, none for the others
+            assert (sc._lg[2][:, 2] > 0).tolist() == [False, True, False, True]
+        c = core.Core(sc, res=64, fov=130)
+        spots = np.array([[3., 3.], [4., 3.1], [3.5, 4.]], np.float32) + rng.uniform(-.2, .2, (4, 3, 2)).astype(np.float32)
+        c.agents.positions[:] = torch.as_tensor(spots, device=c.device)     # a triangle of agents looking at each other
+        c.agents.angles[:] = torch.as_tensor(np.array([30., 150., -90.], np.float32) + rng.uniform(-10, 10, (4, 3)).astype(np.float32), device=c.device)
+        ref = util.OracleWorld(c)
+        np.testing.assert_allclose(sc.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+        ref.pull_baked(c); ref.pull_agents(c)
+        r = cuda.render(c.scenery, c.agents)
+        lit = (r.indices >= 0) & (r.indices < 24)
+        assert all(lit[e].any() for e in range(4)), 'rays should land on agents in every env'
+        want = ref.render()
+        util.assert_render_matches(c, r, want)
+        if grid:                                                    # ... and the fused observations stay available
+            rgb, depth = modules.RGB(c, subsample=4), modules.Depth(c, subsample=4)
+            frame = modules.render(c, observers=(rgb, depth), fields=(), centre=True)
+            assert 'pooled_rgb' in frame and 'screen' not in frame
+            full = torch.as_tensor(want['screen'], device=c.device).permute(0, 1, 3, 2).unsqueeze(3)
+            torch.testing.assert_close(rgb(frame), modules.downsample(full, 4).mean(-1), rtol=0, atol=1e-5)
+    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID', True)
 
     crowd = scene.scenery([toys.box(8)], 66, device='cuda', random=np.random.RandomState(0))
     c = core.Core(crowd, res=16, fov=130)
