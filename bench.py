@@ -170,16 +170,18 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
 
 
 def measured_traffic(args):
-    """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact command (profiles/rNN_traffic.json,
-    written by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950) and the file it was read from. (None, None) when the workload differs
-    from the profiled one: PMC counters cannot be collected from inside the benchmark process."""
+    """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact workload (profiles/rNN_traffic.json, collected
+    by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950) and the file it was read from; the newest round that profiled the shape wins. (None, None) for a shape
+    nobody profiled: PMC counters cannot be collected from inside the benchmark process."""
     import glob
+    want = (args.envs, args.agents, args.res, bool(args.large))
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
         t = json.load(open(path))
-        w = t.get('workload', {})
-        if (w.get('envs'), w.get('agents'), w.get('res'), w.get('large', False)) == (args.envs, args.agents, args.res, args.large):
-            return t['render_bytes_per_launch'], os.path.relpath(path, ROOT)
+        for entry in t.get('shapes', [t]):                              # (one shape per file up to round 2, a list since)
+            w = entry.get('workload', {})
+            if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False))) == want:
+                return entry['render_bytes_per_launch'], os.path.relpath(path, ROOT)
     return None, None
 
 

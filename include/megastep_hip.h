@@ -117,7 +117,9 @@ typedef struct MsScenery {
      *             wg_near_rows), near count within wg_reach_lo | near count in all << 16]
      *   wg_starts (N,) first cell of env n;   wg_geom (N, 4) float: grid origin x, y, cells along x, cells along y
      *             (0 cells: this env has no grid);   wg_cell: cell size in metres
-     *   wg_pool   uint16 wall indices, the vis lists; at least 64 entries longer than the lists need
+     *   wg_pool   the vis lists, one uint32 per entry: wall index | first step << 16 | last step << 24 of the arc of
+     *             directions the wall can be seen in from the cell (steps of 1/64 of a quarter turn-like unit, modulo 256:
+     *             ms_render skips entries whose arc misses its rays'); at least 64 entries longer than the lists need
      *   wg_near_rows  (., 4) float: the near lists as copies of the walls' rows (ax, ay, bx, by), per cell the walls
      *             within wg_reach_lo of it first, then those within wg_reach
      *   wg_near   vis lists hold for near planes (MsConfig.agent_radius) below this and fields of view up to
@@ -128,7 +130,7 @@ typedef struct MsScenery {
     float                 wg_cell;
     float                 wg_reach_lo, wg_reach;
     float                 wg_near;
-    const unsigned short* wg_pool;
+    const unsigned*       wg_pool;
     const float*          wg_near_rows;
     /* Optional: the largest distance of a point of `model` from the agent's origin, 0 = not known.  When it is below
      * the near plane (MsConfig.agent_radius, as in the reference: core.py:14, scene.py:25-33), no ray of an agent can
@@ -268,8 +270,9 @@ int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* 
  *                     every cell within) and an order of magnitude less work on large floorplans.  NULL: every wall.
  *                     max_groups: with a parent the most parent cells any listed env has, without ceil(most cells / 4).
  *   ms_wallgrid_fill  writes the lists: the set bits of each row, in order, from the cell's wg_cells offsets (which the
- *                     caller has filled in from the counts) - vis lists as indices into `pool`, near lists as rows into
- *                     `near_rows`, or as indices into `pool` as well when near_rows is NULL (a parent level).
+ *                     caller has filled in from the counts) - vis lists as entries of `vis_entries` (MsScenery.wg_pool's
+ *                     format), near lists as rows into `near_rows`; or, for a parent level (both NULL), both lists as
+ *                     16-bit indices into `pool`.
  * An env with more than 65535 static walls must have a grid of 0 cells. */
 #define MS_WALLGRID_MAX_FOV 165.f
 typedef struct MsWallGridParent {
@@ -278,7 +281,8 @@ typedef struct MsWallGridParent {
 int ms_wallgrid_scan(const MsScenery* scenery, const MsWallGridParent* parent, const int* reps, int n_reps, int max_groups,
                      const long long* bits_starts, unsigned* bits, unsigned* counts, void* hip_stream);
 int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int max_cells,
-                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, float* near_rows, void* hip_stream);
+                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, unsigned* vis_entries,
+                     float* near_rows, void* hip_stream);
 /* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
  * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);
@@ -287,6 +291,11 @@ int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, 
  * where it is within reach_lo / reach of the cell. */
 void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, int nx, int ny, float cell, int c,
                            float near_plane, float reach_lo, float reach, unsigned char* vis, unsigned char* close);
+
+/* ... and of the arcs: the run of steps [*lo8, *hi8] (modulo 256) of directions wall w can be seen in from the cell; and
+ * whether a wave whose rightmost / leftmost ray point along (right_x, right_y) / (left_x, left_y) would keep such a wall. */
+void ms_host_wall_arc(float x0, float y0, float x1, float y1, const float* w, int* lo8, int* hi8);
+int  ms_host_wedge_meets(float right_x, float right_y, float left_x, float left_y, int lo8, int hi8);
 
 /* Scalar helper exported for tests: sin(pi x), cos(pi x) exactly as the kernels evaluate them. */
 void ms_host_sincospi(float x, float* s, float* c);

@@ -71,7 +71,8 @@ class MsRender(C.Structure):
 SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
-           'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell')
+           'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
+           'ms_host_wedge_meets')
 
 
 def _source_hash():
@@ -148,7 +149,11 @@ def lib():
         handle.ms_wallgrid_scan.argtypes = [C.POINTER(MsScenery), C.POINTER(MsWallGridParent), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         handle.ms_wallgrid_fill.argtypes = [C.POINTER(MsScenery), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                            C.c_void_p, C.c_void_p]
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+        handle.ms_host_wall_arc.argtypes = [C.c_float]*4 + [_f32p, _i32p, _i32p]
+        handle.ms_host_wall_arc.restype = None
+        handle.ms_host_wedge_meets.argtypes = [C.c_float]*4 + [C.c_int, C.c_int]
+        handle.ms_host_wedge_meets.restype = C.c_int
         handle.ms_host_wall_hidden.argtypes = [C.c_float]*4 + [_f32p, _f32p, C.c_float]
         handle.ms_host_wall_hidden.restype = C.c_int
         handle.ms_host_wallgrid_cell.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,

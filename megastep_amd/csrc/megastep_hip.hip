@@ -104,6 +104,27 @@ __host__ __device__ inline float dot(P2 v, P2 w) { return v.x*w.x + v.y*w.y; }
 __host__ __device__ inline float ms_min(float a, float b) { if (a != a) return b; return (b < a) ? b : a; }
 __host__ __device__ inline float ms_max(float a, float b) { if (a != a) return b; return (b > a) ? b : a; }
 
+// direction of (x, y) in [0, 4): 0 along +x, 1 along +y, 2 along -x, 3 along -y; NaN at the origin
+__host__ __device__ inline float pseudo_angle(float x, float y) {
+    const float p = y/(fabsf(x) + fabsf(y));
+    return x < 0.f ? 2.f - p : (p < 0.f ? 4.f + p : p);
+}
+// Runs of directions in 1/64ths of a pseudo-angle unit, modulo 256 (wg_arc, where the wall grid is built, has the whole
+// story): the steps wa..wb (inclusive) that hold the directions from a wave's rightmost ray to its leftmost, widened by
+// the same margin as the walls' arcs; and whether two such runs share a step.
+constexpr float WG_ARC_MARGIN = 2e-3f;
+__host__ __device__ inline void wg_wedge(const float p_right, const float p_left, int& wa8, int& wb8) {
+    float width = p_left - p_right;
+    width = width < 0.f ? width + 4.f : width;
+    const int a = (int)floorf((p_right - WG_ARC_MARGIN)*64.f), b = (int)floorf((p_right + width + WG_ARC_MARGIN)*64.f);
+    wa8 = 0; wb8 = 255;
+    if (!(width < 2.f) || b - a >= 255) return;                          // (half a turn and more: fov < 180 rules it out; NaNs)
+    wa8 = a & 255; wb8 = b & 255;
+}
+__host__ __device__ inline bool wg_arcs_meet(const int lo8, const int hi8, const int wa8, const int wb8) {
+    return (((wa8 - lo8) & 255) <= ((hi8 - lo8) & 255)) | (((lo8 - wa8) & 255) <= ((wb8 - wa8) & 255));
+}
+
 // sin(pi x), cos(pi x); stands in for sinpif/cospif (kernels.cu:305-306,336-337).  The range
 // reduction is exact in binary32, the kernel is a Taylor series in binary64 rounded once.
 __host__ __device__ inline void sincospi_f(float x, float& s, float& c) {
@@ -450,7 +471,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             const float fx = floorf((me.x - geom.x)*inv_cell), fy = floorf((me.y - geom.y)*inv_cell);
             const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);   // (NaNs: outside)
             const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[sc.wg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0)];
-            ok = inside & (my_reach <= sc.wg_reach);
+            ok = (A <= WAVE) & inside & (my_reach <= sc.wg_reach);       // (a lane per agent: more than 64 of them take the sweep)
             first = hdr.z;
             count = ok ? (int)((my_reach <= sc.wg_reach_lo) ? (hdr.w & 0xffffu) : (hdr.w >> 16)) : 0;
         }
@@ -1034,7 +1055,21 @@ __device__ inline void ray_interval(float xa, float ya, float xb, float yb, cons
 // OBS = 1: any of the five per-ray outputs may be NULL, and pooled observations are written on request (the plain
 // instantiation stays within 80 VGPRs: six waves per SIMD)
 template <int IMPL, int RW, int OBS>
-__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_kernel(
+// Occupancy knobs of the render kernel (A/B builds; the defaults are the product): waves per SIMD the register allocation
+// is held to, chunks of rows in flight, capacity of a wave's list of visible lines (which sizes its LDS block)
+#ifndef MS_WAVES
+#define MS_WAVES 6
+#endif
+#ifndef MS_ABLATE
+#define MS_ABLATE 0                          // (instruction-count experiments: 1 stops a wave after its set-up, 2 after pass 1 with
+#endif                                       //  pass 2 skipped, 3 after the raycast; the outputs are then garbage)
+#ifndef MS_AHEAD
+#define MS_AHEAD 3
+#endif
+#ifndef MS_VCAP
+#define MS_VCAP 128
+#endif
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVES, MS_WAVES))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
@@ -1047,7 +1082,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     //   4096 screen (192 x 4 B)  RGB staging
     // IMPL 2 lays its block out differently (see there): 6144 B
     PROBE_INIT
-    constexpr int LDS_PER_WAVE = IMPL == 2 ? 6144 : 4864;
+    constexpr int LDS_PER_WAVE = IMPL == 2 ? 24*MS_VCAP + 3072 : 4864;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
@@ -1110,7 +1145,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
-    constexpr int AHEAD = 3;                     // chunks of lines in flight (IMPL 2)
+    constexpr int AHEAD = MS_AHEAD;              // chunks of lines in flight (IMPL 2)
 
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
     // there is one.  Lanes exchange data in here: call it from wave-uniform control flow only.
@@ -1438,19 +1473,21 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
         //  * a line with an end behind the near clip plane is not clipped: its interval runs from the visible
         //    end's ray to the edge of the fan on the side it leaves by - the sign of cross(a, b).  (Clipping would
         //    only give less when the crossing is within centimetres of the agent.)
-        // LDS per wave:    0 cand (128 x 16 B)  | 2048 info (128 x 8 B: first ray - first pair, line)
-        //               3072 ray (64 x 8 B: rx, ry), 3584 near (64 x 4 B) | 4096 best, 4608 second, 5120 third (64 x 8 B each) | 5632 marks (4096 bits)
+        // LDS per wave (V = V_CAP lines):  cand (V x 16 B) | info (V x 8 B: first ray - first pair, line) | ray (64 x 8 B: rx, ry)
+        //               | near (64 x 4 B) | queue (128 x 2 B) | best, second, third (64 x 8 B each) | marks (4096 bits)
         // ------------------------------------------------------------------------------------------
-        constexpr int V_CAP = 128, P_CAP = 4096;
-        int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][2048]);
+        constexpr int V_CAP = MS_VCAP, P_CAP = 4096 < 64*MS_VCAP ? 4096 : 64*MS_VCAP;
+        constexpr int O_INFO = 16*V_CAP, O_RAY = 24*V_CAP, O_NEAR = O_RAY + 512, O_QUEUE = O_NEAR + 256, O_BEST = O_QUEUE + 256;
+        static_assert(O_BEST + 3*512 + 512 == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
+        int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][O_INFO]);
         // (direction and near plane in arrays of their own: at 8 and 4 bytes a ray, a window's reads - one ray per lane, the
         // rays mostly consecutive - touch every LDS bank once; as one 16-byte record per ray they were two-way conflicts)
-        float2* const s_ray_w = reinterpret_cast<float2*>(&s_raw[wave][3072]);
-        float* const s_near_w = reinterpret_cast<float*>(&s_raw[wave][3584]);
-        unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4096]);
-        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][4608]);
-        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][5120]);
-        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][5632]);
+        float2* const s_ray_w = reinterpret_cast<float2*>(&s_raw[wave][O_RAY]);
+        float* const s_near_w = reinterpret_cast<float*>(&s_raw[wave][O_NEAR]);
+        unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST]);
+        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 512]);
+        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 1024]);
+        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][O_BEST + 1536]);
         s_ray_w[lane] = make_float2(rx, ry);
         s_near_w[lane] = near;
         s_best_w[lane] = ~0ull;
@@ -1489,6 +1526,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int before = 0;                      // marks in earlier windows = lines that start before this one
             n_pairs_total += n_pairs; n_windows += (n_pairs + WAVE - 1)/WAVE;
+            if constexpr (MS_ABLATE == 2) n_pairs = 0;
             // the mark bits of all 64 possible windows in one read: lane w holds window w's, and each window fetches
             // its own with two v_readlane - no LDS round trip per window
             const unsigned long long my_marks = reinterpret_cast<const unsigned long long*>(s_mark_w)[lane];
@@ -1563,57 +1601,97 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
             if constexpr ((MS_V2_OPTS & 1) != 0) drain();
         };
 
-        // The lines this wave meets, as one sequence of items: the AF agent lines (worked out from the agents' state,
-        // never read), then the walls - those on the cell's vis list, in list order, or all of them.  Item i of a chunk
-        // is lane i's; what a lane needs from memory is its list entry (a 16-bit wall index, through a buffer
-        // descriptor over the list: lanes before and past it read zero) and then that wall's row.  AHEAD chunks of rows
-        // are in flight, and the list entries of the AHEAD chunks behind those.  (The chunk loop is unrolled by hand
-        // over the chunks in flight: rotating them through registers would make the moves wait for the loads they
-        // move.  All loads are unconditional: behind a branch hipcc waits for every load in flight at the first use of
-        // any of them, which turns "in flight" into "one at a time".)
-        // (The agent's own model lines are left out when the host has checked that the whole model lies inside the near
-        // plane - MsScenery.model_radius - as the reference's does: a hit on them is never `beyond`, kernels.cu:369, and
-        // seen from their middle they span half the fan - a quarter of all the (line, ray) pairs a wave would test.)
+        // The lines this wave meets: the agents' lines (worked out from the agents' state, never read; the agent's own
+        // are left out when the host has checked that its whole outline lies inside the near plane - MsScenery.model_radius
+        // - as the reference's does: a hit on them is never `beyond`, kernels.cu:369, and seen from their middle they span
+        // half the fan, a quarter of all the (line, ray) pairs a wave would test), then the walls - those on the cell's vis
+        // list, or all of them.
+        //
+        // A list entry names a wall and the arc of directions it can be seen in from anywhere in the cell (wg_arc).  First
+        // the entries are looked at on their own, 64 to an instruction: those whose arc misses the run of directions of
+        // this wave's rays - most of them, the more so the narrower the wave's share of the field of view - are dropped,
+        // the others' wall numbers queued in LDS (ballot + mbcnt).  Only queued walls have their rows fetched and go
+        // through pass 1: a dozen instructions per 64 entries decide what used to cost ninety.  Items (agent lines, then
+        // the queue) are worked through in batches of up to AHEAD chunks, whose rows are all in flight at once; the queue
+        // holds Q_CAP walls, and a long list is a matter of several batches.  (All loads are unconditional: behind a branch
+        // hipcc waits for every load in flight at the first use of any of them.)
+        if constexpr (MS_ABLATE == 1) { if (out.indices) out.indices[(size_t)fan*WAVE + lane] = __float_as_int(near + rlen); return; }
+        constexpr int Q_CAP = 128;
+        unsigned short* const s_queue_w = reinterpret_cast<unsigned short*>(&s_raw[wave][O_QUEUE]);
         const bool listed = wg_count >= 0;                                   // (uniform)
-        const int n_walls = listed ? wg_count : max(L - AF, 0);
+        const int n_raw = listed ? wg_count : max(L - AF, 0);
         const int own0 = a*sc.n_model, own = rc.skip_own ? sc.n_model : 0;
         const int AL = AF - own;                                             // agent lines among the items
-        const int n_items = AL + n_walls;
         const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(sc.wg_pool + wg_first), 0, listed ? 2*n_walls : 0, 0x00020000);
-        const int lane_entry = 2*(lane - AL);
-        auto entry = [&](const int i0) {                                     // list entries of items i0 + lane
-            return (int)__builtin_amdgcn_raw_buffer_load_b16(list_rsrc, lane_entry + 2*i0, 0, 0);
-        };
-        auto line_of = [&](const int i0, const int e) {                      // the env's line behind item i0 + lane
-            const int i = i0 + lane;
-            if (i < AL) return i + (i >= own0 ? own : 0);
-            return AF + (listed ? e : i - AL);
-        };
-        int l_next[AHEAD], e_next[AHEAD];
-        float4 w_next[AHEAD];
-        #pragma unroll
-        for (int k = 0; k < AHEAD; k++) e_next[k] = entry(k*WAVE);
-        #pragma unroll
-        for (int k = 0; k < AHEAD; k++) {
-            l_next[k] = line_of(k*WAVE, e_next[k]);
-            w_next[k] = rows.load(l_next[k]*16, 0);
-            e_next[k] = entry((k + AHEAD)*WAVE);
+            const_cast<unsigned*>(sc.wg_pool + wg_first), 0, listed ? 4*n_raw : 0, 0x00020000);
+        // the run of directions of this wave's rays, from its rightmost ray (the last live lane's) to its leftmost (lane 0's)
+        int wa8, wb8;
+        {
+            // (pseudo_angle with the reciprocal the hardware offers: the margin is 10^4 of its roundings wide)
+            const float pq_ = ry*__builtin_amdgcn_rcpf(fabsf(rx) + fabsf(ry));
+            const float pa = rx < 0.f ? 2.f - pq_ : (pq_ < 0.f ? 4.f + pq_ : pq_);
+            wg_wedge(readlane_f(pa, r_last - g*WAVE), readlane_f(pa, 0), wa8, wb8);
         }
-        PROBE_AT(2, n_items)                                                 // ... the cell's header
-        PROBE_AT(3, w_next[0].x)                                             // ... the first chunk of rows
-        for (int i0 = 0; i0 < n_items; i0 += AHEAD*WAVE) {
-            #pragma unroll
-            for (int k = 0; k < AHEAD; k++) {
-                const int ik = i0 + k*WAVE;
-                const float4 w_now = w_next[k];
-                const int l_now = l_next[k];
-                l_next[k] = line_of(ik + AHEAD*WAVE, e_next[k]);
-                w_next[k] = rows.load(l_next[k]*16, 0);
-                e_next[k] = entry(ik + 2*AHEAD*WAVE);
-                if (ik >= n_items) continue;                                 // uniform
-                admit(w_now, l_now, ik + lane < n_items, ik < AL, ik == 0);
+        auto raw = [&](const int k0) {                                       // entries k0 + lane of the list (past its end: 0)
+            return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(list_rsrc, 4*(k0 + lane), 0, 0);
+        };
+        unsigned e_next[2] = {raw(0), raw(WAVE)};
+        int raw_pos = 0, q_len = 0, al_left = AL;                            // (uniform)
+        for (;;) {
+            // fill the queue from the list
+            while ((raw_pos < n_raw) & (q_len <= Q_CAP - WAVE)) {
+                const unsigned e = e_next[0];
+                e_next[0] = e_next[1];
+                e_next[1] = raw(raw_pos + 2*WAVE);
+                const int k = raw_pos + lane;
+                const int idx = listed ? (int)(e & 0xffffu) : k;
+#ifndef MS_ARC_CULL
+#define MS_ARC_CULL 1                                                        // (0: an A/B build that queues every listed wall)
+#endif
+                const bool keep = (k < n_raw) & (!listed | !MS_ARC_CULL | wg_arcs_meet((int)((e >> 16) & 255u), (int)(e >> 24), wa8, wb8));
+                const unsigned long long km = __ballot(keep);
+                if (keep) s_queue_w[q_len + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u))] = (unsigned short)idx;
+                q_len += __popcll(km);
+                raw_pos += WAVE;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // this batch's items: what is left of the agents' lines, then the queue
+            const int al0 = AL - al_left;                                    // the first agent-line item of this batch
+            const int n_al = min(al_left, AHEAD*WAVE);
+            const int n_items = n_al + min(q_len, AHEAD*WAVE - n_al);
+            const int q_used = n_items - n_al;
+            int l_it[AHEAD];
+            float4 w_it[AHEAD];
+            #pragma unroll
+            for (int kk = 0; kk < AHEAD; kk++) {
+                const int i = kk*WAVE + lane;
+                const int ai = al0 + i;                                      // as an agent-line item
+                const int qe = (int)s_queue_w[min(max(i - n_al, 0), Q_CAP - 1)];
+                l_it[kk] = (i < n_al) ? ai + (ai >= own0 ? own : 0) : AF + qe;
+                w_it[kk] = rows.load(l_it[kk]*16, 0);
+            }
+            PROBE_AT(2, n_items)                                             // ... the cell's header
+            PROBE_AT(3, w_it[0].x)                                           // ... the first chunk of rows
+            #pragma unroll
+            for (int kk = 0; kk < AHEAD; kk++) {
+                if (kk*WAVE >= n_items) continue;                            // uniform
+                admit(w_it[kk], l_it[kk], kk*WAVE + lane < n_items, kk*WAVE < n_al, al0 + kk*WAVE == 0);
+            }
+            al_left -= n_al;
+            // what the batch did not take of the queue moves to its front
+            __builtin_amdgcn_wave_barrier();
+            if (q_used < q_len) {
+                unsigned short keep_[Q_CAP/WAVE];
+                #pragma unroll
+                for (int j = 0; j < Q_CAP/WAVE; j++) keep_[j] = s_queue_w[min(q_used + j*WAVE + lane, Q_CAP - 1)];
+                __builtin_amdgcn_wave_barrier();
+                #pragma unroll
+                for (int j = 0; j < Q_CAP/WAVE; j++) if (j*WAVE + lane < q_len - q_used) s_queue_w[j*WAVE + lane] = keep_[j];
+            }
+            q_len -= q_used;
+            if ((raw_pos >= n_raw) & (q_len == 0) & (al_left == 0)) break;
         }
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1807,6 +1885,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(6, 6)))
     }
 #endif
 
+    if constexpr (MS_ABLATE == 2 || MS_ABLATE == 3) { if (out.indices) out.indices[(size_t)fan*WAVE + lane] = nearest_idx + __float_as_int(nearest_s); return; }
     PROBE_AT(4, nearest_idx)                                             // the raycast is over
     // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
     // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
@@ -2250,11 +2329,6 @@ constexpr int BAKE_BINS = MS_BAKE_BINS;
 constexpr int BAKE_ENTRIES = 6144;           // capacity of the bins' wall lists; beyond it the pass tests every wall
 constexpr float BAKE_BIN_SCALE = BAKE_BINS/4.f;
 
-// direction of (x, y) in [0, 4): 0 along +x, 1 along +y, 2 along -x, 3 along -y; NaN at the origin
-__host__ __device__ inline float pseudo_angle(float x, float y) {
-    const float p = y/(fabsf(x) + fabsf(y));
-    return x < 0.f ? 2.f - p : (p < 0.f ? 4.f + p : p);
-}
 // bin of a point as seen from the light; -1: undecidable
 __host__ __device__ inline int bake_point_bin(P2 I, P2 C) {
     const float dx = C.x - I.x, dy = C.y - I.y;
@@ -2786,6 +2860,37 @@ __host__ __device__ inline bool wg_close(const WgCell& k, const float4 w, const 
     return !(0.9998f*(qx*qx + qy*qy) > rr*rr) | !(vx*vx + vy*vy >= 1e-8f);   // (walls too short for the reach argument: physics_kernel's meet())
 }
 
+// From which directions can wall w be seen from the cell?  The directions from the points of the cell to the points of
+// the wall are the directions of the points of the Minkowski difference wall - cell, a convex polygon spanned by (end
+// of the wall) - (corner of the cell): clear of the origin - the wall clear of the cell - they form one arc, bounded by
+// two of those eight.  Measured as pseudo-angles (pseudo_angle: monotone in the angle, antipodes exactly 2 apart, a full
+// turn 4), widened by WG_ARC_MARGIN and quantised outwards to 1/64ths: the arc runs from step lo to step hi inclusive,
+// modulo 256.  A wall that comes near the cell, or whose arc is undefined, gets the full turn (0, 255).  A ray from the
+// cell hits the wall only if its direction lies in the arc: render_kernel drops listed walls whose arc misses its rays'.
+__host__ __device__ inline void wg_arc(const WgCell& k, const float4 w, int& lo8, int& hi8) {
+    lo8 = 0; hi8 = 255;
+    const float cx = .5f*(k.x0 + k.x1), cy = .5f*(k.y0 + k.y1);
+    const float vx = w.z - w.x, vy = w.w - w.y, pqx = w.x - cx, pqy = w.y - cy;
+    float tc = -(pqx*vx + pqy*vy)/(vx*vx + vy*vy);
+    tc = fminf(fmaxf(tc, 0.f), 1.f);
+    tc = (tc == tc) ? tc : 0.f;
+    const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+    const float rr = .7072f*(k.x1 - k.x0) + 2e-2f + 1e-4f*(fabsf(cx) + fabsf(cy));
+    if (!(0.9998f*(qx*qx + qy*qy) > rr*rr)) return;                      // within a whisker of the cell (or NaN)
+    const float pr = pseudo_angle(.5f*(w.x + w.z) - cx, .5f*(w.y + w.w) - cy);   // a direction in the middle of the arc
+    const float px[4] = {k.x0, k.x1, k.x1, k.x0}, py[4] = {k.y0, k.y0, k.y1, k.y1};
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) {
+        float d = pseudo_angle((j ? w.z : w.x) - px[i], (j ? w.w : w.y) - py[i]) - pr;
+        d = d > 2.f ? d - 4.f : (d <= -2.f ? d + 4.f : d);
+        if (!(d == d)) return;
+        lo = fminf(lo, d); hi = fmaxf(hi, d);
+    }
+    if (!(hi - lo < 1.9f) || !(pr == pr)) return;                        // (an arc is less than half a turn)
+    const float a0 = pr + lo - WG_ARC_MARGIN, a1 = pr + hi + WG_ARC_MARGIN;
+    lo8 = (int)floorf(a0*64.f) & 255;
+    hi8 = (int)floorf(a1*64.f) & 255;
+}
 // The scan, one workgroup per GROUP of cells that share their candidates:
 //   * with a parent grid (coarser cells, scanned before): the cells inside one parent cell.  A wall hidden from the
 //     parent cell is hidden from every cell inside it - by the same occluder - so only the parent's vis list needs looking
@@ -2898,12 +3003,14 @@ __global__ __launch_bounds__(WG) void wallgrid_scan_kernel(const MsScenery sc, c
 }
 
 // One wavefront per (representative env, cell, list): the set bits of the cell's rows, in order, into the pools - the vis
-// list as wall indices; the near list (the walls within wg_reach_lo first, then the others) as the walls' rows themselves
-// (physics_kernel wants nothing else of them, and saves a round trip), or as indices too when near_rows is NULL (a parent
-// level for the next scan).
+// list as wall indices, each with the arc of directions the wall can be seen in from the cell (wg_arc) in its upper half;
+// the near list (the walls within wg_reach_lo first, then the others) as the walls' rows themselves (physics_kernel wants
+// nothing else of them, and saves a round trip).  A parent level for the next scan (vis_entries and near_rows NULL) gets
+// both lists as bare 16-bit indices in `pool`.
 __global__ __launch_bounds__(WG) void wallgrid_fill_kernel(const MsScenery sc, const int* __restrict__ reps,
                                                           const long long* __restrict__ bits_starts, const unsigned* __restrict__ bits,
-                                                          unsigned short* __restrict__ pool, float4* __restrict__ near_rows) {
+                                                          unsigned short* __restrict__ pool, float4* __restrict__ near_rows,
+                                                          unsigned* __restrict__ vis_entries) {
     const int lane = threadIdx.x & 63;
     const int n = reps[blockIdx.y];
     const long long item = (long long)blockIdx.x*WAVES + (threadIdx.x >> 6);
@@ -2926,7 +3033,11 @@ __global__ __launch_bounds__(WG) void wallgrid_fill_kernel(const MsScenery sc, c
             for (unsigned rest = m; rest; rest &= rest - 1) {
                 const int id = 32*(w0 + lane) + __ffs((int)rest) - 1;
                 if (kind && near_rows) near_rows[o++] = ln[id];
-                else pool[o++] = (unsigned short)id;
+                else if (!kind && vis_entries) {                             // wall | first step of its arc << 16 | last << 24
+                    int lo8, hi8;
+                    wg_arc(wg_cell_of(geom, sc.wg_cell, c), ln[id], lo8, hi8);
+                    vis_entries[o++] = (unsigned)id | ((unsigned)lo8 << 16) | ((unsigned)hi8 << 24);
+                } else pool[o++] = (unsigned short)id;
             }
             at += (unsigned)__builtin_amdgcn_readlane(incl, 63);
         }
@@ -3009,6 +3120,15 @@ void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, 
     }
 }
 
+void ms_host_wall_arc(float x0, float y0, float x1, float y1, const float* w, int* lo8, int* hi8) {
+    wg_arc(WgCell{x0, y0, x1, y1}, make_float4(w[0], w[1], w[2], w[3]), *lo8, *hi8);
+}
+int ms_host_wedge_meets(float right_x, float right_y, float left_x, float left_y, int lo8, int hi8) {
+    int wa8, wb8;
+    wg_wedge(pseudo_angle(right_x, right_y), pseudo_angle(left_x, left_y), wa8, wb8);
+    return wg_arcs_meet(lo8, hi8, wa8, wb8) ? 1 : 0;
+}
+
 static bool wallgrid_ok(const MsScenery* sc) {
     return sc->wg_starts && sc->wg_geom && sc->wg_cell > 0.f && sc->wg_reach_lo >= 0.f && sc->wg_reach >= sc->wg_reach_lo &&
            sc->wg_near > 0.f && ((uintptr_t)sc->wg_geom % 16 == 0);
@@ -3032,14 +3152,16 @@ int ms_wallgrid_scan(const MsScenery* sc, const MsWallGridParent* parent, const 
 }
 
 int ms_wallgrid_fill(const MsScenery* sc, const int* reps, int n_reps, int max_cells,
-                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, float* near_rows, void* stream) {
+                     const long long* bits_starts, const unsigned* bits, unsigned short* pool, unsigned* vis_entries, float* near_rows,
+                     void* stream) {
     if (!scenery_ok(sc) || !wallgrid_ok(sc) || !sc->wg_cells || ((uintptr_t)sc->wg_cells % 16) || !reps || n_reps < 0 || max_cells < 0 ||
-        !bits_starts || !bits || !pool || ((uintptr_t)near_rows % 16)) return MS_EINVAL;
+        !bits_starts || !bits || ((vis_entries != nullptr) != (near_rows != nullptr)) || (!pool && !vis_entries) ||
+        ((uintptr_t)near_rows % 16) || ((uintptr_t)vis_entries % 4)) return MS_EINVAL;
     if (n_reps == 0 || max_cells == 0) return MS_OK;
     const long long blocks = (2LL*max_cells + WAVES - 1)/WAVES;
     if (blocks > 0x7fffffffLL || n_reps > 65535) return MS_EUNSUPPORTED;
     hipLaunchKernelGGL(wallgrid_fill_kernel, dim3((unsigned)blocks, (unsigned)n_reps), dim3(WG), 0, (hipStream_t)stream,
-                       *sc, reps, bits_starts, bits, pool, reinterpret_cast<float4*>(near_rows));
+                       *sc, reps, bits_starts, bits, pool, reinterpret_cast<float4*>(near_rows), vis_entries);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }

@@ -389,24 +389,27 @@ class Scenery:
                     off = (both.cumsum(0) - both + base_p).view(-1, 2)
                     off_v, off_n = off[:, 0], off[:, 1]
                     add_p, add_n = int(both.sum()), 0
-                if 2*(base_p + add_p) + 16*(base_n + add_n) > self.WALL_GRID_BYTES or base_p + add_p >= 2**32 - 64 or base_n + add_n >= 2**32 \
+                if (4 if final else 2)*(base_p + add_p) + 16*(base_n + add_n) > self.WALL_GRID_BYTES or base_p + add_p >= 2**32 - 64 \
+                        or base_n + add_n >= 2**32 \
                         or int(n_near.max()) > 65535:
                     return None
                 cell_rows[rows] = torch.stack([off_v, n_vis, off_n, cnt[:, 1] + (n_near << 16)], 1)
                 hdr = _as_u32(cell_rows)
-                pool = torch.zeros(add_p + 64, dtype=torch.int16, device=dev)
+                # (final level: vis entries of 32 bits - wall and view arc; a parent level: bare 16-bit wall numbers)
+                pool = torch.zeros(add_p + 64, dtype=torch.int32 if final else torch.int16, device=dev)
                 near = torch.zeros((max(add_n, 1), 4), dtype=torch.float32, device=dev) if final else None
                 struct.wg_cells = hdr.data_ptr()
                 # the fill kernel writes at the headers' offsets: hand it this group's pools displaced by what came before
                 _lib.check(h.ms_wallgrid_fill(C.byref(struct), r32.data_ptr(), len(r), mc, bits_starts.data_ptr(), bits.data_ptr(),
-                                              C.c_void_p(pool.data_ptr() - 2*base_p),
+                                              None if final else C.c_void_p(pool.data_ptr() - 2*base_p),
+                                              C.c_void_p(pool.data_ptr() - 4*base_p) if final else None,
                                               C.c_void_p(near.data_ptr() - 16*base_n) if final else None, _stream(dev)))
                 torch.cuda.current_stream(dev).synchronize()           # (hdr / bits / pools of this group are done with)
                 pools.append(pool[:add_p])
                 if final:
                     nears.append(near[:add_n])
                 base_p, base_n = base_p + add_p, base_n + add_n
-        pool = torch.cat(pools + [torch.zeros(64, dtype=torch.int16, device=dev)])
+        pool = torch.cat(pools + [torch.zeros(64, dtype=pools[0].dtype, device=dev)])
         near = torch.cat(nears + [torch.zeros((1, 4), dtype=torch.float32, device=dev)]) if final else None
         return _as_u32(cell_rows), starts, geom, pool, near, cells.to(torch.int32)
 

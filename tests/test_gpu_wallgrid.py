@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from tests import util
-from tests.test_wallgrid import scan_cell, NEAR, REACH, REACH_LO
+from tests.test_wallgrid import scan_cell, wall_arc, NEAR, REACH, REACH_LO
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +31,7 @@ def test_lists_built_on_the_gpu_are_the_host_scans():
     cells, starts, geom, cell, reach_lo, reach, near, pool, rows = sc._wg
     assert (reach_lo, reach, near) == tuple(np.float32([REACH_LO, REACH, NEAR]).astype(float)) or (reach_lo, reach, near) == (REACH_LO, REACH, NEAR)
     cells = cells.cpu().numpy().view(np.uint32)
-    starts, geom, pool, rows = starts.cpu().numpy(), geom.cpu().numpy(), pool.cpu().numpy().view(np.uint16), rows.cpu().numpy()
+    starts, geom, pool, rows = starts.cpu().numpy(), geom.cpu().numpy(), pool.cpu().numpy().view(np.uint32), rows.cpu().numpy()
     AF = sc.n_agents*sc.model.shape[0]
     rng = np.random.RandomState(0)
     # envs of one floorplan share their cells
@@ -46,7 +46,9 @@ def test_lists_built_on_the_gpu_are_the_host_scans():
             n_lo, n_all = nn & 0xffff, nn >> 16
             # built through the coarse level: nothing the one-level scan lists may be missing, and next to nothing more
             # (an occluder the coarse cell's list lacks has a stand-in on it, which the thresholds may judge differently)
-            got = pool[v0:v0 + vn]
+            got, arcs = pool[v0:v0 + vn] & 0xffff, pool[v0:v0 + vn] >> 16
+            for e_, arc in zip(got[::7], arcs[::7]):                      # every entry carries its wall's view arc from this cell
+                assert (arc & 255, arc >> 8) == wall_arc(walls[e_], origin, dims, c_, cell)
             assert set(np.nonzero(vis)[0]) <= set(got) and len(got) <= 1.03*vis.sum() + 2 and (np.diff(got.astype(int)) > 0).all()
             excess.append(len(got) - vis.sum())
             want = np.concatenate([walls[close == 2], walls[close == 1]]).reshape(-1, 4)
@@ -110,7 +112,7 @@ def test_where_the_lists_do_not_apply_every_wall_is_met():
 def test_a_grid_too_big_for_its_budget_is_coarsened_or_left_out(monkeypatch):
     from megastep_amd import cuda
     c, _ = _world(4, 1, n_unique=2)
-    needed = 2*c.scenery._wg[7].numel() + 4*c.scenery._wg[8].numel()
+    needed = 4*c.scenery._wg[7].numel() + 4*c.scenery._wg[8].numel()
     monkeypatch.setattr(cuda.Scenery, 'WALL_GRID_BYTES', needed//2)
     c, _ = _world(4, 1, n_unique=2)
     assert c.scenery._wg is not None and c.scenery._wg[3] > cuda.Scenery.WALL_GRID_CELL
@@ -121,3 +123,27 @@ def test_a_grid_too_big_for_its_budget_is_coarsened_or_left_out(monkeypatch):
     assert c.scenery._wg is None
     ref = util.OracleWorld(c)
     util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())
+
+
+def test_more_agents_than_lanes_take_the_sweep():
+    """The near lists are dealt a lane per agent: an env with more than 64 agents meets its walls through the sweep, every
+    agent of it - the last ones too (which a first version of the kernel forgot; the fuzz found it)."""
+    from megastep_amd import core, cuda, scene, toys
+    sc = scene.scenery([toys.box(8), toys.box(8)], 70, device='cuda', random=np.random.RandomState(0))
+    assert sc._wg is not None
+    c = core.Core(sc, res=8, fov=130)
+    rng = np.random.RandomState(3)
+    # everyone close to a wall of the 8 m box (walls at 1 and 9) and heading for it
+    side = rng.randint(0, 4, (2, 70))
+    along = rng.uniform(1.5, 8.5, (2, 70))
+    near, far = np.where(side % 2 == 0, 1.3, 8.7), along
+    pos = np.where((side < 2)[..., None], np.stack([near, far], -1), np.stack([far, near], -1)).astype(np.float32)
+    vel = np.where((side < 2)[..., None], np.stack([np.where(side % 2 == 0, -3., 3.), rng.uniform(-1, 1, (2, 70))], -1),
+                   np.stack([rng.uniform(-1, 1, (2, 70)), np.where(side % 2 == 0, -3., 3.)], -1)).astype(np.float32)
+    c.agents.positions[:] = torch.as_tensor(pos, device='cuda')
+    c.agents.velocity[:] = torch.as_tensor(vel, device='cuda')
+    ref = util.OracleWorld(c)
+    p = cuda.physics(c.scenery, c.agents)
+    prog_ref, agents_ref = ref.physics()
+    util.assert_physics_matches(c, p, prog_ref, agents_ref)
+    assert (prog_ref[:, 64:] < 1).any() and (prog_ref < 1).mean() > .5

@@ -26,6 +26,16 @@ def scan_cell(walls, origin, dims, c, cell=CELL):
     return vis.astype(bool), close
 
 
+def wall_arc(wall, origin, dims, c, cell=CELL, slack=.01):
+    """(first step, last step) of the run of directions the library says `wall` can be seen in from cell c."""
+    x0, y0 = origin[0] + (c % dims[0])*cell - slack, origin[1] + (c//dims[0])*cell - slack
+    lo, hi = C.c_int(), C.c_int()
+    w = (C.c_float*4)(*np.asarray(wall, np.float32).reshape(4))
+    _lib.lib().ms_host_wall_arc(np.float32(x0), np.float32(y0), np.float32(x0) + np.float32(cell + 2*slack),
+                                np.float32(y0) + np.float32(cell + 2*slack), w, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
 def grid_of(walls, cell=CELL):
     """Origin and dims as cuda.Scenery._build_wall_grid lays them out."""
     fin = walls[np.isfinite(walls).all((1, 2))]
@@ -159,3 +169,42 @@ def test_one_wall_hides_another_only_when_it_really_does():
     nan = float('nan')
     assert not hidden(cell, (2., nan, 2., 3.), target) and not hidden(cell, wide, (4., nan, 4., .5))
     assert not hidden(cell, wide, (4., -.5, 4., -.5 + 1e-30))
+
+
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'large', 'box'])
+def test_a_wall_is_only_ever_seen_inside_its_arc(name):
+    """The view arcs the vis entries carry (wg_arc) and the test the render kernel makes with them (wg_wedge,
+    wg_arcs_meet): whenever a ray from a point of the cell can hit a wall at all - its direction is that of some point of
+    the wall - a wave whose fan holds that ray keeps the wall, however narrow the fan; and most walls are dropped by a
+    narrow fan looking elsewhere."""
+    walls = case_walls(name)
+    rng = np.random.RandomState(4)
+    origin, dims = grid_of(walls)
+    meets = _lib.lib().ms_host_wedge_meets
+    kept = []
+    for c in rng.choice(dims[0]*dims[1], 12, replace=False):
+        x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
+        for t in rng.choice(len(walls), min(len(walls), 40), replace=False):
+            lo, hi = wall_arc(walls[t], origin, dims, c)
+            if not np.isfinite(walls[t]).all():
+                assert (lo, hi) == (0, 255)
+                continue
+            for _ in range(12):
+                p = np.array([x0, y0]) + rng.choice([0., 1., rng.uniform()], 2)*CELL      # corners and edges too
+                q = walls[t, 0] + rng.choice([0., 1., rng.uniform()])*(walls[t, 1] - walls[t, 0])
+                d = (q - p).astype(np.float64)
+                if not np.abs(d).sum() > 1e-6:
+                    continue
+                # fans around that direction: a single ray, a sliver, a third of a turn
+                for half in (0., 1e-3, .3, 1.):
+                    rot = lambda v, a: np.array([v[0]*np.cos(a) - v[1]*np.sin(a), v[0]*np.sin(a) + v[1]*np.cos(a)])
+                    off = rng.uniform(-half, half)
+                    right, left = rot(d, off - half), rot(d, off + half)
+                    assert meets(*np.float32(right), *np.float32(left), lo, hi), (name, c, t)
+            # a 30-degree fan looking the other way
+            away = -(walls[t].mean(0) - np.array([x0 + CELL/2, y0 + CELL/2]))
+            if np.abs(away).sum() > 1.:
+                rot = lambda v, a: np.array([v[0]*np.cos(a) - v[1]*np.sin(a), v[0]*np.sin(a) + v[1]*np.cos(a)])
+                kept.append(meets(*np.float32(rot(away, -.26)), *np.float32(rot(away, .26)), lo, hi))
+    if name != 'box':
+        assert np.mean(kept) < .2, f'{np.mean(kept):.2f} of the walls behind a fan are kept'
