@@ -167,7 +167,8 @@ def test_light_grid_shard_repacks_candidate_lists():
     for start, stop in [(0, 2), (1, 4), (2, 3), (0, 4)]:
         v, s, g, cell, mx, l, p = sharding._shard_light_grid(lg, start, stop, 'cpu')
         c0, c1 = int(starts[start]), int(starts[stop]) if stop < 4 else total
-        assert torch.equal(v, vals[c0:c1]) and torch.equal(g, geom[start:stop]) and cell == .25
+        assert torch.equal(v[:-1], vals[c0:c1]) and not v[-1].any() and torch.equal(g, geom[start:stop]) and cell == .25    # (+ the padding row)
+        assert len(l) == len(v)
         assert s.tolist() == (starts[start:stop] - c0).tolist() and mx == int(cells[start:stop].max())
         l64, p64 = l.long() & 0xffffffff, p.long() & 0xffffffff
         assert int(p64[0]) == len(p) - 1
