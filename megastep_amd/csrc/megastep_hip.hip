@@ -1,28 +1,35 @@
 // megastep_hip.hip -- gfx950 (MI355X / CDNA4) simulation core behind include/megastep_hip.h.
 //
-// Nine kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
+// Eleven kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
 //
-//   physics_kernel<MOVE, EXTRA>   one wavefront per env: wall chunks requested up front (buffer loads), lane = agent
-//                   for the state and the agent-agent tests, lane = wall for a reach-box prefilter (the boxes of up to
-//                   four agents in scalar registers), compacted (wall, agent) pairs for the exact collision test,
-//                   atomicMin fold, integration epilogue; leaves each agent's sin/cos for the renderer.  MOVE = 1 runs
-//                   the movement modules' velocity update first, EXTRA = 1 the envs' respawn / lifespan / IMU bookkeeping.
+//   physics_kernel<MOVE, EXTRA>   one wavefront per env: lane = agent for the state, the reach and the agent-agent
+//                   tests; the walls from the near lists of the agents' cells of the wall grid (rows of the dozen walls
+//                   within reach, dealt to the lanes one (wall, agent) pair each) - or, where no list applies, a sweep
+//                   over all the env's walls (buffer loads in flight, lane = wall, reach boxes in scalar registers,
+//                   compacted pairs); the exact collision test, atomicMin fold, integration epilogue; leaves each
+//                   agent's sin/cos for the renderer.  MOVE = 1 runs the movement modules' velocity update first,
+//                   EXTRA = 1 the envs' respawn / lifespan / IMU bookkeeping.
 //                                                            (reference: kernels.cu:179-230, modules.py:24-118,263-366)
-//   render_kernel<IMPL, RW, OBS>   one wavefront per (env, agent, 64-ray group).  Pass 1 (lane = line) turns every
-//                   line into a conservative interval of the wave's rays and compacts the visible ones into an LDS
-//                   list; pass 2 deals the (line, ray) pairs of the list to the lanes, 64 at a time, one exact
-//                   intersection each, merged per ray with one 64-bit LDS atomic; the order-dependent nearest-hit rule
-//                   is resolved from the three smallest keys (or a literal fold where it must be); rays that landed on
-//                   an agent are lit through the light grid; shading; optional pooled observations, crosshair ids and
-//                   first-sight books.  draw, raycast and shader (three launches + five allocations in the reference)
-//                   are one launch.  IMPL = 2 is the default; 1 (per-chunk pair windows) and 0 (literal order) are kept
-//                   for A/B runs and produce the same bits.     (reference: kernels.cu:297-475)
+//   render_kernel<IMPL, RW, OBS>   one wavefront per (env, agent, 64-ray group).  The lines it meets: the other agents'
+//                   and the walls on the vis list of the agent's cell of the wall grid, less those whose view arc misses
+//                   the wave's rays.  Pass 1 (lane = line) turns every line into a conservative interval of the wave's
+//                   rays and compacts the visible ones into an LDS list; pass 2 deals the (line, ray) pairs of the list
+//                   to the lanes, 64 at a time, one exact intersection each, merged per ray with one 64-bit LDS atomic;
+//                   the order-dependent nearest-hit rule is resolved from the three smallest keys (or a literal fold
+//                   where it must be); rays that landed on an agent are lit through the light grid; shading; optional
+//                   pooled observations, crosshair ids and first-sight books.  draw, raycast and shader (three launches +
+//                   five allocations in the reference) are one launch.  IMPL = 2 is the product; 1 (per-chunk pair
+//                   windows) and 0 (literal order, every line) exist in -DMS_AB_IMPLS=1 builds for A/B runs and produce
+//                   the same bits.                               (reference: kernels.cu:297-475)
 //   render_prep_kernel, dynlight_kernel   the renderer's helpers for callers without a heading cache / light grid.
 //   visibility_kernel, bake_sum_kernel    the two-phase bake: per (representative env, light) the walls that can shadow
 //                   each angular bin; per texel the sum over the lights, occluders looked up by bin.
 //   bake_kernel     the one-pass bake: one workgroup per env, lane = texel, the env's occluders staged once in LDS.
 //                                                            (reference: kernels.cu:238-293)
 //   lightgrid_kernel, lightlist_kernel   per (cell, light) LIT / DARK / UNKNOWN verdicts and candidate walls.
+//   wallgrid_scan_kernel, wallgrid_fill_kernel   the wall grid: per cell of a floorplan which walls can matter to a ray
+//                   from the cell (one wall hiding another from the whole cell, exactly) and which an agent in it can
+//                   touch; and the lists made of that.   (replaces the all-lines loops kernels.cu:203-205,352-377)
 //
 // Numerics contract: IEEE binary32 evaluated as the reference source is written -- compiled with
 // -ffp-contract=off, correctly rounded divide/sqrt, no fast-math -- so that collision masks and hit
@@ -1048,7 +1055,7 @@ __device__ inline void ray_interval(float xa, float ya, float xb, float yb, cons
 }
 
 // IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
-// IMPL 1 ("pairs", default): (line, ray) pairs flattened over all 64 lanes + LDS atomic argmin; rays whose
+// IMPL 1 ("pairs"): (line, ray) pairs flattened over all 64 lanes + LDS atomic argmin; rays whose
 //          two best hits sit inside the 1e-4 hysteresis band get the sequential fold.  Same bits, ~2x faster.
 // RW = waves per workgroup.  The waves never talk to each other, so RW = 1 lets every wave give its slot and
 // LDS back the moment it is done instead of waiting for the slowest of four.

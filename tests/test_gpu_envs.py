@@ -273,3 +273,25 @@ def test_first_sight_bookkeeping_in_the_render_kernel():
     assert memory.count.min() > 20
     gained = memory.gained()
     assert (gained >= 0).all() and memory.gained().sum() == 0
+
+
+def test_env_steps_replayed_as_a_hip_graph():
+    """graphs.GraphedStep: the captured step takes the actions it is given, moves the world on and keeps producing sane
+    observations; an env whose agents all hold still under the no-op action does so under the graph too."""
+    from megastep_amd import arrdict, cubicasa, graphs
+    from megastep_amd.demo import Explorer
+    geometries = cubicasa.sample(16, n_unique=16)
+    env = graphs.GraphedStep(Explorer(16, geometries=geometries))
+    env.reset()
+    before = env.core.agents.positions.clone()
+    forward = arrdict.arrdict(actions=torch.ones((16, 1), dtype=torch.long, device='cuda'))
+    for _ in range(4):
+        world = env.step(forward)
+    moved = (env.core.agents.positions - before).norm(dim=-1)
+    assert (moved > .05).float().mean() > .5 and torch.isfinite(world.obs.rgb).all() and world.obs.rgb.shape == (16, 1, 3, 1, 64)
+    noop = arrdict.arrdict(actions=torch.zeros((16, 1), dtype=torch.long, device='cuda'))
+    for _ in range(60):
+        env.step(noop)                                                     # momentum decays away
+    at_rest = env.core.agents.positions.clone()
+    env.step(noop)
+    assert (env.core.agents.positions - at_rest).norm(dim=-1).max() < 2e-3
