@@ -341,6 +341,9 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     // this stream is what the kernel used to last.)
     const LineRows rows(ln, L);
     const bool gridded = sc.wg_cells != nullptr;                         // (the same for every wave of the launch)
+    float4 wg_geom_n = make_float4(0.f, 0.f, 0.f, 0.f);                  // (the env's row of the wall grid, asked for with its other rows)
+    int wg_start_n = 0;
+    if (gridded) { wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n]; wg_start_n = sc.wg_starts[n]; }
     float4 w[PHYS_AHEAD];
     #pragma unroll
     for (int k = 0; k < PHYS_AHEAD; k++) w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -472,12 +475,12 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         int count = 0;
         bool ok = A <= WAVE;
         if (lane < A) {
-            const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+            const float4 geom = wg_geom_n;
             const float inv_cell = __builtin_amdgcn_rcpf(sc.wg_cell);
             const float4 me = s_task[lane];
             const float fx = floorf((me.x - geom.x)*inv_cell), fy = floorf((me.y - geom.y)*inv_cell);
             const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);   // (NaNs: outside)
-            const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[sc.wg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0)];
+            const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[wg_start_n + (inside ? (int)fy*(int)geom.z + (int)fx : 0)];
             ok = (A <= WAVE) & inside & (my_reach <= sc.wg_reach);       // (a lane per agent: more than 64 of them take the sweep)
             first = hdr.z;
             count = ok ? (int)((my_reach <= sc.wg_reach_lo) ? (hdr.w & 0xffffu) : (hdr.w >> 16)) : 0;
@@ -1127,6 +1130,13 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
 
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
+    // (the env's row of the wall grid is asked for here, with the env's other rows: where it is used - once the agent's
+    // position is known - it would be one more round trip in the chain position -> cell -> list -> walls)
+    float4 wg_geom_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    int wg_start_n = 0;
+    if constexpr (IMPL == 2) {
+        if (sc.wg_cells) { wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n]; wg_start_n = sc.wg_starts[n]; }
+    }
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
     const LineRows rows(ln, L);
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
@@ -1195,12 +1205,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     int wg_count = -1;
     if constexpr (IMPL == 2) {
         if (sc.wg_cells) {                                                  // (the same for every wave of the launch)
-            const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+            const float4 geom = wg_geom_n;
             const float inv_cell = __builtin_amdgcn_rcpf(sc.wg_cell);       // (cells are grown by a centimetre: an ulp is nothing)
             const float fx = floorf((pp.x - geom.x)*inv_cell), fy = floorf((pp.y - geom.y)*inv_cell);
             const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);    // (NaNs, an env without a grid: outside)
             // every wave reads a header that exists - its cell's, or the row at its env's start (the array is padded by one)
-            const int cell_id = __builtin_amdgcn_readfirstlane(sc.wg_starts[n] + (inside ? (int)fy*(int)geom.z + (int)fx : 0));
+            const int cell_id = __builtin_amdgcn_readfirstlane(wg_start_n + (inside ? (int)fy*(int)geom.z + (int)fx : 0));
             const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[cell_id];
             wg_first = inside ? hdr.x : 0u;
             wg_count = inside ? (int)hdr.y : -1;
