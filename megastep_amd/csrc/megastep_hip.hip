@@ -333,17 +333,17 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
 
     const int L = sc.lines_widths[n];
     const float4* __restrict__ ln = reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n];
-    // the first wall chunks are requested before anything else: nothing below depends on them until the sweep, and on
-    // large maps the stream of walls is what the kernel lasts (asking for the agents first cost 12 % there).
-    // (Unconditional loads - behind a branch hipcc waits for every load in flight at the first use of any of them;
-    // lanes past the last wall read zeros and are masked by `live` in the sweep.)
-    // (With a wall grid the walls come from the agents' cells instead, and nothing is asked for here: on large maps
-    // this stream is what the kernel used to last.)
+    // Without a wall grid the first wall chunks are requested before anything else: nothing below depends on them until
+    // the sweep, and on large maps the stream of walls is what that path lasts (unconditional buffer loads: lanes past the
+    // last wall read zeros and are masked by `live` in the sweep).  With a grid the walls come from the agents' cells
+    // instead, and nothing is asked for here.
     const LineRows rows(ln, L);
     const bool gridded = sc.wg_cells != nullptr;                         // (the same for every wave of the launch)
-    float4 wg_geom_n = make_float4(0.f, 0.f, 0.f, 0.f);                  // (the env's row of the wall grid, asked for with its other rows)
-    int wg_start_n = 0;
-    if (gridded) { wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n]; wg_start_n = sc.wg_starts[n]; }
+    // (the env's row of the wall grid, asked for with its other rows - where it is used, once the agents' positions are
+    // known, it would be one more round trip; unconditionally: without a grid ms_step_physics points the two at rows
+    // that exist)
+    const float4 wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+    const int wg_start_n = sc.wg_starts[n];
     float4 w[PHYS_AHEAD];
     #pragma unroll
     for (int k = 0; k < PHYS_AHEAD; k++) w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -351,8 +351,9 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         #pragma unroll
         for (int k = 0; k < PHYS_AHEAD; k++) w[k] = rows.chunk(lane, AF + k*WAVE);
     }
-    // one lane per agent: its state (kept for the epilogue).  (Behind a guard on purpose: everything requested before it
-    // has arrived by the time it is used, which measured no worse at 300 walls and 4 % better at 1000.)
+    // one lane per agent: its state (kept for the epilogue).  (Behind a guard on purpose: asked for by every lane, the
+    // last agent's re-read by the idle ones - which lets hipcc batch these loads with the env's rows - measured 8 % slower
+    // at the headline shape and 7 % on 1000-wall maps.)
     float2 my_p, my_v;
     float my_w, my_ang;
     my_p = make_float2(0.f, 0.f); my_v = make_float2(0.f, 0.f); my_w = 0.f; my_ang = 0.f;
@@ -1115,12 +1116,15 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     __builtin_amdgcn_wave_barrier();
     const int fan = lb;
 #else
-    const int nb = gridDim.x, b = blockIdx.x;
+    // (With one wave per workgroup the grid is exactly the fans - ms_render launches it so: the count comes from the
+    // kernel's own arguments, not from the dispatch packet, and there is no early exit - either of which is a round trip
+    // of its own before the loads below may even be asked for.)
+    const int nb = RW == 1 ? n_fans : (int)gridDim.x, b = blockIdx.x;
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
-    const int lb = (xcd < r8 ? xcd*(q8 + 1) : r8*(q8 + 1) + (xcd - r8)*q8) + ix;
-
+    const int lb = xcd*q8 + min(xcd, r8) + ix;      // (XCDs 0..r8-1 get a block more; no branch: a branch ends the stretch of
+                                                    //  code hipcc gathers the kernel-argument loads of to its top)
     const int fan = lb*RW + wave;
-    if (fan >= n_fans) return;                   // waves are independent: no workgroup barriers below
+    if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
 #endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
@@ -1132,11 +1136,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const int base = sc.lines_starts[n];
     // (the env's row of the wall grid is asked for here, with the env's other rows: where it is used - once the agent's
     // position is known - it would be one more round trip in the chain position -> cell -> list -> walls)
-    float4 wg_geom_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    int wg_start_n = 0;
-    if constexpr (IMPL == 2) {
-        if (sc.wg_cells) { wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n]; wg_start_n = sc.wg_starts[n]; }
-    }
+    // (Unconditionally: ms_render points wg_geom / wg_starts at rows that exist when there is no grid, so that these two
+    // are part of the one batch of loads and not the body of a branch with a round trip of its own.)
+    const float4 wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n];
+    const int wg_start_n = sc.wg_starts[n];
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
     const LineRows rows(ln, L);
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
@@ -3202,10 +3205,12 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
     const MsStepExtras no_extras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
     const MsMovement mvv = mv ? *mv : no_move;
     const MsStepExtras exv = ex ? *ex : no_extras;
+    MsScenery scn = *sc;
+    if (!sc->wg_cells) { scn.wg_geom = sc->lines_vals; scn.wg_starts = sc->lines_starts; }   // (rows the kernel may read: see there)
     const hipStream_t hs = (hipStream_t)stream;
     // one wavefront per env (several envs per wave, one after the other: 2 -> +25 %, 4 -> +85 % at 4096 envs)
 #define MS_LAUNCH_PHYSICS(M, E) \
-    hipLaunchKernelGGL((physics_kernel<M, E>), dim3(sc->n_envs), dim3(WAVE), slice*16, hs, *sc, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv)
+    hipLaunchKernelGGL((physics_kernel<M, E>), dim3(sc->n_envs), dim3(WAVE), slice*16, hs, scn, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv)
     if (mv && ex) MS_LAUNCH_PHYSICS(1, 1);
     else if (ex) MS_LAUNCH_PHYSICS(0, 1);
     else if (mv) MS_LAUNCH_PHYSICS(1, 0);
@@ -3256,8 +3261,12 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // longer than sqrt(WG_MAX_RU2) (wallgrid_scan_kernel); a call outside that meets every wall instead
     const bool walls_listed = sc->wg_cells && sc->wg_starts && sc->wg_geom && sc->wg_pool && sc->wg_cell > 0.f &&
                               cfg->agent_radius*1.001f < sc->wg_near && 1.f + half_screen*half_screen <= WG_MAX_RU2;
-    if (!walls_listed) scn.wg_cells = nullptr;
-    else if (((uintptr_t)sc->wg_cells % 16) || ((uintptr_t)sc->wg_geom % 16)) return MS_EINVAL;
+    if (walls_listed && (((uintptr_t)sc->wg_cells % 16) || ((uintptr_t)sc->wg_geom % 16))) return MS_EINVAL;
+    if (!walls_listed) {                                                 // (the kernel reads a row of each whatever happens: see there)
+        scn.wg_cells = nullptr;
+        scn.wg_geom = sc->lines_vals;                                    // at least 16 bytes per env: every env has its agents' lines
+        scn.wg_starts = sc->lines_starts;
+    }
     // Headings: from ms_physics' cache when the agents carry one and a single kernel does the whole job (then the
     // workspace is not needed at all); otherwise from render_prep_kernel, which also resets the workspace's counters.
     MsAgents agn = *ag;
