@@ -207,3 +207,23 @@ def test_seen_texel_books_follow_the_reference_bookkeeping():
         np.testing.assert_array_equal(books.mask().view(F, per_env).numpy(), seen)
         assert (books.spare.numpy()[respawn] == 0).all() and (books.gained() == 0).all()
     assert potential.max() > 10
+
+
+def test_an_imu_reading_taken_inside_the_physics_launch_goes_stale_with_the_agents():
+    """modules.IMU hands out the reading the physics launch took (`_pending`) only while nobody has touched the agents
+    since: a respawn through the modules' helpers, or another physics call, moves the agents' epoch on and the reading
+    is worked out afresh (round 2's advisor: a reset between mover(..., imu=) and imu() returned the old observation)."""
+    from megastep_amd import core, modules, scene, toys
+    sc = scene.scenery(3*[toys.box()], 2, device='cpu', bake=False)
+    c = core.Core(sc, res=8)
+    c.agents.velocity[:] = torch.tensor([1., 2.])
+    c.agents.angvelocity[:] = 90.
+    imu = modules.IMU(c)
+    fresh = imu().clone()
+    stale = torch.full_like(fresh, 7.)
+    imu._pending = (stale, c.agents._epoch)                              # as _move leaves it after a fused physics call
+    assert torch.equal(imu(), stale) and imu._pending is None
+    imu._pending = (stale, c.agents._epoch)
+    spawns = modules.RandomSpawns(3*[toys.box()], c)
+    spawns(c.agent_full(True))                                           # a respawn with tensor ops: velocities are zero now
+    assert c.agents._epoch > 0 and torch.equal(imu(), torch.zeros_like(fresh))
