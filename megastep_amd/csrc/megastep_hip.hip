@@ -674,7 +674,7 @@ struct LightScene {                   // what grid_light_intensity reads of an M
 __device__ inline float grid_light_intensity(
         const LightScene sc, const MsAgents& ag, const int n, const int lane, const bool dynamic, const int nearest_idx,
         const float cx_l, const float cy_l, const int L, const float4* __restrict__ ln,
-        LightPair* s_pair, unsigned* s_shadow) {
+        LightPair* s_pair, unsigned* s_shadow, unsigned& telemetry) {
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int n_lights = sc.lights_widths[n];
     const bool MANY = n_lights > WAVE;                                   // (uniform)
@@ -737,6 +737,8 @@ __device__ inline float grid_light_intensity(
     const bool need = dynamic & !saturated & has_unk;
     // Everyone else is done: with no light left open the reference's in-order sum over the unblocked lights IS `part`
     if (!__ballot(need)) return MANY ? acc_in : (saturated ? 1.f : ms_min(part, 1.f));
+    // (`telemetry`, for the probe build only: rays with open lights, of them without a list, lists, rounds of pairs, lights)
+    telemetry = 0x80000000u | (unsigned)__popcll(__ballot(need)) | ((unsigned)min(ni, 63) << 25);
 
     // ---- the rest is the rare path: rays with lights the grid leaves open
     auto status = [&](int i) {                   // light i's 2-bit verdict for this ray's cell; i is wave-uniform
@@ -745,41 +747,62 @@ __device__ inline float grid_light_intensity(
     };
     unsigned long long shadow = 0ull;            // open lights the walls turn out to block
     // (1) rays whose cell has a candidate list: only those (light, wall) pairs can matter anywhere in the cell.
-    // All the wave's (ray, candidate) pairs are laid end to end and dealt to the lanes, 64 at a time, so that the
-    // dependent loads (candidate -> wall) are paid once per round rather than once per candidate.
+    // Rays on one target mostly share a cell, hence a list: per distinct list its candidates are fetched once, lane =
+    // candidate (entry, then the wall's row: the only dependent loads, whatever the number of rays), and left in LDS
+    // with their light's position; the list's (ray, candidate) pairs are then laid end to end and dealt to the lanes,
+    // 64 at a time, which read their candidate from LDS.  (Before: every pair fetched entry and wall itself, two
+    // dependent round trips to cold lines per 64 pairs.)
     const bool sweep = need & (lst.y == 0u);     // no list (outside the grid, pool exhausted, ...): all the walls
     const int n_cd = (need & !sweep) ? (int)(lst.y & 0x7fffffffu) : 0;
+    telemetry |= (unsigned)__popcll(__ballot(sweep)) << 7;
     if (__ballot(n_cd > 0)) {
         s_shadow[2*lane] = 0u; s_shadow[2*lane + 1] = 0u;
-        int pj = -1, pk = 0, fill = 0;           // this lane's pair: ray, candidate; lanes dealt so far
-        auto round = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int src = max(pj, 0);
-            const int at = __shfl((int)lst.x, src, WAVE) + pk;
-            const P2 C = p2(__shfl(cx_l, src, WAVE), __shfl(cy_l, src, WAVE));
-            if (pj >= 0) {
-                const unsigned e = sc.lg_pool[at];
-                const int i = (int)((e >> 24) & 63u);
-                const float4 w = ln[AF + (int)(e & 0xffffffu)];
-                const P2 I = p2(lights[3*i], lights[3*i + 1]);
-                if (light_blocked(I, C - I, w.x, w.y, w.z - w.x, w.w - w.y)) atomicOr(&s_shadow[2*pj + (i >> 5)], 1u << (i & 31));
-            }
-            pj = -1; fill = 0;
-        };
-        for (unsigned long long rays = __ballot(n_cd > 0); rays; rays &= rays - 1) {
-            const int j = __ffsll((long long)rays) - 1;
-            const int c = __builtin_amdgcn_readlane(n_cd, j);
-            for (int k0 = 0; k0 < c; ) {
-                const int take = min(c - k0, WAVE - fill);
-                if ((lane >= fill) & (lane < fill + take)) { pj = j; pk = k0 + lane - fill; }
-                fill += take; k0 += take;
-                if (fill == WAVE) round();
+        for (unsigned long long lists = __ballot(n_cd > 0); lists; ) {
+            const int j0 = __ffsll((long long)lists) - 1;
+            const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)lst.x, j0);
+            const int c = __builtin_amdgcn_readlane(n_cd, j0);
+            const unsigned long long members = __ballot((n_cd > 0) & (lst.x == first));
+            lists &= ~members;
+            telemetry += 1u << 14;
+            for (int c0 = 0; c0 < c; c0 += LG_PAIRS) {
+                const int nc = min(LG_PAIRS, c - c0);
+                {
+                    const unsigned e = sc.lg_pool[first + (unsigned)(c0 + min(lane, nc - 1))];
+                    const int i = (int)((e >> 24) & 63u);
+                    const float4 w = ln[AF + (int)(e & 0xffffffu)];
+                    const float ix = __shfl(Ix, i, WAVE), iy = __shfl(Iy, i, WAVE);
+                    __builtin_amdgcn_wave_barrier();                     // (the last batch's readers are through)
+                    if (lane < nc) s_pair[lane] = LightPair{w.x, w.y, w.z - w.x, w.w - w.y, ix, iy, i, 0};
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                int pj = -1, pk = 0, fill = 0;       // this lane's pair: ray, candidate of the batch; lanes dealt so far
+                auto round = [&]() {
+                    const int src = max(pj, 0);
+                    const P2 C = p2(__shfl(cx_l, src, WAVE), __shfl(cy_l, src, WAVE));
+                    const LightPair pr = s_pair[pk];
+                    const P2 I = p2(pr.ix, pr.iy);
+                    if ((pj >= 0) && light_blocked(I, C - I, pr.ax, pr.ay, pr.vx, pr.vy))
+                        atomicOr(&s_shadow[2*pj + (pr.light >> 5)], 1u << (pr.light & 31));
+                    pj = -1; pk = 0; fill = 0;
+                    telemetry += 1u << 18;
+                };
+                for (unsigned long long rays = members; rays; rays &= rays - 1) {
+                    const int j = __ffsll((long long)rays) - 1;
+                    for (int k0 = 0; k0 < nc; ) {
+                        const int take = min(nc - k0, WAVE - fill);
+                        if ((lane >= fill) & (lane < fill + take)) { pj = j; pk = k0 + lane - fill; }
+                        fill += take; k0 += take;
+                        if (fill == WAVE) round();
+                    }
+                }
+                if (fill) round();
             }
         }
-        if (fill) round();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (n_cd > 0) shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
         __builtin_amdgcn_wave_barrier();
     }
@@ -858,14 +881,31 @@ __device__ inline float grid_light_intensity(
         if (sweep) shadow = ((unsigned long long)s_shadow[2*lane + 1] << 32) | s_shadow[2*lane];
         __builtin_amdgcn_wave_barrier();
     }
-    // (3) the reference's sum (kernels.cu:261-267) in light order: the grid's verdict where it has one, else the walls'
+    // (3) the reference's sum (kernels.cu:261-267) in light order: the grid's verdict where it has one, else the walls'.
+    // Only over the lights that some open ray's cell does not call DARK (86 % of verdicts are): one pass per distinct
+    // verdict word set collects them, as for `part` above.  (The sum used to visit every light, a divide each: with
+    // two or three open rays in a wave and sixteen lights it was most of what the launch's last waves were doing.)
+    unsigned cand[4] = {0u, 0u, 0u, 0u};         // (uniform) low bit of field i set: light i is LIT or UNKNOWN for an open ray
+    for (unsigned long long rem = __ballot(need); rem; ) {
+        const int j = __ffsll((long long)rem) - 1;
+        const unsigned sw[4] = {(unsigned)__builtin_amdgcn_readlane((int)st.x, j), (unsigned)__builtin_amdgcn_readlane((int)st.y, j),
+                                (unsigned)__builtin_amdgcn_readlane((int)st.z, j), (unsigned)__builtin_amdgcn_readlane((int)st.w, j)};
+        rem &= ~__ballot(need & (st.x == sw[0]) & (st.y == sw[1]) & (st.z == sw[2]) & (st.w == sw[3]));
+        #pragma unroll
+        for (int k = 0; k < 4; k++) cand[k] |= ~(sw[k] >> 1) & 0x55555555u;
+    }
     float acc = MANY ? acc_in : AMBIENT;
-    for (int i = 0; i < ni; i++) {
-        const unsigned s2 = status(i);
-        const bool unblocked = (s2 == 1u) | ((s2 == 0u) & !((shadow >> i) & 1ull));
-        const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
-        const float d2 = len2(I - p2(cx_l, cy_l));
-        if (need & unblocked) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+    #pragma unroll
+    for (int k = 0; k < 4; k++) {
+        for (unsigned lw = cand[k]; lw; lw &= lw - 1) {
+            const int i = 16*k + ((__ffs((int)lw) - 1) >> 1);
+            if (i >= ni) break;
+            const unsigned s2 = status(i);
+            const bool unblocked = (s2 == 1u) | ((s2 == 0u) & !((shadow >> i) & 1ull));
+            const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
+            const float d2 = len2(I - p2(cx_l, cy_l));
+            if (need & unblocked) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+        }
     }
     if (MANY) {
         if (first_light + WAVE >= n_lights) return ms_min(acc, 1.f);
@@ -1692,7 +1732,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
                 l_it[kk] = (i < n_al) ? ai + (ai >= own0 ? own : 0) : AF + qe;
                 w_it[kk] = rows.load(l_it[kk]*16, 0);
             }
-            PROBE_AT(2, n_items)                                             // ... the cell's header
+            PROBE_VAL(2, 0)                                                  // (slot 2: what the dynamic lighting had to do)
             PROBE_AT(3, w_it[0].x)                                           // ... the first chunk of rows
             #pragma unroll
             for (int kk = 0; kk < AHEAD; kk++) {
@@ -1955,6 +1995,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     // Rays that landed on an agent (dynamic) are lit from the lights (kernels.cu:432-436).  With a light grid
     // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
     // ray group is queued for dynlight_kernel, launched right behind this kernel.
+    [[maybe_unused]] unsigned light_telemetry = 0x80000000u;
     if (__ballot(dynamic)) {
         if (sc.lg_vals) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1964,7 +2005,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
                                  late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
                                  late->sc.lg_list, late->sc.lg_pool};         // (fetched now: see RenderArgs)
             intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
-                reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]));
+                reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry);
+            PROBE_VAL(2, light_telemetry)
         } else if (out.workspace) {
             if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
         }

@@ -14,7 +14,7 @@ from megastep_amd import _lib, cuda, modules                             # noqa:
 
 WORDS, STAMPS = 11, 8
 NAMES = {'physics': ['start', 'agent state in', 'cell headers in', 'walls met', '', '', '', 'end'],
-         'render': ['start', 'agent state in', 'cell header in', 'first rows in', 'raycast done', 'winner row + texel row in', 'texels in', 'end']}
+         'render': ['start', 'agent state in', '', 'first rows in', 'raycast done', 'winner row + texel row in', 'texels in', 'end']}
 
 
 def analyse(name, rec, tick_ns, kernel_us):
@@ -38,6 +38,14 @@ def analyse(name, rec, tick_ns, kernel_us):
     for a, b in zip(used[:-1], used[1:]):
         d = t[:, b] - t[:, a]
         print(f'   {NAMES[name][a]:>26s} -> {NAMES[name][b]:<26s} mean {d.mean():6.2f}  p50 {np.median(d):6.2f}  p90 {np.quantile(d, .9):6.2f} us')
+    # how waves fare by when they start (a section that shrinks as the chip empties is contention, one that does not is latency)
+    qs = np.quantile(start, np.linspace(0, 1, 9))
+    print('   by start time (eighths of the waves): ' + ' | '.join(f'{qs[i]:.0f}-{qs[i + 1]:.0f} us: life {life[(start >= qs[i]) & (start <= qs[i + 1])].mean():.1f}' for i in range(8)))
+    for a, b in zip(used[:-1], used[1:]):
+        d = t[:, b] - t[:, a]
+        print(f'   {NAMES[name][a]:>26s} -> {NAMES[name][b]:<26s} ' + ' '.join(f'{d[(start >= qs[i]) & (start <= qs[i + 1])].mean():5.2f}' for i in range(8)))
+    last = np.argsort(-end)[:12]
+    print('   the 12 waves that end last (start, life | sections):', [(round(float(start[i]), 1), round(float(life[i]), 1), [round(float(t[i, b] - t[i, a]), 1) for a, b in zip(used[:-1], used[1:])]) for i in last])
     simd = xcc*65536 + (where & 0xfff0)                                   # xcc | se, sh, cu, simd (wave slot masked off)
     per = np.unique(simd, return_counts=True)[1]
     print(f'   SIMDs used {len(per)}; waves per SIMD: min {per.min()} mean {per.mean():.1f} max {per.max()}')
@@ -49,6 +57,15 @@ def analyse(name, rec, tick_ns, kernel_us):
             m = (extra[:, 2] >= lo_) & (extra[:, 2] < hi_)
             if m.any():
                 print(f'   waves with {lo_}..{hi_ - 1} stopped agents: {int(m.sum())}, life mean {life[m].mean():.2f} p99 {np.quantile(life[m], .99):.2f}; pairs mean {extra[m, 0].mean():.1f} max {extra[m, 0].max()}; swept {int(extra[m, 1].sum())}')
+    if name == 'render':                       # slot 2: 0 no ray on an agent; bit 31 some, settled by the grid's verdicts; else the work left
+        v = rec[:, 2]
+        light = t[:, 5] - t[:, 4]
+        dyn, need = v != 0, (v != 0) & (v != 0x80000000)
+        print(f'   waves with a ray on an agent: {int(dyn.sum())} ({light[dyn & ~need].mean():.2f} us from raycast to winner row, others {light[~dyn].mean():.2f}); '
+              f'with open lights: {int(need.sum())} ({light[need].mean():.2f} us; rays {(v[need] & 127).mean():.1f}, of them without a list {((v[need] >> 7) & 127).mean():.2f}, '
+              f'lists {((v[need] >> 14) & 15).mean():.2f}, rounds of pairs {((v[need] >> 18) & 127).mean():.2f}, lights {(v[need] >> 25).mean():.1f})')
+        last = np.argsort(-end)[:12]
+        print('   the 12 waves that end last (open rays, without list, lists, rounds, lights):', [(int(x & 127), int((x >> 7) & 127), int((x >> 14) & 15), int((x >> 18) & 127), int(x >> 25)) for x in v[last]])
     slowest = np.argsort(-life)[:len(life)//100 + 1]
     print(f'   the slowest 1 %: starts at {np.median(start[slowest]):.1f} us (median), ' + ', '.join(
         f'{NAMES[name][a]}->{NAMES[name][b]} {np.mean(t[slowest, b] - t[slowest, a]):.2f}' for a, b in zip(used[:-1], used[1:])))
