@@ -1007,10 +1007,16 @@ __device__ inline Filt tex_filter(float x, int w) {
 // Launch-invariant values the host works out once per ms_render call instead of every wave doing so on the VALU:
 // culling constants, and exact unsigned division by F = A*G, G and M via multiply-high (Granlund & Montgomery).
 struct Divisor { unsigned mul, sh1, sh2; };
+#ifndef MS_ORDER_EXPERIMENT
+#define MS_ORDER_EXPERIMENT 0          // 1: ms_debug_order() hands render_kernel an order to take its fans in and a place for their lives
+#endif
 struct RenderConsts {
     float x_clip, c_b;
     Divisor by_f, by_g, by_m;
     int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
+#if MS_ORDER_EXPERIMENT
+    const int* fan_order; unsigned* fan_cost;      // (experiment) dispatch slot -> fan; every wave's life in shader clocks
+#endif
 };
 __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     unsigned s = 0;
@@ -1133,7 +1139,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     //   4096 screen (192 x 4 B)  RGB staging
     // IMPL 2 lays its block out differently (see there): 6144 B
     PROBE_INIT
-    constexpr int LDS_PER_WAVE = IMPL == 2 ? 24*MS_VCAP + 3072 : 4864;
+    constexpr int LDS_PER_WAVE = (IMPL == 2 ? 24*MS_VCAP + 3072 : 4864) + 16*(MS_ORDER_EXPERIMENT != 0);
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
@@ -1163,7 +1169,14 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
     const int lb = xcd*q8 + min(xcd, r8) + ix;      // (XCDs 0..r8-1 get a block more; no branch: a branch ends the stretch of
                                                     //  code hipcc gathers the kernel-argument loads of to its top)
+#if MS_ORDER_EXPERIMENT
+    const int fan = rc.fan_order[lb];          // (the experiment always passes an order)
+#if MS_ORDER_EXPERIMENT == 2
+    if (lane == 0) *reinterpret_cast<unsigned*>(&s_raw[wave][LDS_PER_WAVE - 16]) = (unsigned)clock64();
+#endif
+#else
     const int fan = lb*RW + wave;
+#endif
     if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
 #endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
@@ -1538,7 +1551,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = MS_VCAP, P_CAP = 4096 < 64*MS_VCAP ? 4096 : 64*MS_VCAP;
         constexpr int O_INFO = 16*V_CAP, O_RAY = 24*V_CAP, O_NEAR = O_RAY + 512, O_QUEUE = O_NEAR + 256, O_BEST = O_QUEUE + 256;
-        static_assert(O_BEST + 3*512 + 512 == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
+        static_assert(O_BEST + 3*512 + 512 + 16*(MS_ORDER_EXPERIMENT != 0) == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][O_INFO]);
         // (direction and near plane in arrays of their own: at 8 and 4 bytes a ray, a window's reads - one ray per lane, the
         // rays mostly consecutive - touch every LDS bank once; as one 16-byte record per ray they were two-way conflicts)
@@ -2094,6 +2107,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         }
     }
     PROBE_DONE(fan)
+#if MS_ORDER_EXPERIMENT == 2
+    {
+        unsigned* const costs = late_args()->rc.fan_cost;
+        if (costs && lane == 0) costs[((size_t)n*A + a)*G + g] = (unsigned)clock64() - *reinterpret_cast<unsigned*>(&s_raw[wave][LDS_PER_WAVE - 16]);
+    }
+#endif
 #if MS_PERSISTENT
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -3153,6 +3172,12 @@ void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, fl
     bake_wall_bins(p2(light_x, light_y), ax, ay, bx, by, *first, *count);
 }
 
+#if MS_ORDER_EXPERIMENT
+static const int* g_fan_order = nullptr;
+static unsigned* g_fan_cost = nullptr;
+int ms_debug_order(const int* order, unsigned* cost) { g_fan_order = order; g_fan_cost = cost; return MS_OK; }
+#endif
+
 #if MS_PROBE
 // (probe builds only, not part of the ABI) buf: device memory of capacity records of 11 32-bit words (8 stamps, HW_ID |
 // XCC_ID << 16, the real-time counter at the wave's start and end), or NULL to stop recording
@@ -3339,6 +3364,9 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_g = divisor_of((unsigned)G);
     rc.by_m = divisor_of((unsigned)sc->n_model);
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
+#if MS_ORDER_EXPERIMENT
+    rc.fan_order = g_fan_order; rc.fan_cost = g_fan_cost;
+#endif
     constexpr int RW = 1;
 #if MS_PERSISTENT
     static int* cursor = nullptr;
