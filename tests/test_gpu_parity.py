@@ -240,11 +240,16 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
     assert 0 < int(pool[0]) < len(pool)
 
 
-def test_crowded_rooms_exercise_dynamic_lighting():
+@pytest.mark.parametrize('res,fov,cell', [(64, 130, .25), (256, 70, 1.), (128, 100, .5)])
+def test_crowded_rooms_exercise_dynamic_lighting(monkeypatch, res, fov, cell):
     """Four agents packed into one room of each plan, looking at each other: many rays land on agents, under every
-    mix of lit / shadowed / partly shadowed lights."""
+    mix of lit / shadowed / partly shadowed lights.  With coarser light-grid cells more lights stay open and the
+    candidate lists grow past one LDS batch (64 pairs): several lists per wave, several batches per list, several rounds
+    of (ray, candidate) pairs per batch."""
     from megastep_amd import cuda
-    c, geometries = _world(24, 4, 64, 130, seed=5)
+    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_CELL', cell)
+    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_POOL', 12 if cell == .25 else 200)
+    c, geometries = _world(24, 4, res, fov, seed=5)
     rng = np.random.RandomState(2)
     pos = np.zeros((24, 4, 2), np.float32)
     ang = np.zeros((24, 4), np.float32)
@@ -262,6 +267,9 @@ def test_crowded_rooms_exercise_dynamic_lighting():
     r = cuda.render(c.scenery, c.agents)
     idx = r.indices.cpu().numpy()
     assert ((idx >= 0) & (idx < 32)).mean() > .05, 'expected plenty of rays on agents'
+    if cell > .25:
+        counts = (c.scenery._lg[5].view(-1, 2)[:, 1].cpu().numpy().astype(np.int64)) & 0x7fffffff
+        assert counts.max() > 64, 'expected candidate lists longer than one batch'
     util.assert_render_matches(c, r, ref.render())
 
 
