@@ -65,3 +65,6 @@ if os.path.exists(f):
     a.to_csv(f'{out}/valu_busy.csv'); print(a.round(3).to_string())
 PY
 tail -1 $out/bench_stats.log | cut -c1-400
+# (gpurun brings back at most 64 MiB: the raw traces stay on the box, the summaries above travel)
+cp $out/stats/bench_kernel_stats.csv $out/kernel_stats_all.csv 2>/dev/null
+rm -rf $out/stats $out/fetch $out/write $out/sq $out/active
