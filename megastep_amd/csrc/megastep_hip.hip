@@ -1006,6 +1006,21 @@ __device__ inline Filt tex_filter(float x, int w) {
 // form (telemetry for tests) | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
 // Launch-invariant values the host works out once per ms_render call instead of every wave doing so on the VALU:
 // culling constants, and exact unsigned division by F = A*G, G and M via multiply-high (Granlund & Montgomery).
+// sqrtf() for an argument known to be a normal number (not zero, denormal, infinite or NaN): the correctly rounded root
+// the compiler's own expansion gives (v_sqrt_f32 is good to 1 ulp; the residuals of its two neighbours decide) without
+// that expansion's rescaling of tiny arguments and its special cases - 8 instructions of 20.
+#ifndef MS_SQRT_NORMAL
+#define MS_SQRT_NORMAL 1               // (0: sqrtf() for the rays' lengths - the A/B: 34.5 -> 34.3 us at the headline, same bits)
+#endif
+__device__ inline float sqrt_normal(const float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = bits_f(f_bits(s) - 1u), up = bits_f(f_bits(s) + 1u);
+    const float r_dn = __builtin_fmaf(-dn, s, x), r_up = __builtin_fmaf(-up, s, x);
+    float r = (r_dn <= 0.f) ? dn : s;
+    r = (r_up > 0.f) ? up : r;
+    return r;
+}
+
 struct Divisor { unsigned mul, sh1, sh2; };
 #ifndef MS_ORDER_EXPERIMENT
 #define MS_ORDER_EXPERIMENT 0          // 1: ms_debug_order() hands render_kernel an order to take its fans in and a place for their lives
@@ -1285,7 +1300,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const float Rf = (float)R;
     const float uy = (Rf - 2*(float)r - 1)*half_screen/Rf;            // ray_y, kernels.cu:234-236
     const float rx = cs*1.f - sn*uy, ry = sn*1.f + cs*uy;
+#if MS_SQRT_NORMAL
+    const float rlen = sqrt_normal(rx*rx + ry*ry);                      // (|r|^2 = (cos^2 + sin^2)(1 + uy^2): 1 to 1 + half_screen^2)
+#else
     const float rlen = sqrtf(rx*rx + ry*ry);
+#endif
     const float near = agent_radius/rlen;
 
     // Screen-space bookkeeping for the culling below.  In the agent frame (x' forward, y' left) a point
