@@ -18,9 +18,11 @@ the host and builds and bakes ITS slice only - weak scaling, no collective on th
 ranks meet only in a gloo barrier around each timed region and a MAX over their times, so RCCL is never initialised.
 Rank 0 prints one JSON line.
 
-Timing: a timed region is exactly K steps between barrier + synchronize pairs; regions are repeated until they add up
-to a quarter of a second and `value` / `ms_per_step` are the MEDIAN region's (min and max beside it), so that a
-K = 20 run is as repeatable as a K = 200 one.
+Timing: a timed region is the W untimed warm-up steps from the spawn points and then exactly K steps between barrier +
+synchronize pairs - steps W..W+K of one fixed trajectory of the env loop (recorded beforehand: the velocities handed to
+`ms_physics` at every step), the same in every region. Regions are repeated until they add up to a quarter of a second
+and `value` / `ms_per_step` are the MEDIAN region's (min and max beside it), so that a K = 20 run is as repeatable as a
+K = 200 one and times the same kind of step.
 
 Besides the contract fields the line carries
   roofline      render kernel (the dominant one): algorithmic bytes per launch / its mean launch time (HIP events
@@ -386,23 +388,39 @@ def main(argv=None):
     scenery, agents = core.scenery, core.agents
     hot = dev.hot_path(scenery)
 
-    # velocities per step are produced by the (untimed) torch movement glue ahead of time: a dry run of the env loop
-    vel = torch.empty((total, N, A, 2), device=device)
-    angvel = torch.empty((total, N, A), device=device)
+    # The velocities the hot path is handed at each step are produced by the (untimed) torch movement glue ahead of
+    # time: a dry run of the env loop from the spawn points, W + K steps, recording what ms_physics is given - the
+    # velocities BEFORE it stops the agents that run into something.
+    start = (agents.angles.clone(), agents.positions.clone())
+    vel0 = torch.empty((total, N, A, 2), device=device)
+    angvel0 = torch.empty((total, N, A), device=device)
     for i in range(total):
         delta = mover._actionset[actions[i]]
         agents.angvelocity[:] = (1 - mover.decay)*agents.angvelocity + delta.angvelocity
         agents.velocity[:] = (1 - mover.decay)*agents.velocity + modules.to_global_frame(agents.angles, delta.velocity)
+        vel0[i], angvel0[i] = agents.velocity, agents.angvelocity
         hot(agents)
-        vel[i], angvel[i] = agents.velocity, agents.angvelocity
     dev.sync()
 
     # One Agents view per step: positions/angles are the persistent state, velocity/angvelocity point at that
     # step's pre-generated inputs, already resident in HBM - the hot path reads its inputs in place, no copies.
+    vel, angvel = vel0.clone(), angvel0.clone()                         # (ms_physics zeroes the stopped agents' in place)
     views = [cuda.Agents(agents.angles, agents.positions, angvel[i], vel[i]) for i in range(total)]
 
+    def rewind():
+        """Back to the spawn points, inputs pristine, then the W untimed warm-up steps: every timed region is the same K
+        steps of the same trajectory - steps W..W+K of the env loop dry-run above - however often it is repeated.  (Regions
+        that carried on from each other's end state replayed K inputs thousands of times over, agents ground into the
+        corners their net drift pointed at: with the driver's --steps 20 a third slower than with --steps 200.)"""
+        agents.angles.copy_(start[0]); agents.positions.copy_(start[1])
+        vel.copy_(vel0); angvel.copy_(angvel0)
+        for i in range(args.warmup):
+            hot(views[i])
+
     def timed(run):
-        """One timed region: barrier + synchronize on both sides, the slowest rank's wall time."""
+        """One timed region: W untimed warm-up steps from the spawn points, then exactly K steps between barrier +
+        synchronize pairs; the slowest rank's wall time."""
+        rewind()
         barrier()
         dev.sync()
         t0 = time.perf_counter()
@@ -420,8 +438,6 @@ def main(argv=None):
         return np.array([first] + [timed(run) for _ in range(n - 1)])
 
     # ---- eager: K steps launched one by one, events around every step and every render
-    for i in range(args.warmup):
-        hot(views[i])
     events = []
 
     def eager():
