@@ -150,6 +150,39 @@ def test_crawling_agents_meet_far_walls_like_the_reference():
     np.testing.assert_array_equal(p.progress.cpu().numpy(), prog_ref)
 
 
+@pytest.mark.parametrize('n_agents', [2, 4, 7])
+def test_agents_meet_agents_like_the_reference_whatever_their_relative_velocity(n_agents):
+    """The reach cull in front of the agent-agent test: pairs at every distance around the threshold, relative
+    velocities from a brisk walk down to 1e-9 a step (project()'s `+ 1e-6` stretches the reach of a pair that moves
+    almost in step, kernels.cu:91-107), pairs in perfect step, pairs with a NaN or an infinity in their state."""
+    from megastep_amd import core, cuda, scene, toys
+    E = 512
+    sc = scene.scenery(E*[toys.box()], n_agents, device='cuda')
+    c = core.Core(sc, res=8, fps=10)
+    rng = np.random.RandomState(3)
+    base = rng.uniform(2.5, 3.5, (E, 1, 2))
+    gap = 10.**rng.uniform(-2.5, .7, (E, n_agents, 1))                    # 3 mm .. 5 m from the first agent
+    ang = rng.uniform(0, 2*np.pi, (E, n_agents, 1))
+    pos = (base + gap*np.concatenate([np.cos(ang), np.sin(ang)], -1)).astype(np.float32)
+    pos[:, 0] = base[:, 0]
+    common = rng.uniform(-3, 3, (E, 1, 2))*(rng.rand(E, 1, 1) < .8)       # a fifth of the envs: no common drift
+    rel = 10.**rng.uniform(-8, .5, (E, n_agents, 1))                      # 10 x the relative velocity per step
+    rang = rng.uniform(0, 2*np.pi, (E, n_agents, 1))
+    vel = (common + rel*np.concatenate([np.cos(rang), np.sin(rang)], -1)).astype(np.float32)
+    vel[::7, 1] = vel[::7, 0]                                             # in perfect step
+    vel[5::31, 1, 0] = np.nan
+    vel[11::37, 0, 1] = np.inf
+    pos[17::41, 1, 0] = np.nan
+    c.agents.positions[:] = torch.as_tensor(pos, device='cuda')
+    c.agents.velocity[:] = torch.as_tensor(vel, device='cuda')
+    ref = util.OracleWorld(c)
+    p = cuda.physics(c.scenery, c.agents)
+    prog_ref, agents_ref = ref.physics()
+    np.testing.assert_array_equal(p.progress.cpu().numpy(), prog_ref)
+    util.assert_physics_matches(c, p, prog_ref, agents_ref)
+    assert ((prog_ref < 1) & (prog_ref > 0)).sum() > 5 and (prog_ref == 0).sum() > 50 and (prog_ref == 1).sum() > 50
+
+
 @pytest.mark.parametrize('n_agents', [1, 4, 6])
 def test_walls_with_non_finite_coordinates_go_through_the_exact_test(n_agents):
     """A NaN or an infinity among a wall's coordinates: the reach boxes cannot judge such a wall, so the sweep hands it to
