@@ -283,6 +283,9 @@ int ms_wallgrid_scan(const MsScenery* scenery, const MsWallGridParent* parent, c
 int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int max_cells,
                      const long long* bits_starts, const unsigned* bits, unsigned short* pool, unsigned* vis_entries,
                      float* near_rows, void* hip_stream);
+/* Host instantiation of ms_physics' reach cull in front of the agent-agent collision test (reference: kernels.cu:119-133,
+ * 193-200), for CPU tests: me, other = (x, y, vx/fps, vy/fps); 1 = the pair cannot collide this step, the test is skipped. */
+int ms_host_agents_apart(const float* me, const float* other, float agent_radius);
 /* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
  * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);

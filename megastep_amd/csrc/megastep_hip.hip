@@ -210,6 +210,23 @@ __device__ inline float collision_cc(P2 p0, P2 v0, P2 p1, P2 v1, float agent_rad
     return x;
 }
 
+// Reach cull in front of collision_cc (exact).  me, o = (position, velocity per step) of the two agents; dv their relative
+// velocity, D their distance, r = 2.002 R, k = 1 + 1e-6/|dv| (project()'s "+ 1e-6").  collision_cc leaves x = 1 unless
+// d = D |sin| / k < r and s - backoff = D cos /(|dv| k^2) - sqrt(r^2 - d^2)/|dv| < 1/0.99, so unless
+// D < k^2 (1.0102 |dv| + r) + k r; and for dv = 0 exactly project()'s s is 0 and its test never fires.  |dv| is bounded
+// from both sides by its components; 2 %, a millimetre and the positions' rounding are added.  A NaN anywhere fails the
+// cull and takes the test.  (tests/test_wallgrid.py checks "apart => the oracle's collision_cc is 1" on random pairs.)
+__host__ __device__ inline bool agents_apart(const float4 me, const float4 o, const float agent_radius) {
+    const float ax = fabsf(me.z - o.z), ay = fabsf(me.w - o.w);
+    const float v_up = ax + ay, v_lo = fmaxf(ax, ay);
+    const float r2 = 1.001f*2.002f*agent_radius;
+    const float kq = 1.f + 1.0001e-6f/v_lo;
+    const float reach = 1.02f*(kq*kq*(1.0102f*v_up + r2) + kq*r2) + 1e-3f
+                      + 1e-4f*(fabsf(me.x) + fabsf(me.y) + fabsf(o.x) + fabsf(o.y));
+    const float dx = o.x - me.x, dy = o.y - me.y;
+    return (0.9998f*(dx*dx + dy*dy) > reach*reach) | ((ax == 0.f) & (ay == 0.f));
+}
+
 // kernels.cu:135-171
 __device__ inline float collision_cs(P2 p, P2 v, P2 la, P2 lb, float agent_radius) {
     const float r = 1.001f*agent_radius;
@@ -439,25 +456,13 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PROBE_AT(1, my_box.x)                                                // agent state has arrived
     // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane
-    // Reach cull (exact, the walls' argument of above with the agents' relative velocity dv and r = 2.002 R): with D the
-    // distance between the two and k = 1 + 1e-6/|dv|, collision_cc leaves x = 1 unless D |sin| / k < r and
-    // D cos /(|dv| k^2) - sqrt(r^2 - d^2)/|dv| < 1/0.99, so unless D < k^2 (1.0102 |dv| + r) + k r; and for dv = 0 exactly
-    // project()'s s is 0 and the test never fires.  |dv| is bounded from both sides by its components; 2 %, a millimetre
-    // and the positions' rounding are added.  Agents of one env are mostly rooms apart: then no lane of the wave goes
-    // into the test at all (a fifth of a physics wave's instructions).  NaNs anywhere fail the cull and take the test.
+    // (behind agents_apart(): agents of one env are mostly rooms apart, and then no lane of the wave goes into the test at
+    // all - a fifth of a physics wave's instructions)
     for (int i = lane; i < A*A; i += WAVE) {
         const int t = i / A, d1 = i - t*A;
         if (d1 != t) {
             const float4 me = s_task[t], o = s_task[d1];
-            const float ax = fabsf(me.z - o.z), ay = fabsf(me.w - o.w);
-            const float v_up = ax + ay, v_lo = fmaxf(ax, ay);
-            const float r2 = 1.001f*2.002f*agent_radius;
-            const float kq = 1.f + 1.0001e-6f*__builtin_amdgcn_rcpf(v_lo);
-            const float reach = 1.02f*(kq*kq*(1.0102f*v_up + r2) + kq*r2) + 1e-3f
-                              + 1e-4f*(fabsf(me.x) + fabsf(me.y) + fabsf(o.x) + fabsf(o.y));
-            const float dx = o.x - me.x, dy = o.y - me.y;
-            const bool apart = (0.9998f*(dx*dx + dy*dy) > reach*reach) | ((ax == 0.f) & (ay == 0.f));
-            if (!apart) {
+            if (!agents_apart(me, o, agent_radius)) {
                 const float x = collision_cc(p2(me.x, me.y), p2(me.z, me.w), p2(o.x, o.y), p2(o.z, o.w), agent_radius);
                 if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
             }
@@ -3222,6 +3227,10 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
     return MS_OK;
 }
 #endif
+
+int ms_host_agents_apart(const float* me, const float* other, float agent_radius) {
+    return agents_apart(make_float4(me[0], me[1], me[2], me[3]), make_float4(other[0], other[1], other[2], other[3]), agent_radius) ? 1 : 0;
+}
 
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane) {
     const WgCell k{x0, y0, x1, y1};

@@ -208,3 +208,39 @@ def test_a_wall_is_only_ever_seen_inside_its_arc(name):
                 kept.append(meets(*np.float32(rot(away, -.26)), *np.float32(rot(away, .26)), lo, hi))
     if name != 'box':
         assert np.mean(kept) < .2, f'{np.mean(kept):.2f} of the walls behind a fan are kept'
+
+
+def test_agents_the_cull_calls_apart_cannot_collide(oracle):
+    """ms_physics skips the agent-agent test for pairs its reach cull calls apart: for every such pair the
+    oracle's collision_cc (kernels.cu:119-133) must leave x = 1 - at every distance around the threshold, relative
+    velocities from a sprint down to 1e-12 a step (project()'s `+ 1e-6` stretches the reach of a pair that moves almost in
+    step), pairs in perfect step, coordinates far from the origin, and a NaN or an infinity here and there (apart only when in step)."""
+    rng = np.random.RandomState(0)
+    lib, cc = _lib.lib(), oracle.lib().oracle_collision_cc
+    f32p = C.POINTER(C.c_float)
+    n, culled, hits, hits_kept = 60000, 0, 0, 0
+    for i in range(n):
+        R = float(np.float32(10.**rng.uniform(-2, 0)))
+        base = rng.uniform(-1, 1, 2)*10.**rng.uniform(0, 3)
+        common = rng.uniform(-1, 1, 2)*10.**rng.uniform(-3, 1)*(rng.rand() < .8)
+        rel = 10.**rng.uniform(-12, .7)
+        a = rng.uniform(0, 2*np.pi)
+        dv = rel*np.array([np.cos(a), np.sin(a)])*(rng.rand() < .95)             # 5 %: in perfect step
+        # distances around what the pair can cover: |dv| + 2R, scaled by 0.2 .. 30; now and then much closer / farther
+        D = (rel + 2*R)*10.**rng.uniform(-.7, 1.5) if rng.rand() < .8 else 10.**rng.uniform(-3, 2)
+        b = a + rng.normal(0, .5) if rng.rand() < .7 else rng.uniform(0, 2*np.pi)   # mostly closing in on each other
+        me = np.array([*base, *(common + dv)], np.float32)
+        other = np.array([*(base + D*np.array([np.cos(b), np.sin(b)])), *common], np.float32)
+        if i % 997 == 0: me[rng.randint(4)] = [np.nan, np.inf, -np.inf][i % 3]
+        if i % 1009 == 0: other[rng.randint(4)] = [np.nan, np.inf, -np.inf][i % 3]
+        apart = lib.ms_host_agents_apart(me.ctypes.data_as(f32p), other.ctypes.data_as(f32p), R)
+        x = cc(*[float(v) for v in me], *[float(v) for v in other], R)
+        hits += x < 1
+        if apart:
+            culled += 1
+            assert x == 1., (i, me, other, R, x)
+            assert (np.isfinite(me).all() and np.isfinite(other).all()) or (me[2:] == other[2:]).all()   # (in step: never collide)
+        else:
+            hits_kept += x < 1
+    assert hits > n//20 and hits_kept == hits, 'the sample holds plenty of collisions, none of them culled'
+    assert culled > n//4, 'and the cull does cull'
