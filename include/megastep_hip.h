@@ -286,6 +286,10 @@ int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int 
 /* Host instantiation of ms_physics' reach cull in front of the agent-agent collision test (reference: kernels.cu:119-133,
  * 193-200), for CPU tests: me, other = (x, y, vx/fps, vy/fps); 1 = the pair cannot collide this step, the test is skipped. */
 int ms_host_agents_apart(const float* me, const float* other, float agent_radius);
+/* ... and of the reach cull in front of the agent-wall test (kernels.cu:135-171,202-205): agent = (x, y, vx/fps, vy/fps),
+ * wall = (ax, ay, bx, by); 1 = the wall is beyond the agent's reach this step, the test is skipped.  (The host evaluates the
+ * foot of the perpendicular with a true division, the kernel with v_rcp_f32: both are lower bounds on the distance.) */
+int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius);
 /* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
  * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);

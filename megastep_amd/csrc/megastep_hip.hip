@@ -227,6 +227,40 @@ __host__ __device__ inline bool agents_apart(const float4 me, const float4 o, co
     return (0.9998f*(dx*dx + dy*dy) > reach*reach) | ((ax == 0.f) & (ay == 0.f));
 }
 
+// Reach cull in front of collision_cs (exact).  How far a wall can be from an agent and still matter: the crossing and
+// side tests need it within |v| + r of p; an endpoint test (kernels.cu:147-160) needs d = D |sin| |v|/(|v| + 1e-6) < r and
+// s - backoff = D cos |v|/(|v| + 1e-6)^2 - sqrt(r^2 - d^2)/|v| below 1/0.99 (beyond that the 0.99 margin clamps x to 1),
+// which bounds the endpoint's distance D by k^2 (1.0102 |v| + r) + k r with k = 1 + 1e-6/|v|.  At everyday speeds k is 1
+// and that is the familiar |v| + 2 r; it is project()'s "+ 1e-6" that lets a CRAWLING agent - a momentum velocity that
+// has decayed for a hundred steps - be stopped by walls metres away, and k says exactly how many (reach 1.3 m at 6e-7 m
+// a step, every wall of the map below 1e-8).  2 %, a millimetre and the position's rounding are added.  (p0, v0: position
+// and velocity per step.  tests/test_wallgrid.py checks "beyond => the oracle's collision_cs is 1" on random pairs.)
+__host__ __device__ inline float wall_reach(const P2 p0, const P2 v0, const float agent_radius) {
+    const float vl = len(v0);
+    const float r1 = 1.001f*agent_radius;
+    const float kq = 1.f + 1e-6f/vl;                                       // (|v| = 0: inf, unused)
+    const float reach = (vl > 0.f) ? 1.02f*(kq*kq*(1.0102f*vl + r1) + kq*r1) : 2.04f*r1;
+    return reach + 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
+}
+__host__ __device__ inline float reach_squared(const float reach) { return (reach == reach) ? reach*reach : INFINITY; }   // NaN positions: test everything
+// ... and the wall u = (ax, ay, bx, by) against it: the squared distance from the agent tk = (x, y, ..) to the segment,
+// shaved so it is a lower bound (the reciprocal may be the hardware's approximate one: a foot a few ulps off the nearest
+// point is farther away, not nearer).  Walls shorter than a tenth of a millimetre are never beyond: project()'s "+ 1e-6"
+// on the WALL's length stretches the side test's reach for them (kernels.cu:91-107,163-168).  NaNs are never beyond.
+__host__ __device__ inline bool wall_beyond(const float4 tk, const float4 u, const float reach2) {
+    const float vx = u.z - u.x, vy = u.w - u.y;
+    const float pqx = u.x - tk.x, pqy = u.y - tk.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+    float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
+#else
+    float tc = -(pqx*vx + pqy*vy)/(vx*vx + vy*vy);
+#endif
+    tc = fminf(fmaxf(tc, 0.f), 1.f);
+    tc = (tc == tc) ? tc : 0.f;
+    const float qx = pqx + tc*vx, qy = pqy + tc*vy;
+    return (0.9998f*(qx*qx + qy*qy) > reach2) & (vx*vx + vy*vy >= 1e-8f);
+}
+
 // kernels.cu:135-171
 __device__ inline float collision_cs(P2 p, P2 v, P2 la, P2 lb, float agent_radius) {
     const float r = 1.001f*agent_radius;
@@ -432,19 +466,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
         const P2 p0 = p2(pp.x, pp.y);
         const P2 v0 = p2(mm.x, mm.y)/fps;
-        const float vl = len(v0);
-        // How far a wall can be and still matter: the crossing and side tests need it within |v| + r of p; an endpoint
-        // test (kernels.cu:147-160) needs d = D |sin| |v|/(|v| + 1e-6) < r and s - backoff = D cos |v|/(|v| + 1e-6)^2 -
-        // sqrt(r^2 - d^2)/|v| below 1/0.99 (beyond that the 0.99 margin clamps x to 1), which bounds the endpoint's
-        // distance D by k^2 (1.0102 |v| + r) + k r with k = 1 + 1e-6/|v|.  At everyday speeds k is 1 and that is the
-        // familiar |v| + 2 r; it is project()'s "+ 1e-6" that lets a CRAWLING agent - a momentum velocity that has decayed
-        // for a hundred steps - be stopped by walls metres away, and k says exactly how many (reach 1.3 m at 6e-7 m a
-        // step, every wall of the map below 1e-8).  2 % and a millimetre are added for the rounding.
-        const float r1 = 1.001f*agent_radius;
-        const float kq = 1.f + 1e-6f/vl;                                   // (|v| = 0: inf, unused)
-        float reach = (vl > 0.f) ? 1.02f*(kq*kq*(1.0102f*vl + r1) + kq*r1) : 2.04f*r1;
-        reach += 1e-3f + 1e-4f*(fabsf(p0.x) + fabsf(p0.y));
-        s_reach2[t] = (reach == reach) ? reach*reach : INFINITY;         // NaN velocities: test everything
+        const float reach = wall_reach(p0, v0, agent_radius);
+        s_reach2[t] = reach_squared(reach);
         const float4 box = make_float4(p0.x - reach, p0.y - reach, p0.x + reach, p0.y + reach);   // NaNs: never rejects
         if (t == lane) { my_box = box; my_reach = (reach == reach) ? reach : INFINITY; }
         s_box[t] = box;
@@ -472,16 +495,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     // one (wall, agent) pair: the reach cull on the true distance, then the reference's test (kernels.cu:135-171,202-205)
     auto meet = [&](const float4 u, const int t) {
         const float4 tk = s_task[t];
-        // squared distance from the agent to the segment, shaved so it is a lower bound
-        const float vx = u.z - u.x, vy = u.w - u.y;
-        const float pqx = u.x - tk.x, pqy = u.y - tk.y;
-        float tc = -(pqx*vx + pqy*vy)*__builtin_amdgcn_rcpf(vx*vx + vy*vy);
-        tc = fminf(fmaxf(tc, 0.f), 1.f);
-        tc = (tc == tc) ? tc : 0.f;
-        const float qx = pqx + tc*vx, qy = pqy + tc*vy;
-        // (walls shorter than a tenth of a millimetre are met whatever their distance: project()'s "+ 1e-6" on the WALL's
-        // length stretches the side test's reach for them, kernels.cu:91-107,163-168)
-        if (!(0.9998f*(qx*qx + qy*qy) > s_reach2[t]) | !(vx*vx + vy*vy >= 1e-8f)) {   // NaNs stay in
+        if (!wall_beyond(tk, u, s_reach2[t])) {
             const float x = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
             if (x < 1.f) atomicMin(&s_prog[t], f_bits(x));
         }
@@ -3227,6 +3241,12 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
     return MS_OK;
 }
 #endif
+
+int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius) {
+    const float reach = wall_reach(p2(agent[0], agent[1]), p2(agent[2], agent[3]), agent_radius);
+    return wall_beyond(make_float4(agent[0], agent[1], agent[2], agent[3]), make_float4(wall[0], wall[1], wall[2], wall[3]),
+                       reach_squared(reach)) ? 1 : 0;
+}
 
 int ms_host_agents_apart(const float* me, const float* other, float agent_radius) {
     return agents_apart(make_float4(me[0], me[1], me[2], me[3]), make_float4(other[0], other[1], other[2], other[3]), agent_radius) ? 1 : 0;

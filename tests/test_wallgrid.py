@@ -244,3 +244,43 @@ def test_agents_the_cull_calls_apart_cannot_collide(oracle):
             hits_kept += x < 1
     assert hits > n//20 and hits_kept == hits, 'the sample holds plenty of collisions, none of them culled'
     assert culled > n//4, 'and the cull does cull'
+
+
+def test_walls_the_cull_calls_beyond_reach_cannot_stop_the_agent(oracle):
+    """ms_physics skips the agent-wall test for walls its reach cull calls beyond the agent's reach: for
+    every such pair the oracle's collision_cs (kernels.cu:135-171) must leave x = 1 - walls at every distance around the
+    reach, agents from a sprint down to 1e-12 a step (project()'s `+ 1e-6`: a crawling agent is stopped by walls metres
+    away), walls from 10 m down to a micrometre (its `+ 1e-6` on the wall's length), a NaN or an infinity now and then."""
+    rng = np.random.RandomState(1)
+    lib, cs = _lib.lib(), oracle.lib().oracle_collision_cs
+    f32p = C.POINTER(C.c_float)
+    n, culled, hits, hits_kept = 80000, 0, 0, 0
+    for i in range(n):
+        R = float(np.float32(10.**rng.uniform(-2, 0)))
+        p = rng.uniform(-1, 1, 2)*10.**rng.uniform(0, 3)
+        speed = 10.**rng.uniform(-12, .7)*(rng.rand() < .97)                     # 3 %: standing still
+        a = rng.uniform(0, 2*np.pi)
+        v = speed*np.array([np.cos(a), np.sin(a)])
+        reach = (speed + 2*R)*(1 + 1e-6/max(speed, 1e-30))**2 if speed > 0 else 2*R
+        D = min(reach, 1e4)*10.**rng.uniform(-.7, 1.) if rng.rand() < .8 else 10.**rng.uniform(-3, 2)
+        b = a + rng.normal(0, .6) if rng.rand() < .7 else rng.uniform(0, 2*np.pi)   # mostly ahead of the agent
+        mid = p + D*np.array([np.cos(b), np.sin(b)])
+        length = 10.**rng.uniform(-6, 1)
+        c = rng.uniform(0, 2*np.pi)
+        half = .5*length*np.array([np.cos(c), np.sin(c)])
+        shift = rng.uniform(-1, 1)*half*(rng.rand() < .5)                         # the nearest point: an end as often as not
+        agent = np.array([*p, *v], np.float32)
+        wall = np.array([*(mid - half + shift), *(mid + half + shift)], np.float32)
+        if i % 997 == 0: agent[rng.randint(4)] = [np.nan, np.inf, -np.inf][i % 3]
+        if i % 1009 == 0: wall[rng.randint(4)] = [np.nan, np.inf, -np.inf][i % 3]
+        beyond = lib.ms_host_wall_beyond_reach(agent.ctypes.data_as(f32p), wall.ctypes.data_as(f32p), R)
+        x = cs(*[float(t) for t in agent], *[float(t) for t in wall], R)
+        hits += x < 1
+        if beyond:
+            culled += 1
+            assert x == 1., (i, agent, wall, R, x)
+            assert np.isfinite(agent[:2]).all() and np.isfinite(wall).all()      # (a NaN velocity stops nobody: every test of collision_cs fails)
+        else:
+            hits_kept += x < 1
+    assert hits > n//20 and hits_kept == hits, 'the sample holds plenty of collisions, none of them culled'
+    assert culled > n//4, 'and the cull does cull'
