@@ -283,6 +283,10 @@ int ms_wallgrid_scan(const MsScenery* scenery, const MsWallGridParent* parent, c
 int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int max_cells,
                      const long long* bits_starts, const unsigned* bits, unsigned short* pool, unsigned* vis_entries,
                      float* near_rows, void* hip_stream);
+/* Host instantiation of render_kernel's pass 1 for one line (reference: the all-lines loop kernels.cu:352-377, which it
+ * culls): pose = (x, y, sin, cos of the heading), line = (ax, ay, bx, by), `group` = which 64 rays of the agent's `res`:
+ * rays first .. first + count - 1 of the group (0-based within it) are the only ones the kernel intersects with the line. */
+void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count);
 /* Host instantiation of ms_physics' reach cull in front of the agent-agent collision test (reference: kernels.cu:119-133,
  * 193-200), for CPU tests: me, other = (x, y, vx/fps, vy/fps); 1 = the pair cannot collide this step, the test is skipped. */
 int ms_host_agents_apart(const float* me, const float* other, float agent_radius);

@@ -1123,8 +1123,23 @@ __device__ inline LateArgs late_args() {
 //   CLIP = 1: an end behind the near clip plane is clipped to it;
 //   CLIP = 0: it is replaced by the edge of the fan on the side the line leaves by (the sign of cross(a, b)) - the same
 //             interval unless the line crosses the clip plane within centimetres of the agent, for fewer instructions.
+// (the hardware's approximate reciprocal on the device, a division on the host - whose instantiations of the culls exist
+// for the CPU tests: everything that goes through here only feeds margins that are thousands of roundings wide)
+__host__ __device__ inline float rcp_approx(const float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f/x;
+#endif
+}
+// agent-frame coordinates (x forward, y left) of a line's two ends, given relative to the agent: PQ = a - p, DB = b - p
+__host__ __device__ inline void agent_frame(const float cs, const float sn, const float pqx, const float pqy, const float dbx, const float dby,
+                                            float& xa, float& ya, float& xb, float& yb) {
+    xa = __builtin_fmaf(cs, pqx, sn*pqy); ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
+    xb = __builtin_fmaf(cs, dbx, sn*dby); yb = __builtin_fmaf(cs, dby, -(sn*dbx));
+}
 template <int CLIP>
-__device__ inline void ray_interval(float xa, float ya, float xb, float yb, const bool live, const float x_clip,
+__host__ __device__ inline void ray_interval(float xa, float ya, float xb, float yb, const bool live, const float x_clip,
                                     const float c_a, const float c_b, const float g0, const float last_local, int& lo, int& len) {
     const bool fa = xa >= x_clip, fb = xb >= x_clip;
     float ra, rb, marg;
@@ -1132,16 +1147,16 @@ __device__ inline void ray_interval(float xa, float ya, float xb, float yb, cons
     if constexpr (CLIP == 1) {
         inc = fa | fb | !(xa == xa) | !(xb == xb);                      // wholly behind the clip plane: never hit
         if (fa != fb) {                                                 // clip the hidden end to x' = x_clip
-            const float t = (x_clip - xa)*__builtin_amdgcn_rcpf(xb - xa);
+            const float t = (x_clip - xa)*rcp_approx(xb - xa);
             const float yc = __builtin_fmaf(t, yb - ya, ya);
             if (fa) { xb = x_clip; yb = yc; } else { xa = x_clip; ya = yc; }
         }
-        const float ysa = ya*__builtin_amdgcn_rcpf(xa), ysb = yb*__builtin_amdgcn_rcpf(xb);
+        const float ysa = ya*rcp_approx(xa), ysb = yb*rcp_approx(xb);
         ra = __builtin_fmaf(-ysa, c_b, c_a); rb = __builtin_fmaf(-ysb, c_b, c_a);
         marg = __builtin_fmaf(1e-4f, fabsf(ra) + fabsf(rb), 0.05f);
     } else {
         inc = fa | fb;                                                  // (a NaN coordinate: the reference never hits such a line)
-        const float ia = fa ? ya*__builtin_amdgcn_rcpf(xa) : 0.f, ib = fb ? yb*__builtin_amdgcn_rcpf(xb) : 0.f;
+        const float ia = fa ? ya*rcp_approx(xa) : 0.f, ib = fb ? yb*rcp_approx(xb) : 0.f;
         const float fra = __builtin_fmaf(-ia, c_b, c_a), frb = __builtin_fmaf(-ib, c_b, c_a);
         marg = __builtin_fmaf(1e-4f, fabsf(fra) + fabsf(frb), 0.05f);
         const float edge = (xa*yb - ya*xb > 0.f) ? -INFINITY : INFINITY;   // from a towards b the ray index falls / rises
@@ -1151,7 +1166,8 @@ __device__ inline void ray_interval(float xa, float ya, float xb, float yb, cons
     const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
     const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
     lo = (int)ceilf(flo);
-    len = (live & inc) ? max((int)floorf(fhi) - lo + 1, 0) : 0;
+    const int n_ = (int)floorf(fhi) - lo + 1;
+    len = (live & inc) ? (n_ > 0 ? n_ : 0) : 0;
 }
 
 // IMPL 0 ("seq"): every ray walks its group's line mask in index order - the reference's fold verbatim.
@@ -1638,9 +1654,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
             const float pqx = w.x - pp.x, pqy = w.y - pp.y;            // PQ = Q - P
             const float dbx = w.z - pp.x, dby = w.w - pp.y;
             cd = Cand{pqx, pqy, w.z - w.x, w.w - w.y};                 // v = b - a
-            // agent-frame coordinates of both endpoints
-            const float xa = __builtin_fmaf(cs, pqx, sn*pqy), ya = __builtin_fmaf(cs, pqy, -(sn*pqx));
-            const float xb = __builtin_fmaf(cs, dbx, sn*dby), yb = __builtin_fmaf(cs, dby, -(sn*dbx));
+            float xa, ya, xb, yb;
+            agent_frame(cs, sn, pqx, pqy, dbx, dby, xa, ya, xb, yb);
             ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, live, x_clip, c_a, c_b, g0, last_local, lo, len);
         };
 
@@ -3241,6 +3256,18 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
     return MS_OK;
 }
 #endif
+
+void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count) {
+    // (the launch-invariant values as ms_render works them out, the per-wave ones as render_kernel does)
+    const float half_screen = tanf(3.14159265358979323846f/180.f*fov/2.);
+    const float x_clip = 0.5f*agent_radius/sqrtf(1.f + half_screen*half_screen), c_b = 0.5f*(float)res/half_screen;
+    const float c_a = 0.5f*((float)res - 1.f), g0 = (float)(group*WAVE);
+    const int r_last = (group*WAVE + WAVE - 1 < res - 1) ? group*WAVE + WAVE - 1 : res - 1;
+    const float last_local = (float)(r_last - group*WAVE);
+    float xa, ya, xb, yb;
+    agent_frame(pose[3], pose[2], line[0] - pose[0], line[1] - pose[1], line[2] - pose[0], line[3] - pose[1], xa, ya, xb, yb);
+    ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, true, x_clip, c_a, c_b, g0, last_local, *first, *count);
+}
 
 int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius) {
     const float reach = wall_reach(p2(agent[0], agent[1]), p2(agent[2], agent[3]), agent_radius);

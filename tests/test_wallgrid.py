@@ -284,3 +284,51 @@ def test_walls_the_cull_calls_beyond_reach_cannot_stop_the_agent(oracle):
             hits_kept += x < 1
     assert hits > n//20 and hits_kept == hits, 'the sample holds plenty of collisions, none of them culled'
     assert culled > n//4, 'and the cull does cull'
+
+
+@pytest.mark.parametrize('res,fov', [(64, 130.), (512, 130.), (200, 60.), (7, 170.), (1, 90.), (128, 165.)])
+def test_no_ray_outside_a_lines_interval_hits_it(oracle, res, fov):
+    """render_kernel's pass 1 turns a line into an interval of the wave's rays and intersects it with no others
+    (DESIGN.md 3.2): every ray the oracle's raycast (kernels.cu:352-377, which tries them all) lands on the line must be
+    inside - lines near and far, behind the agent, through its near plane, across the edges of the fan, end-on, tiny."""
+    from megastep_amd import scene as scene_
+    rng = np.random.RandomState(res)
+    lib = _lib.lib()
+    E, M = 3000, len(scene_.agent_model())
+    radius = float(np.float32(.15/2**.5))
+    pos = rng.uniform(-5, 5, (E, 2)).astype(np.float32)
+    ang = rng.uniform(-180, 180, E).astype(np.float32)
+    # a wall somewhere around the agent: its middle at a log-uniform distance in a direction anywhere, any orientation
+    dist = 10.**rng.uniform(-1.3, 1.3, E)
+    where = rng.uniform(0, 2*np.pi, E)
+    mid = pos + (dist*np.array([np.cos(where), np.sin(where)])).T
+    length = 10.**rng.uniform(-3, 1.3, E)
+    along = np.where(rng.rand(E) < .3, where + rng.normal(0, .02, E), rng.uniform(0, 2*np.pi, E))   # a third: end-on
+    half = (.5*length*np.array([np.cos(along), np.sin(along)])).T
+    walls = np.concatenate([mid - half, mid + half], 1).astype(np.float32).reshape(E, 1, 2, 2)
+    model = scene_.agent_model()
+    lines = np.concatenate([np.tile(model[None], (E, 1, 1, 1)), walls], 1)              # (agent rows are redrawn by the oracle)
+    texw = np.full(E*(M + 1), 4, np.int32)
+    S = oracle.Scene(dict(n_agents=1, model=model, lights_vals=np.zeros((0, 3)), lights_widths=[0]*E,
+                          lines_vals=lines.reshape(-1, 2, 2), lines_widths=[M + 1]*E,
+                          textures_vals=np.full((texw.sum(), 3), .5), textures_widths=texw))
+    ag = dict(angles=ang.reshape(E, 1), positions=pos.reshape(E, 1, 2), angvelocity=np.zeros((E, 1), np.float32),
+              velocity=np.zeros((E, 1, 2), np.float32))
+    idx = oracle.render(S, ag, oracle.config(radius, res, fov, 10))['indices'][:, 0]
+    f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    hits = covered = 0
+    for e in range(E):
+        s_, c_ = C.c_float(), C.c_float()
+        lib.ms_host_sincospi(float(np.float32(ang[e])/np.float32(180.)), C.byref(s_), C.byref(c_))
+        pose = np.array([pos[e, 0], pos[e, 1], s_.value, c_.value], np.float32)
+        line = walls[e].reshape(4)
+        for g in range((res + 63)//64):
+            lo, n = C.c_int(), C.c_int()
+            lib.ms_host_ray_interval(pose.ctypes.data_as(f32p), line.ctypes.data_as(f32p), res, fov, radius, g, C.byref(lo), C.byref(n))
+            rays = np.nonzero(idx[e, 64*g:64*g + 64] == M)[0]
+            hits += len(rays)
+            covered += n.value
+            assert n.value == 0 or (lo.value >= 0 and lo.value + n.value <= min(64, res - 64*g)), (e, g, lo.value, n.value)
+            assert len(rays) == 0 or (rays.min() >= lo.value and rays.max() < lo.value + n.value), (e, g, rays, lo.value, n.value, pose, line)
+    assert hits > E*res//200, 'plenty of rays land on their wall'
+    assert covered < 8*hits + E, 'and the intervals are not much wider than what they must hold'
