@@ -287,6 +287,12 @@ int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int 
  * culls): pose = (x, y, sin, cos of the heading), line = (ax, ay, bx, by), `group` = which 64 rays of the agent's `res`:
  * rays first .. first + count - 1 of the group (0-based within it) are the only ones the kernel intersects with the line. */
 void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count);
+/* Host restatement of how render_kernel's pass 2 settles a ray's nearest hit (reference: the order-dependent fold
+ * kernels.cu:369-376): the n_hits hits (s[i] > near plane, line[i]) go through the kernel's three key slots in the order
+ * `order` (a permutation of 0..n_hits-1), 64 to a window, lockstep within a window as a wavefront plays them.  Returns 1
+ * when the slots cannot tell (the kernel then redoes the ray by the literal fold), else 0 with the hit in *nearest_s /
+ * *nearest_line (-1: none). */
+int ms_host_fold_hits(const float* s, const int* line, int n_hits, const int* order, float* nearest_s, int* nearest_line);
 /* Host instantiation of ms_physics' reach cull in front of the agent-agent collision test (reference: kernels.cu:119-133,
  * 193-200), for CPU tests: me, other = (x, y, vx/fps, vy/fps); 1 = the pair cannot collide this step, the test is skipped. */
 int ms_host_agents_apart(const float* me, const float* other, float agent_radius);

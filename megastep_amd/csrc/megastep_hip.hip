@@ -40,6 +40,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <string.h>
 #include "../../include/megastep_hip.h"
 
 namespace {
@@ -1123,6 +1124,62 @@ __device__ inline LateArgs late_args() {
 //   CLIP = 1: an end behind the near clip plane is clipped to it;
 //   CLIP = 0: it is replaced by the edge of the fan on the side the line leaves by (the sign of cross(a, b)) - the same
 //             interval unless the line crosses the clip plane within centimetres of the agent, for fewer instructions.
+// A ray's nearest hit out of hits that arrive in any order (render_kernel, pass 2) - the reference folds them in LINE order
+// with a hysteresis, `if (near < s && s < x - 1e-4) x = s` (kernels.cu:369-376), so its answer depends on that order.
+// A hit is a key (s bits << 32 | line): s > 0, so keys order by s, ties by line.  Three slots per ray hold the least keys
+// seen - the second and third only fed by losers within 4e-4 of what beat them, which is all that can matter to the
+// hysteresis.  hit_resolve: with (m, j*) the least key and m2 the runner-up's s, if m < m2 - 1e-4 then when the fold
+// reaches j* its state is inf or some s_k >= m2, so j* takes over, and nothing later can pass `s < m - 1e-4`: the fold
+// ends on (m, j*).  Otherwise the two best sit inside the band (a ray through a shared corner, coincident walls): with
+// the third-best clearly behind, the fold of those two in line order settles it; failing that the caller redoes the ray
+// by the literal fold (returns true).
+// These four are the merge and the resolution of render_kernel's pass 2 word for word - there they stay written out in
+// place (as calls they changed the register allocation of the whole kernel, and it is tuned to the last register); here
+// they serve ms_host_fold_hits, with which tests/test_wallgrid.py plays hits in random orders, lockstep window by
+// window as a wave does, against the literal fold.
+__host__ inline uint32_t host_f_bits(const float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+__host__ inline float host_bits_f(const uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+__host__ inline unsigned long long slot_min(unsigned long long* slot, const unsigned long long key) {   // atomicMin's stand-in
+    const unsigned long long old = *slot;
+    if (key < old) *slot = key;
+    return old;
+}
+__host__ inline unsigned long long hit_key(const float sv, const int line) { return ((unsigned long long)host_f_bits(sv) << 32) | (unsigned)line; }
+// after slot_min on the first slot returned `old`: was there a hit before this one, and does the loser of the merge go on
+// to the second slot?
+__host__ inline bool hit_loser_matters(const unsigned long long key, const float sv, const unsigned long long old, unsigned long long& lose1) {
+    const unsigned oh = (unsigned)(old >> 32);
+    if (oh == 0xffffffffu) return false;
+    const bool won = key < old;
+    const float so = host_bits_f(oh);
+    const float front = won ? sv : so, back = won ? so : sv;
+    lose1 = won ? old : key;
+    return back < front + 4.e-4f;
+}
+__host__ inline bool hit_resolve(const unsigned long long best, const unsigned long long second, const unsigned long long third,
+                                 float& nearest_s, int& nearest_idx) {
+    bool ambiguous = false;
+    if (best != ~0ull) {
+        const float s1 = host_bits_f((uint32_t)(best >> 32)), s2 = host_bits_f((uint32_t)(second >> 32)), s3 = host_bits_f((uint32_t)(third >> 32));
+        const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
+        nearest_s = s1;
+        nearest_idx = i1;
+        if ((second != ~0ull) && !(s1 < s2 - 1.e-4f)) {
+            if ((third == ~0ull) || (s2 < s3 - 1.e-4f)) {
+                const bool first_is_1 = i1 < i2;
+                const float sa = first_is_1 ? s1 : s2, sb = first_is_1 ? s2 : s1;
+                const int ia = first_is_1 ? i1 : i2, ib = first_is_1 ? i2 : i1;
+                const bool b_wins = sb < sa - 1.e-4f;
+                nearest_s = b_wins ? sb : sa;
+                nearest_idx = b_wins ? ib : ia;
+            } else {
+                ambiguous = true;
+            }
+        }
+    }
+    return ambiguous;
+}
+
 // (the hardware's approximate reciprocal on the device, a division on the host - whose instantiations of the culls exist
 // for the CPU tests: everything that goes through here only feeds margins that are thousands of roundings wide)
 __host__ __device__ inline float rcp_approx(const float x) {
@@ -3267,6 +3324,29 @@ void ms_host_ray_interval(const float* pose, const float* line, int res, float f
     float xa, ya, xb, yb;
     agent_frame(pose[3], pose[2], line[0] - pose[0], line[1] - pose[1], line[2] - pose[0], line[3] - pose[1], xa, ya, xb, yb);
     ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, true, x_clip, c_a, c_b, g0, last_local, *first, *count);
+}
+
+int ms_host_fold_hits(const float* s, const int* line, int n_hits, const int* order, float* nearest_s, int* nearest_line) {
+    // one ray's hits through the three slots the way a wave plays them: windows of 64 in the given order, and within a
+    // window in lockstep - every hit's first merge, then the second merges of those that go on, then the third
+    unsigned long long best = ~0ull, second = ~0ull, third = ~0ull;
+    for (int w0 = 0; w0 < n_hits; w0 += WAVE) {
+        const int nw = (n_hits - w0 < WAVE) ? n_hits - w0 : WAVE;
+        unsigned long long lose1[WAVE], lose2[WAVE];
+        bool on[WAVE];
+        for (int k = 0; k < nw; k++) {
+            const int h = order[w0 + k];
+            const unsigned long long key = hit_key(s[h], line[h]);
+            on[k] = hit_loser_matters(key, s[h], slot_min(&best, key), lose1[k]);
+        }
+        for (int k = 0; k < nw; k++) if (on[k]) {
+            const unsigned long long old2 = slot_min(&second, lose1[k]);
+            lose2[k] = old2 > lose1[k] ? old2 : lose1[k];
+        }
+        for (int k = 0; k < nw; k++) if (on[k] && lose2[k] != ~0ull) slot_min(&third, lose2[k]);
+    }
+    *nearest_s = INFINITY; *nearest_line = -1;
+    return hit_resolve(best, second, third, *nearest_s, *nearest_line) ? 1 : 0;
 }
 
 int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius) {

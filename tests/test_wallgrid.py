@@ -332,3 +332,44 @@ def test_no_ray_outside_a_lines_interval_hits_it(oracle, res, fov):
             assert len(rays) == 0 or (rays.min() >= lo.value and rays.max() < lo.value + n.value), (e, g, rays, lo.value, n.value, pose, line)
     assert hits > E*res//200, 'plenty of rays land on their wall'
     assert covered < 8*hits + E, 'and the intervals are not much wider than what they must hold'
+
+
+def test_three_key_slots_settle_a_ray_like_the_literal_fold():
+    """The reference folds a ray's hits in LINE order with a hysteresis - `if (near < s && s < x - 1e-4) x = s`
+    (kernels.cu:369-376) - so its answer depends on that order; render_kernel meets the hits in whatever order its lists
+    and its 64 lanes bring them and keeps three keys per ray.  Hits in clusters inside the band,
+    coincident walls, duplicates of one distance, far-apart hits; every set played in several random orders, lockstep
+    window by window: either the slots say they cannot tell (the kernel then folds literally) or they give the fold's hit."""
+    rng = np.random.RandomState(0)
+    lib = _lib.lib()
+    f32p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    settled = unsure = 0
+    for trial in range(6000):
+        n = int(rng.choice([1, 2, 3, 4, 6, 10, 40, 100, 200]))
+        kind = trial % 4
+        if kind == 0:                                  # scattered
+            s = rng.uniform(.2, 20., n)
+        elif kind == 1:                                # a cluster in the band at the front, others behind
+            s = np.concatenate([3. + rng.uniform(0, 3e-4, (n + 1)//2), rng.uniform(3., 9., n//2)])
+        elif kind == 2:                                # steps just under / just over the hysteresis, a chain of them
+            s = 5. - np.cumsum(rng.choice([.9e-4, .99e-4, 1.01e-4, 1.1e-4, 2e-4], n))
+        else:                                          # exact duplicates and near-duplicates
+            s = rng.choice(np.float32([2., 2. + 1e-4, 2. + 5e-5, 2. - 1e-4, 7.]), n) + rng.choice([0., 0., 1e-7], n)
+        s = np.ascontiguousarray(s, np.float32)
+        line = np.ascontiguousarray(rng.permutation(4*n)[:n], np.int32)          # distinct lines, any order
+        # the literal fold, in line order (float32 arithmetic, as the kernels')
+        x, xi = np.float32(np.inf), -1
+        for k in np.argsort(line):
+            if s[k] < x - np.float32(1e-4):
+                x, xi = s[k], int(line[k])
+        for rep in range(4):
+            order = np.ascontiguousarray(rng.permutation(n), np.int32)
+            out_s, out_i = C.c_float(), C.c_int()
+            amb = lib.ms_host_fold_hits(s.ctypes.data_as(f32p), line.ctypes.data_as(i32p), n, order.ctypes.data_as(i32p),
+                                        C.byref(out_s), C.byref(out_i))
+            if amb:
+                unsure += 1
+            else:
+                settled += 1
+                assert out_i.value == xi and np.float32(out_s.value) == x, (trial, rep, s, line, order, out_s.value, out_i.value, x, xi)
+    assert settled > unsure > 1000, 'settled by the slots more often than not, even here; and the sample does reach the cases they leave to the fold'
