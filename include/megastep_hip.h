@@ -287,6 +287,13 @@ int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int 
  * culls): pose = (x, y, sin, cos of the heading), line = (ax, ay, bx, by), `group` = which 64 rays of the agent's `res`:
  * rays first .. first + count - 1 of the group (0-based within it) are the only ones the kernel intersects with the line. */
 void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count);
+/* Host instantiation of the light grid's build (ms_bake; accelerates kernels.cu:238-268) for one cell c (row-major in a grid
+ * of nx x ny cells of size `cell` from (ox, oy)), over n_walls walls (n_walls x 4 floats: ax, ay, bx, by) and n_lights
+ * lights (n_lights x 3: x, y, intensity), HOST memory: words[4] = the lights' 2-bit verdicts as in lg_vals (0 unknown, 1 lit,
+ * 2 dark); candidates = the (light, wall) pairs of the cell's list as in lg_pool (0x80000000 | light << 24 | wall), at most
+ * max_candidates of them written; returns how many there are. */
+int ms_host_lightgrid_cell(const float* walls, int n_walls, const float* lights, int n_lights, float ox, float oy, int nx, int ny,
+                           float cell, int c, unsigned* words, unsigned* candidates, int max_candidates);
 /* Host restatement of how render_kernel's pass 2 settles a ray's nearest hit (reference: the order-dependent fold
  * kernels.cu:369-376): the n_hits hits (s[i] > near plane, line[i]) go through the kernel's three key slots in the order
  * `order` (a permutation of 0..n_hits-1), 64 to a window, lockstep within a window as a wavefront plays them.  Returns 1

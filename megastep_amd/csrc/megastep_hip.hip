@@ -2751,7 +2751,7 @@ struct LgView {                        // the cell as one light sees it
     float ex, ey, el;                  // corridor frame: unit vector light -> cell centre, its length
 };
 
-__device__ inline LgCell lg_cell_of(const float4 geom, const float cell, const int c) {
+__host__ __device__ inline LgCell lg_cell_of(const float4 geom, const float cell, const int c) {
     const int nx = (int)geom.z;
     const int ix = c % nx, iy = c / nx;
     LgCell k;
@@ -2762,7 +2762,7 @@ __device__ inline LgCell lg_cell_of(const float4 geom, const float cell, const i
     return k;
 }
 
-__device__ inline LgView lg_view_of(const LgCell& k, const P2 I) {
+__host__ __device__ inline LgView lg_view_of(const LgCell& k, const P2 I) {
     LgView v;
     v.I = I;
     const float dx = k.ctr.x - I.x, dy = k.ctr.y - I.y;
@@ -2773,7 +2773,7 @@ __device__ inline LgView lg_view_of(const LgCell& k, const P2 I) {
 }
 
 // Can wall w = (ax, ay, vx, vy) shadow any point of the cell from the light?  false only when provably not.
-__device__ inline bool lg_touches(const LgCell& k, const LgView& v, const float4 w) {
+__host__ __device__ inline bool lg_touches(const LgCell& k, const LgView& v, const float4 w) {
     const float ax = w.x - k.ctr.x, ay = w.y - k.ctr.y, bx = ax + w.z, by = ay + w.w;
     const float m = k.rho + 1e-4f*(fabsf(ax) + fabsf(ay) + fabsf(bx) + fabsf(by));
     const float ua = v.ex*ax + v.ey*ay, va = v.ex*ay - v.ey*ax;
@@ -2798,6 +2798,25 @@ __device__ inline bool lg_touches(const LgCell& k, const LgView& v, const float4
     const bool opp_b = beyond(-sb, b0, lb2) & beyond(-sb, b1, lb2) & beyond(-sb, b2, lb2) & beyond(-sb, b3, lb2);
     const bool front = same(si, w0_, lv2) & same(si, w1_, lv2) & same(si, w2_, lv2) & same(si, w3_, lv2);
     return !(opp_a | opp_b | front);
+}
+
+// Does wall w = (ax, ay, vx, vy) shadow the whole cell from the light - all four corners, with room to spare (|UxV| >= 1e-2,
+// t in (d, 1-d), s in (d, .999-d), d = 2e-3)?  For a fixed light and wall obstructed()'s conditions are affine inequalities
+// in the point, so then they hold on the whole cell.
+__host__ __device__ inline bool lg_shadows(const LgView& v, const float4 w) {
+    const P2 V = p2(w.z, w.w), PQ = p2(w.x, w.y) - v.I;
+    const float c1 = cross(PQ, V);
+    const float d0 = cross(v.U0, V), d1 = cross(v.U1, V), d2 = cross(v.U2, V), d3 = cross(v.U3, V);
+    const float sg = d0 < 0.f ? -1.f : 1.f;
+    const float e0 = sg*d0, e1 = sg*d1, e2 = sg*d2, e3 = sg*d3, cc = sg*c1;
+    bool full = (e0 >= 1e-2f) & (e1 >= 1e-2f) & (e2 >= 1e-2f) & (e3 >= 1e-2f);
+    const float n0 = sg*cross(PQ, v.U0), n1 = sg*cross(PQ, v.U1), n2 = sg*cross(PQ, v.U2), n3 = sg*cross(PQ, v.U3);
+    constexpr float D = 2e-3f;
+    full &= (n0 > D*e0) & (n0 < (1.f - D)*e0) & (n1 > D*e1) & (n1 < (1.f - D)*e1) &
+            (n2 > D*e2) & (n2 < (1.f - D)*e2) & (n3 > D*e3) & (n3 < (1.f - D)*e3);
+    full &= (cc > D*e0) & (cc < (.999f - D)*e0) & (cc > D*e1) & (cc < (.999f - D)*e1) &
+            (cc > D*e2) & (cc < (.999f - D)*e2) & (cc > D*e3) & (cc < (.999f - D)*e3);
+    return full;
 }
 
 __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
@@ -2835,20 +2854,7 @@ __global__ __launch_bounds__(WG) void lightgrid_kernel(const MsScenery sc) {
                 const float4 w = s_wall[j];
                 if (!lg_touches(k, v, w)) continue;
                 touched |= bit;
-                // does this wall shadow the whole cell?
-                const P2 V = p2(w.z, w.w), PQ = p2(w.x, w.y) - v.I;
-                const float c1 = cross(PQ, V);
-                const float d0 = cross(v.U0, V), d1 = cross(v.U1, V), d2 = cross(v.U2, V), d3 = cross(v.U3, V);
-                const float sg = d0 < 0.f ? -1.f : 1.f;
-                const float e0 = sg*d0, e1 = sg*d1, e2 = sg*d2, e3 = sg*d3, cc = sg*c1;
-                bool full = (e0 >= 1e-2f) & (e1 >= 1e-2f) & (e2 >= 1e-2f) & (e3 >= 1e-2f);
-                const float n0 = sg*cross(PQ, v.U0), n1 = sg*cross(PQ, v.U1), n2 = sg*cross(PQ, v.U2), n3 = sg*cross(PQ, v.U3);
-                constexpr float D = 2e-3f;
-                full &= (n0 > D*e0) & (n0 < (1.f - D)*e0) & (n1 > D*e1) & (n1 < (1.f - D)*e1) &
-                        (n2 > D*e2) & (n2 < (1.f - D)*e2) & (n3 > D*e3) & (n3 < (1.f - D)*e3);
-                full &= (cc > D*e0) & (cc < (.999f - D)*e0) & (cc > D*e1) & (cc < (.999f - D)*e1) &
-                        (cc > D*e2) & (cc < (.999f - D)*e2) & (cc > D*e3) & (cc < (.999f - D)*e3);
-                if (full) { dark |= bit; break; }
+                if (lg_shadows(v, w)) { dark |= bit; break; }
             }
         }
     }
@@ -3324,6 +3330,36 @@ void ms_host_ray_interval(const float* pose, const float* line, int res, float f
     float xa, ya, xb, yb;
     agent_frame(pose[3], pose[2], line[0] - pose[0], line[1] - pose[1], line[2] - pose[0], line[3] - pose[1], xa, ya, xb, yb);
     ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, true, x_clip, c_a, c_b, g0, last_local, *first, *count);
+}
+
+int ms_host_lightgrid_cell(const float* walls, int n_walls, const float* lights, int n_lights, float ox, float oy, int nx, int ny,
+                           float cell, int c, unsigned* words, unsigned* candidates, int max_candidates) {
+    // lightgrid_kernel's verdicts and lightlist_kernel's candidates for one cell, from the predicates those are compiled from
+    const LgCell k = lg_cell_of(make_float4(ox, oy, (float)nx, (float)ny), cell, c);
+    const int num_i = n_lights < LG_LIGHTS ? n_lights : LG_LIGHTS;
+    words[0] = words[1] = words[2] = words[3] = 0u;
+    int count = 0;
+    for (int i = 0; i < num_i; i++) {
+        const LgView v = lg_view_of(k, p2(lights[3*i], lights[3*i + 1]));
+        bool touched = false, dark = false;
+        for (int j = 0; j < n_walls && !dark; j++) {
+            const float4 w = make_float4(walls[4*j], walls[4*j + 1], walls[4*j + 2] - walls[4*j], walls[4*j + 3] - walls[4*j + 1]);
+            if (!lg_touches(k, v, w)) continue;
+            touched = true;
+            dark = lg_shadows(v, w);
+        }
+        const unsigned st = dark ? 2u : (touched ? 0u : 1u);
+        words[i >> 4] |= st << (2*(i & 15));
+        if (st == 0u) {
+            for (int j = 0; j < n_walls; j++) {
+                const float4 w = make_float4(walls[4*j], walls[4*j + 1], walls[4*j + 2] - walls[4*j], walls[4*j + 3] - walls[4*j + 1]);
+                if (!lg_touches(k, v, w)) continue;
+                if (count < max_candidates) candidates[count] = 0x80000000u | ((unsigned)i << 24) | (unsigned)j;
+                count++;
+            }
+        }
+    }
+    return count;
 }
 
 int ms_host_fold_hits(const float* s, const int* line, int n_hits, const int* order, float* nearest_s, int* nearest_line) {

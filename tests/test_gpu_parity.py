@@ -179,17 +179,7 @@ def test_full_benchmark_size_matches_oracle():
         util.assert_render_matches(c, r, ref.render())
 
 
-def _obstructed(I, C, walls):
-    """obstructed() of kernels.cu:253-257 in float32 numpy: (n_points, n_walls) booleans."""
-    f = np.float32
-    a, v = walls[None, :, 0], (walls[:, 1] - walls[:, 0])[None]
-    U = (C - I)[:, None]
-    d = U[..., 0]*v[..., 1] - U[..., 1]*v[..., 0]
-    PQ = a - I
-    with np.errstate(divide='ignore', invalid='ignore'):
-        s = (PQ[..., 0]*v[..., 1] - PQ[..., 1]*v[..., 0])/d
-        t = (PQ[..., 0]*U[..., 1] - PQ[..., 1]*U[..., 0])/d
-    return (np.abs(d) >= f(1e-3)) & (t > 0) & (t < 1) & (s > 0) & (s < f(.999))
+_obstructed = util.obstructed
 
 
 def test_light_grid_verdicts_hold_for_every_sampled_point():

@@ -373,3 +373,52 @@ def test_three_key_slots_settle_a_ray_like_the_literal_fold():
                 settled += 1
                 assert out_i.value == xi and np.float32(out_s.value) == x, (trial, rep, s, line, order, out_s.value, out_i.value, x, xi)
     assert settled > unsure > 1000, 'settled by the slots more often than not, even here; and the sample does reach the cases they leave to the fold'
+
+
+@pytest.mark.parametrize('name', ['plan0', 'plan1', 'plan3', 'large', 'box', 'column'])
+def test_light_grid_verdicts_and_candidates_hold_on_every_sampled_point(name):
+    """The light grid (ms_bake) may call a light LIT or DARK for a cell only where the reference's
+    obstructed() (kernels.cu:253-257) says so at EVERY point of the cell, and the candidate walls it lists for the lights
+    it leaves open must reproduce obstructed()'s verdict over all walls at every point - checked on the library's host
+    instantiation of the build (the predicates the gfx950 kernels are compiled from), points all over the cell and on its
+    corners.  (tests/test_gpu_parity.py does the same with the grid a GPU built.)"""
+    from tests import util
+    rng = np.random.RandomState(3)
+    if name.startswith('plan') or name == 'large':
+        g = cubicasa.sample(1, n_unique=16, large=True)[0] if name == 'large' else cubicasa.sample(4, n_unique=16)[int(name[4])]
+    else:
+        g = toys.box() if name == 'box' else toys.column()
+    walls = np.ascontiguousarray(g.walls, np.float32)
+    pos = np.asarray(g.lights, np.float32).reshape(-1, 2)
+    lo, hi = walls.reshape(-1, 2).min(0), walls.reshape(-1, 2).max(0)
+    extra = rng.uniform(lo, hi, (6, 2)).astype(np.float32)                    # a few lights anywhere, inside walls or not
+    lights = np.ascontiguousarray(np.concatenate([np.concatenate([pos, extra])[:64], np.ones((min(len(pos) + 6, 64), 1), np.float32)], 1), np.float32)
+    origin, dims = grid_of(walls)
+    lib = _lib.lib()
+    flat = np.ascontiguousarray(walls.reshape(-1, 4))
+    n_lit = n_dark = n_open = 0
+    for c in rng.choice(dims[0]*dims[1], min(40 if name == 'large' else 120, dims[0]*dims[1]), replace=False):
+        words, cands = np.zeros(4, np.uint32), np.zeros(4096, np.uint32)
+        n = lib.ms_host_lightgrid_cell(flat.ctypes.data, len(flat), lights.ctypes.data, len(lights), float(origin[0]), float(origin[1]),
+                                       int(dims[0]), int(dims[1]), CELL, int(c), words.ctypes.data, cands.ctypes.data, len(cands))
+        assert 0 <= n <= len(cands)
+        cands = cands[:n]
+        assert ((cands >> 31) == 1).all()
+        x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
+        pts = (np.array([x0, y0]) + rng.uniform(0, CELL, (24, 2))).astype(np.float32)
+        pts = np.concatenate([pts, np.float32([[x0, y0], [x0 + CELL, y0], [x0, y0 + CELL], [x0 + CELL, y0 + CELL]])])
+        for i, light in enumerate(lights):
+            state = (int(words[i >> 4]) >> (2*(i & 15))) & 3
+            blocked = util.obstructed(light[:2], pts, walls).any(1)
+            if state == 1:
+                assert not blocked.any(), (name, c, i, 'LIT cell has a shadowed point')
+                n_lit += 1
+            elif state == 2:
+                assert blocked.all(), (name, c, i, 'DARK cell has a lit point')
+                n_dark += 1
+            else:
+                mine = [int(k & 0xffffff) for k in cands if (int(k) >> 24) & 63 == i]
+                few = util.obstructed(light[:2], pts, walls[mine]).any(1) if mine else np.zeros(len(pts), bool)
+                assert (few == blocked).all(), (name, c, i, 'candidate list misses a blocker')
+                n_open += 1
+    assert n_lit > 20 and n_dark > 20 and n_open > 20, (n_lit, n_dark, n_open)

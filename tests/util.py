@@ -183,3 +183,16 @@ def assert_subset_matches(core, sub, p, r):
     for k in ('indices', 'locations', 'dots', 'distances', 'screen'):
         setattr(R, k, getattr(r, k)[e])
     assert_render_matches(None, R, sub.render())
+
+
+def obstructed(I, C, walls):
+    """obstructed() of kernels.cu:253-257 in float32 numpy: (n_points, n_walls) booleans."""
+    f = np.float32
+    a, v = walls[None, :, 0], (walls[:, 1] - walls[:, 0])[None]
+    U = (C - I)[:, None]
+    d = U[..., 0]*v[..., 1] - U[..., 1]*v[..., 0]
+    PQ = a - I
+    with np.errstate(divide='ignore', invalid='ignore'):
+        s = (PQ[..., 0]*v[..., 1] - PQ[..., 1]*v[..., 0])/d
+        t = (PQ[..., 0]*U[..., 1] - PQ[..., 1]*U[..., 0])/d
+    return (np.abs(d) >= f(1e-3)) & (t > 0) & (t < 1) & (s > 0) & (s < f(.999))
