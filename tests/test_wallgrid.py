@@ -424,3 +424,60 @@ def test_light_grid_verdicts_and_candidates_hold_on_every_sampled_point(name):
                 assert (few == blocked).all(), (name, c, i, 'candidate list misses a blocker')
                 n_open += 1
     assert n_lit > 20 and n_dark > 20 and n_open > 20, (n_lit, n_dark, n_open)
+
+
+@pytest.mark.parametrize('name,res,fov', [('plan0', 64, 130.), ('plan1', 256, 130.), ('plan2_mutated', 128, 90.), ('plan6', 512, 60.),
+                                          ('large', 64, 160.), ('column', 32, 130.)])
+def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fov):
+    """What a render wave intersects, put together on the host from the pieces the kernel is compiled from: the walls on
+    the vis list of the agent's cell, less those whose view arc misses the run of directions of the wave's own rays
+    (first ray to last), each with its interval of the wave's rays.  For poses all over sampled cells the oracle's raycast
+    of the WHOLE world (kernels.cu:352-377) must land every ray on a (wall, ray) pair of that set - and, since the set
+    only ever leaves out pairs that do not intersect, the fold over it then ends where the fold over everything does."""
+    walls = case_walls(name)
+    rng = np.random.RandomState(7)
+    lib = _lib.lib()
+    origin, dims = grid_of(walls)
+    M = len(scene.agent_model())
+    cells = rng.choice(dims[0]*dims[1], 6 if name == 'large' else 16, replace=False)
+    poses, cell_of = [], []
+    for c in cells:
+        x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
+        for k in range(4):
+            u = rng.uniform(0, 1, 2) if k < 3 else rng.choice([0., 1.], 2)
+            poses.append((x0 + u[0]*CELL, y0 + u[1]*CELL, rng.uniform(-180, 180)))
+            cell_of.append(c)
+    full, _ = worlds(oracle, walls, poses, fov=fov, res=res)
+    f32, f32p, i32p = np.float32, C.POINTER(C.c_float), C.POINTER(C.c_int)
+    half_screen = f32(np.tan(np.pi/180*fov/2))
+    lists = {c: (scan_cell(walls, origin, dims, c)[0], [wall_arc(w, origin, dims, c) for w in walls]) for c in cells}
+    kept_pairs = all_pairs = on_walls = 0
+    for i, (x, y, a) in enumerate(poses):
+        vis, arcs = lists[cell_of[i]]
+        s_, c_ = C.c_float(), C.c_float()
+        lib.ms_host_sincospi(float(f32(a)/f32(180.)), C.byref(s_), C.byref(c_))
+        sn, cs = f32(s_.value), f32(c_.value)
+        pose = np.array([x, y, sn, cs], f32)
+        r = np.arange(res, dtype=f32)
+        uy = (f32(res) - f32(2)*r - f32(1))*half_screen/f32(res)           # ray_y, kernels.cu:234-236, in float32 as the kernel
+        rx, ry = cs*f32(1) - sn*uy, sn*f32(1) + cs*uy
+        for g in range((res + 63)//64):
+            first, last = 64*g, min(64*g + 63, res - 1)
+            allowed = np.zeros((len(walls), last - first + 1), bool)
+            for t in np.nonzero(vis)[0]:
+                lo8, hi8 = arcs[t]
+                # rays run from the left of the view (ray 0) to its right: the wave's rightmost ray is its last
+                if not lib.ms_host_wedge_meets(float(rx[last]), float(ry[last]), float(rx[first]), float(ry[first]), lo8, hi8):
+                    continue
+                lo, n = C.c_int(), C.c_int()
+                lib.ms_host_ray_interval(pose.ctypes.data_as(f32p), np.ascontiguousarray(walls[t].reshape(4)).ctypes.data_as(f32p),
+                                         res, fov, float(core.AGENT_RADIUS), g, C.byref(lo), C.byref(n))
+                allowed[t, lo.value:lo.value + n.value] = True
+            hit = full[i, first:last + 1]
+            for k in np.nonzero(hit >= M)[0]:
+                assert allowed[hit[k] - M, k], (name, i, g, k, int(hit[k] - M), poses[i])
+            on_walls += int((hit >= M).sum())
+            kept_pairs += int(allowed.sum())
+            all_pairs += allowed.size
+    assert on_walls > (50 if name == 'column' else len(poses)*res//3), 'rays do land on walls'
+    assert kept_pairs < .2*all_pairs, f'{kept_pairs/all_pairs:.2f} of all (wall, ray) pairs are kept: nothing is being culled'
