@@ -307,6 +307,8 @@ int ms_host_agents_apart(const float* me, const float* other, float agent_radius
  * wall = (ax, ay, bx, by); 1 = the wall is beyond the agent's reach this step, the test is skipped.  (The host evaluates the
  * foot of the perpendicular with a true division, the kernel with v_rcp_f32: both are lower bounds on the distance.) */
 int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius);
+/* ... and the reach itself, which also picks the tier of the cell's near list (wg_reach_lo, wg_reach) or the sweep. */
+float ms_host_wall_reach(const float* agent, float agent_radius);
 /* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
  * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);

@@ -72,7 +72,7 @@ SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_coun
            'ms_step_physics',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
            'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
-           'ms_host_wedge_meets', 'ms_host_agents_apart', 'ms_host_wall_beyond_reach', 'ms_host_ray_interval', 'ms_host_fold_hits', 'ms_host_lightgrid_cell')
+           'ms_host_wedge_meets', 'ms_host_agents_apart', 'ms_host_wall_beyond_reach', 'ms_host_ray_interval', 'ms_host_fold_hits', 'ms_host_lightgrid_cell', 'ms_host_wall_reach')
 
 
 def _source_hash():
@@ -165,6 +165,8 @@ def lib():
         handle.ms_host_agents_apart.restype = C.c_int
         handle.ms_host_wall_beyond_reach.argtypes = [_f32p, _f32p, C.c_float]
         handle.ms_host_wall_beyond_reach.restype = C.c_int
+        handle.ms_host_wall_reach.argtypes = [_f32p, C.c_float]
+        handle.ms_host_wall_reach.restype = C.c_float
         handle.ms_host_wall_hidden.argtypes = [C.c_float]*4 + [_f32p, _f32p, C.c_float]
         handle.ms_host_wall_hidden.restype = C.c_int
         handle.ms_host_wallgrid_cell.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,

@@ -3385,6 +3385,8 @@ int ms_host_fold_hits(const float* s, const int* line, int n_hits, const int* or
     return hit_resolve(best, second, third, *nearest_s, *nearest_line) ? 1 : 0;
 }
 
+float ms_host_wall_reach(const float* agent, float agent_radius) { return wall_reach(p2(agent[0], agent[1]), p2(agent[2], agent[3]), agent_radius); }
+
 int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius) {
     const float reach = wall_reach(p2(agent[0], agent[1]), p2(agent[2], agent[3]), agent_radius);
     return wall_beyond(make_float4(agent[0], agent[1], agent[2], agent[3]), make_float4(wall[0], wall[1], wall[2], wall[3]),

@@ -481,3 +481,44 @@ def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fo
             all_pairs += allowed.size
     assert on_walls > (50 if name == 'column' else len(poses)*res//3), 'rays do land on walls'
     assert kept_pairs < .2*all_pairs, f'{kept_pairs/all_pairs:.2f} of all (wall, ray) pairs are kept: nothing is being culled'
+
+
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'plan7', 'box'])
+def test_the_walls_a_physics_wave_meets_are_all_that_can_stop_the_agent(oracle, name):
+    """ms_physics' chain put together on the host: the agent's reach picks the short or the long tier of its cell's near
+    list (or, past the long one, every wall), the reach cull drops what is beyond, the rest goes through the exact test -
+    and the least progress over those must be the least over ALL the env's walls (kernels.cu:202-221), for agents
+    anywhere in sampled cells, from a sprint that outruns the lists down to a crawl whose reach outgrows them."""
+    walls = case_walls(name)
+    rng = np.random.RandomState(9)
+    lib, cs = _lib.lib(), oracle.lib().oracle_collision_cs
+    f32p = C.POINTER(C.c_float)
+    origin, dims = grid_of(walls)
+    R = float(core.AGENT_RADIUS)
+    flat = [np.ascontiguousarray(w.reshape(4), np.float32) for w in walls]
+    listed = swept = stops = met = 0
+    for c in rng.choice(dims[0]*dims[1], 30, replace=False):
+        _, close = scan_cell(walls, origin, dims, c)
+        x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
+        for k in range(8):
+            u = rng.uniform(0, 1, 2) if k < 6 else rng.choice([0., 1.], 2)
+            speed = 10.**rng.uniform(-9, .3)                                    # per step: a nanometre to two metres
+            a = rng.uniform(0, 2*np.pi)
+            agent = np.array([x0 + u[0]*CELL, y0 + u[1]*CELL, speed*np.cos(a), speed*np.sin(a)], np.float32)
+            ap = agent.ctypes.data_as(f32p)
+            reach = lib.ms_host_wall_reach(ap, R)
+            if reach <= REACH_LO: mine = np.nonzero(close >= 2)[0]
+            elif reach <= REACH: mine = np.nonzero(close >= 1)[0]
+            else: mine = np.arange(len(walls))                                  # the sweep
+            listed += reach <= REACH; swept += reach > REACH
+            x_all = min((cs(*[float(t) for t in agent], *[float(t) for t in w], R) for w in flat), default=1.)
+            x_mine = 1.
+            for t in mine:
+                if not lib.ms_host_wall_beyond_reach(ap, flat[t].ctypes.data_as(f32p), R):
+                    met += reach <= REACH
+                    x_mine = min(x_mine, cs(*[float(v) for v in agent], *[float(v) for v in flat[t]], R))
+            assert x_mine == x_all, (name, c, k, agent, reach, x_mine, x_all)
+            stops += x_all < 1
+    assert listed > 100 and swept > 5 and stops > 20, (listed, swept, stops)
+    if name != 'box':
+        assert met < .1*listed*len(walls), 'an agent whose reach the lists cover meets a fraction of the walls'
