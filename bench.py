@@ -12,7 +12,9 @@ The K timed steps are enqueued as ONE HIP graph (2K kernel nodes, recorded once,
 one from Python (`eager`) are timed beside it, with HIP events around every step and every render for the per-step
 spread and the roofline.
 
-With --gpus N>1 the driver launches this file under torch.distributed.run, one rank per GPU. The job holds N x
+With --gpus N>1 there is one rank per GPU: `python bench.py --gpus N` on its own starts the N ranks itself
+(torch.distributed.run on this node, 127.0.0.1, a free port; it refuses if the node has fewer GPUs), and under a launcher
+that has already set WORLD_SIZE (the driver's torch.distributed.run command) it is one of them. The job holds N x
 --envs envs; every rank works out the same contiguous cuts (balanced by lines x agents x rays) from the floorplans on
 the host and builds and bakes ITS slice only - weak scaling, no collective on the data path: envs are independent; the
 ranks meet only in a gloo barrier around each timed region and a MAX over their times, so RCCL is never initialised.
@@ -337,6 +339,27 @@ class _Stub:
         return fn
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside any launcher: starts the N ranks itself - one process per GPU (the reference's
+    model: one device per process, common.h:39-41) under torch.distributed.run on this node, rendezvous on 127.0.0.1 at a
+    free port, rank r on device r - and passes rank 0's JSON line through. Refuses loudly when the node has fewer GPUs."""
+    import socket
+    import subprocess
+    if not args.dry_run_cpu:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} asked for, but this node shows {have} GPU(s)')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '8'))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    log(f'starting {args.gpus} ranks: {" ".join(cmd[1:8])} ...')
+    raise SystemExit(subprocess.call(cmd, env=env, cwd=ROOT))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -355,8 +378,13 @@ def main(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
     ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
     args = ap.parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args, sys.argv[1:] if argv is None else list(argv))
 
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python bench.py --gpus N starts them itself)')
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     distributed = world > 1
     import faulthandler
@@ -417,6 +445,8 @@ def main(argv=None):
         for i in range(args.warmup):
             hot(views[i])
 
+    own = []
+
     def timed(run):
         """One timed region: W untimed warm-up steps from the spawn points, then exactly K steps between barrier +
         synchronize pairs; the slowest rank's wall time."""
@@ -426,6 +456,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         run()
         dev.sync()
+        own.append(time.perf_counter() - t0)                           # this rank's own time, before it waits for the others
         barrier()
         return sharding.max_over_ranks(time.perf_counter() - t0)       # the slowest rank sets the step rate
 
@@ -464,11 +495,14 @@ def main(argv=None):
 
     elapsed = graph_s if graph_s is not None else eager_s
     runs = graph_runs if graph_runs is not None else eager_runs
+    # every rank's own median region of the leg `value` comes from (before it waits for the others): an imbalance shows here
+    per_rank = [(N, 1e3*float(np.median(own[-len(runs):]))/args.steps)]
     n_total = N
     if distributed:
-        t = torch.tensor([N], dtype=torch.int64)
-        dist.all_reduce(t)
-        n_total = int(t)
+        gathered = [None]*world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+        n_total = sum(n for n, _ in per_rank)
     rb, pb = algorithmic_bytes(core)
     flops = all_pairs_flops(core)
     achieved = rb/(render_ms*1e-3)/1e9
@@ -489,6 +523,7 @@ def main(argv=None):
             'lines_per_env': scenery.lines.vals.shape[0]/N, 'lights_per_env': scenery.lights.vals.shape[0]/N,
             'parallelism': f'env-sharded x{world} (contiguous slices balanced by lines x agents x rays), no collectives'},
         'agent_steps_per_sec': value*A,
+        'per_rank': {'envs': [n for n, _ in per_rank], 'ms_per_step': [t for _, t in per_rank]},
         # `value` is the MEDIAN timed region (each exactly K steps between barrier + synchronize pairs); the spread:
         'timed_regions': {'count': int(len(runs)), 'ms_per_step_min': 1e3*float(runs.min())/args.steps,
                           'ms_per_step_median': ms_per_step, 'ms_per_step_max': 1e3*float(runs.max())/args.steps},

@@ -131,3 +131,22 @@ def test_bake_bins_never_hide_an_obstructing_wall():
         narrow += count.value < 64
         assert pb == -1 or (pb - first.value) % 64 < count.value, (i, pb, first.value, count.value)
     assert narrow > 1000        # the bins do cull
+
+
+def test_a_compile_error_is_never_papered_over_with_the_library_on_disk(monkeypatch):
+    """Sources that differ from what the in-tree library was built from and do not compile: lib() must raise, not load
+    yesterday's kernels (a missing toolchain is the one case in which the library on disk is taken as it is)."""
+    import subprocess
+    import types
+    from megastep_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, '_source_hash', lambda: 'edited')
+    monkeypatch.delenv('MEGASTEP_HIP_LIB', raising=False)
+    monkeypatch.setattr(subprocess, 'run', lambda *a, **k: types.SimpleNamespace(returncode=1, stdout='', stderr='error: expected ;'))
+    with pytest.raises(RuntimeError, match='hipcc build of libmegastep_hip.so failed'):
+        _lib.lib()
+    # ... whereas without the tools the library that is there is loaded, with a warning
+    monkeypatch.setenv('HIPCC', '/nonexistent/hipcc')
+    with pytest.warns(UserWarning, match='could not be rebuilt'):
+        assert _lib.lib().ms_abi_version() == _lib.ABI_VERSION

@@ -8,11 +8,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(nproc, extra=()):
+def _run(nproc, extra=(), self_launch=False):
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
+        env.pop(k, None)
     args = ['--gpus', str(nproc), '--steps', '6', '--warmup', '2', '--envs', '24', '--agents', '2', '--res', '16',
             '--unique', '16', '--dry-run-cpu', *extra]
-    if nproc == 1:
+    if nproc == 1 or self_launch:
         cmd = [sys.executable, 'bench.py', *args]
     else:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}',
@@ -38,9 +40,27 @@ def test_bench_line_two_ranks_gloo():
     assert out['roofline']['algorithmic_bytes_per_launch'] > 0 and 'no collectives' in cfg['parallelism']
 
 
+def test_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as the driver types it, no torchrun around it: bench.py starts the two ranks itself
+    (one process per device, reference common.h:39-41) and rank 0's line says n_gpus 2 and counts both slices."""
+    out = _run(2, self_launch=True)
+    assert out['n_gpus'] == 2 and out['config']['envs_total'] == 2*24
+    pr = out['per_rank']
+    assert len(pr['envs']) == 2 and sum(pr['envs']) == 48 and len(pr['ms_per_step']) == 2
+    assert all(0 < t <= out['ms_per_step']*1.5 + 1 for t in pr['ms_per_step'])
+
+
+def test_world_size_must_match_the_gpus_asked_for():
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', WORLD_SIZE='1', RANK='0')
+    proc = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--dry-run-cpu', '--envs', '8', '--unique', '8'], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=300)
+    assert proc.returncode != 0 and 'WORLD_SIZE' in proc.stderr
+
+
 def test_bench_line_single_rank():
     out = _run(1, ('--no-graph',))
     assert out['n_gpus'] == 1 and out['config']['envs_total'] == 24 and out['config']['envs_this_rank'] == 24
+    assert out['per_rank']['envs'] == [24] and len(out['per_rank']['ms_per_step']) == 1
     assert 'eager' in out['config']['launch']
 
 
