@@ -32,8 +32,11 @@ Besides the contract fields the line carries
   cpu_baseline  a pure-PyTorch CPU step (oracle/torch_step.py, the restatement of the reference's kernels as tensor
                 ops) on this box's host cores, on a bounded sample of the same workload - reported only, never the
                 target; `cpu_baseline_c` is the plain-C port with OpenMP over envs on the same sample;
+  shapes        BASELINE.json's other single-GPU shapes under the same protocol at K = 20, W = 5: C2 with all five planes
+                and depth-only, C3, 512 rays, C5's per-GPU share - ms per step, env-steps/s, the render kernel's HIP-event
+                median and its roofline fraction from that shape's own algorithmic bytes (N = 1 only);
   env_step      whole `env.step()` rates of the reference-shaped Explorer and Deathmatch envs (what the reference's
-                docs quote), eager and replayed as a HIP graph.
+                docs quote), eager and replayed as a HIP graph; `env_step_headline_shape` the same at the headline shape.
 """
 import argparse
 import json
@@ -58,10 +61,24 @@ def log(msg):
         print(f'[bench {time.perf_counter() - _T0:7.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
-def world_geometries(n_envs, world, seed, n_unique=512, large=False):
-    """The floorplan of every env of the whole (world x n_envs)-env job: a pool of distinct plans, tiled."""
+def plan_count(n_envs, n_agents, unique=None):
+    """SURVEY 8(d): distinct floorplans = max(N // 4, 1), tiled, for a multi-agent world (as Deathmatch builds it,
+    deathmatch.py:24), N for a single-agent one (Explorer, explorer.py:11) - unless --unique says otherwise."""
+    if unique:
+        return max(1, min(int(unique), n_envs))
+    return n_envs if n_agents == 1 else max(n_envs//4, 1)
+
+
+def world_geometries(n_envs, world, seed, n_unique=512, large=False, legacy=False):
+    """The floorplan of every env of the whole (world x n_envs)-env job: a pool of exactly `n_unique` distinct plans, tiled.
+    (`legacy`: the pool of rounds 1-3 - the training split of a 512-plan sample, 460 distinct - for a figure comparable
+    with theirs.)  Plans that are not cached yet are generated on forked worker processes."""
     from megastep_amd import cubicasa
-    pool = cubicasa.sample(min(n_unique, n_envs), seed=seed + 1, n_unique=max(n_unique, 16), large=large)
+    workers = min(os.cpu_count() or 1, 32)
+    if legacy:
+        pool = cubicasa.sample(min(512, n_envs), seed=seed + 1, n_unique=512, large=large, workers=workers)
+    else:
+        pool = cubicasa.sample(n_unique, split='all', seed=seed + 1, n_unique=n_unique, large=large, workers=workers)
     return [pool[i % len(pool)] for i in range(world*n_envs)]
 
 
@@ -76,12 +93,13 @@ def rank_slice(geometries, n_agents, res, rank, world):
     return sharding.env_slice(len(geometries), rank, world, cost)
 
 
-def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False):
+def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False,
+                legacy=False):
     """The benchmark's world - this rank's slice of it. With world > 1 the job has world x n_envs envs; every rank works
     out the same cost-balanced cuts from the floorplans and builds (and bakes) its own slice only: nothing of the other
     ranks' envs ever reaches this rank's device (reference: common.h:136-144 slices, it does not replicate)."""
     from megastep_amd import core, modules, scene
-    geometries = world_geometries(n_envs, world, seed, n_unique, large)
+    geometries = world_geometries(n_envs, world, seed, n_unique, large, legacy)
     start, stop = rank_slice(geometries, n_agents, res, rank, world)
     np.random.seed(seed)
     scenery = scene.scenery(geometries, n_agents, device=device, random=np.random.RandomState(seed), bake=bake, fast=fast,
@@ -95,17 +113,22 @@ def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=Fa
     return c, geometries
 
 
-def algorithmic_bytes(core):
+def algorithmic_bytes(core, fields=None):
     """Bytes one hot-path step must move, per SURVEY.md section 8(d) / BASELINE.md section 3, with the real ragged
-    sizes of this scenery. Returns (render bytes per launch, physics bytes per launch)."""
+    sizes of this scenery. Returns (render bytes per launch, physics bytes per launch). `fields`: the per-ray outputs the
+    render call is asked for (default: all five, RGBD); without `screen` neither the colour writes nor the texel /
+    baked-light gathers are part of the job."""
     sc = core.scenery
     N, A, M, R = core.n_envs, core.n_agents, sc.model.shape[0], core.res
     L, I = sc.lines.vals.shape[0], sc.lights.vals.shape[0]
+    fields = ('indices', 'locations', 'dots', 'distances', 'screen') if fields is None else fields
+    per_ray = sum(12 if f == 'screen' else 4 for f in fields)     # idx, loc, dot, dist + rgb written
+    if 'screen' in fields:
+        per_ray += 40                                              # 2 texels x 12 B + 2 baked x 4 B + texture width/start gathered per ray
     render = (16*L + 12*I + 8*N            # lines, lights, ragged offsets read once per env
               + 12*N*A                     # angle + position read
               + 16*N*A*M                   # agent lines written back
-              + N*A*R*(16 + 12)            # idx, loc, dot, dist + rgb written
-              + N*A*R*40)                  # 2 texels x 12 B + 2 baked x 4 B + texture width/start gathered per ray
+              + N*A*R*per_ray)
     physics = (16*(L - N*A*M) + 8*N        # wall segments + offsets read once per env
                + 48*N*A                    # agent state read + written
                + 4*N*A)                    # progress
@@ -179,12 +202,12 @@ def measured_traffic(args):
     for gfx950) and the file it was read from; the newest round that profiled the shape wins. (None, None) for a shape
     nobody profiled: PMC counters cannot be collected from inside the benchmark process."""
     import glob
-    want = (args.envs, args.agents, args.res, bool(args.large))
+    want = (args.envs, args.agents, args.res, bool(args.large), bool(args.depth_only))
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
         t = json.load(open(path))
         for entry in t.get('shapes', [t]):                              # (one shape per file up to round 2, a list since)
             w = entry.get('workload', {})
-            if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False))) == want:
+            if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False)), bool(w.get('depth_only', False))) == want:
                 return entry['render_bytes_per_launch'], os.path.relpath(path, ROOT)
     return None, None
 
@@ -286,7 +309,7 @@ class _Gpu:
     def event(self):
         return torch.cuda.Event(enable_timing=True)
 
-    def hot_path(self, scenery):
+    def hot_path(self, scenery, fields=None):
         from megastep_amd import cuda
         state = {}
 
@@ -294,7 +317,7 @@ class _Gpu:
             state['p'] = cuda.physics(scenery, view, out=state.get('p'))
             if ev is not None:
                 ev[1].record()
-            state['r'] = cuda.render(scenery, view, out=state.get('r'))
+            state['r'] = cuda.render(scenery, view, fields=fields, out=state.get('r'))
             if ev is not None:
                 ev[2].record()
         return step
@@ -325,7 +348,7 @@ class _Stub:
                 return 1e3*(other.t - self.t)
         return E()
 
-    def hot_path(self, scenery):
+    def hot_path(self, scenery, fields=None):
         def step(view, ev=None):
             view.positions.add_(view.velocity, alpha=.1)
             if ev is not None:
@@ -360,61 +383,20 @@ def launch_ranks(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env, cwd=ROOT))
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
-    ap.add_argument('--agents', type=int, default=4)
-    ap.add_argument('--res', type=int, default=64)
-    ap.add_argument('--fov', type=float, default=130.)
-    ap.add_argument('--large', action='store_true', help='800-1200 wall segments per env')
-    ap.add_argument('--unique', type=int, default=512, help='distinct floorplans in the world (tiled)')
-    ap.add_argument('--fast-build', action='store_true', help="draw textures, lights and spawns on the device (10^4+ envs)")
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-env-fps', action='store_true', help="skip the whole-env.step() rates of Explorer and Deathmatch")
-    ap.add_argument('--env-fps', action='store_true', help='(default now; kept for old command lines)')
-    ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
-    ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
-    args = ap.parse_args(argv)
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        return launch_ranks(args, sys.argv[1:] if argv is None else list(argv))
-
-    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-    if world != max(args.gpus, 1):
-        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
-                         f'(python bench.py --gpus N starts them itself)')
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    distributed = world > 1
-    import faulthandler
-    faulthandler.enable()
-    if os.environ.get('BENCH_WATCHDOG_S'):       # where is it, if it is still running by then?
-        faulthandler.dump_traceback_later(float(os.environ['BENCH_WATCHDOG_S']), repeat=True)
-    dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank)
-    device = dev.device
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # gloo: the ranks only meet in a barrier and a MAX of one float - envs are independent, RCCL stays out of it
-        dist.init_process_group('gloo')
-        barrier = dist.barrier
-    else:
-        barrier = lambda: None
-
+def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields=None, graph=True, eager_floor=None, graph_floor=.25):
+    """The timing protocol (module docstring) on one world: a dry run of the env loop records the W + K steps' inputs;
+    the K timed steps are then launched one by one with HIP events around every step and every render (`eager`) and, with
+    `graph`, replayed as one HIP graph - timed regions repeated until they add up to the floors. Returns the raw numbers."""
     from megastep_amd import cuda, modules, sharding
-    core, _ = build_world(args.envs, args.agents, args.res, args.fov, device, seed=1, n_unique=args.unique, large=args.large,
-                          rank=rank, world=world, bake=not args.dry_run_cpu, fast=args.fast_build)
+    device = dev.device
     N, A = core.n_envs, core.n_agents
-    total = args.steps + args.warmup
-    log(f'world built: {N} envs on this rank')
-
+    total = steps + warmup
     # pre-generated random momentum actions -> per-step velocity targets, resident in HBM
     torch.manual_seed(rank)
     mover = modules.MomentumMovement(core)
     actions = torch.randint(0, 7, (total, N, A), device=device)
     scenery, agents = core.scenery, core.agents
-    hot = dev.hot_path(scenery)
+    hot = dev.hot_path(scenery, fields)
 
     # The velocities the hot path is handed at each step are produced by the (untimed) torch movement glue ahead of
     # time: a dry run of the env loop from the spawn points, W + K steps, recording what ms_physics is given - the
@@ -442,7 +424,7 @@ def main(argv=None):
         corners their net drift pointed at: with the driver's --steps 20 a third slower than with --steps 200.)"""
         agents.angles.copy_(start[0]); agents.positions.copy_(start[1])
         vel.copy_(vel0); angvel.copy_(angvel0)
-        for i in range(args.warmup):
+        for i in range(warmup):
             hot(views[i])
 
     own = []
@@ -472,55 +454,230 @@ def main(argv=None):
     events = []
 
     def eager():
-        evs = [(dev.event(), dev.event(), dev.event()) for _ in range(args.steps)]
-        for i in range(args.steps):
+        evs = [(dev.event(), dev.event(), dev.event()) for _ in range(steps)]
+        for i in range(steps):
             evs[i][0].record()
-            hot(views[args.warmup + i], evs[i])
+            hot(views[warmup + i], evs[i])
         events.append(evs)
-    eager_runs = repeated(eager, floor_s=0.1 if args.steps < 100 else 0.)
-    eager_s = float(np.median(eager_runs))
-    log(f'eager leg: {1e3*eager_s/args.steps:.4f} ms/step (median of {len(eager_runs)} regions of {args.steps} steps)')
-    step_ms = np.array([e[0].elapsed_time(e[2]) for evs in events for e in evs])
-    render_each = np.array([e[1].elapsed_time(e[2]) for evs in events for e in evs])
-    render_ms = float(np.median(render_each))
-
+    if eager_floor is None:
+        eager_floor = 0.1 if steps < 100 else 0.
+    eager_runs = repeated(eager, floor_s=eager_floor)
+    m = {'eager_runs': eager_runs,
+         'step_ms': np.array([e[0].elapsed_time(e[2]) for evs in events for e in evs]),
+         'render_each': np.array([e[1].elapsed_time(e[2]) for evs in events for e in evs]),
+         'graph_runs': None}
     # ---- graph: the same K steps as one HIP graph, replayed
-    graph_s, graph_runs = None, None
-    if not args.no_graph:
-        replay = dev.graph(lambda: [hot(views[args.warmup + i]) for i in range(args.steps)])
+    if graph:
+        replay = dev.graph(lambda: [hot(views[warmup + i]) for i in range(steps)])
         replay()                                                       # (instantiation / first-launch costs stay outside)
-        graph_runs = repeated(replay)
+        m['graph_runs'] = repeated(replay, floor_s=graph_floor)
+    runs = m['graph_runs'] if m['graph_runs'] is not None else eager_runs
+    m['runs'] = runs
+    m['own_ms_per_step'] = 1e3*float(np.median(own[-len(runs):]))/steps
+    return m
+
+
+def shape_entry(dev, core, steps, warmup, fields=None, note=None):
+    """One line of the `shapes` block: the hot path on another of BASELINE.json's shapes, timed like the headline (same
+    protocol, shorter floors), with that shape's own algorithmic bytes against the HBM peak."""
+    m = time_hot_path(dev, core, steps, warmup, fields=fields, eager_floor=.05, graph_floor=.12)
+    s = float(np.median(m['runs']))
+    render_ms = float(np.median(m['render_each']))
+    rb, pb = algorithmic_bytes(core, fields)
+    sc = core.scenery
+    e = {'envs': core.n_envs, 'agents': core.n_agents, 'res': core.res, 'fov': core.fov,
+         'outputs': 'RGBD (all five planes)' if fields is None else '+'.join(fields),
+         'lines_per_env': sc.lines.vals.shape[0]/core.n_envs,
+         'distinct_floorplans': int((sc.geom == torch.arange(core.n_envs, device=sc.geom.device)).sum()) if sc.geom is not None else core.n_envs,
+         'ms_per_step': 1e3*s/steps, 'env_steps_per_s': core.n_envs*steps/s, 'timed_regions': int(len(m['runs'])),
+         'eager_ms_per_step': 1e3*float(np.median(m['eager_runs']))/steps,
+         'render_launch_ms': render_ms, 'render_algorithmic_bytes': rb,
+         'roofline_frac': rb/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+         'step_achieved_GBps': (rb + pb)/(1e3*s/steps*1e-3)/1e9}
+    if note:
+        e['note'] = note
+    return e
+
+
+def other_shapes(dev, steps=20, warmup=5):
+    """BASELINE.json's other single-GPU shapes, each timed with the headline's protocol at the driver's K / W: C2 (RGBD and
+    depth-only), C3, the reference Deathmatch's own 512 rays, C5's per-GPU share, and the headline on rounds 1-3's
+    460-plan pool for continuity. About 20 s altogether."""
+    from megastep_amd import core as core_
+    out = {}
+
+    def world(tag, *a, **kw):
+        t0 = time.perf_counter()
+        c, _ = build_world(*a, device=dev.device, seed=1, **kw)
+        log(f'{tag}: world built in {time.perf_counter() - t0:.1f}s')
+        return c
+
+    c = world('C2', 4096, 1, 64, 130., n_unique=plan_count(4096, 1))
+    out['c2_rgbd'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 2 (Explorer shape, one floorplan per env) with all five planes')
+    out['c2_depth_only'] = shape_entry(dev, c, steps, warmup, fields=('distances',),
+                                       note="BASELINE config 2 as stated: depth-only - render_kernel<2,1,1,0>, no shading pass")
+    del c
+    torch.cuda.empty_cache()
+    c = world('C3', 4096, 4, 128, 70., n_unique=plan_count(4096, 4))
+    out['c3'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 3 (Deathmatch shape at 128 rays)')
+    c512 = core_.Core(c.scenery, res=512, fov=70., fps=10)
+    c512.agents.positions[:], c512.agents.angles[:] = c.agents.positions, c.agents.angles
+    del c
+    out['r512'] = shape_entry(dev, c512, steps, warmup, note="the reference Deathmatch's own resolution (512 rays -> 128 px)")
+    del c512
+    torch.cuda.empty_cache()
+    c = world('C5 share', 32768, 1, 256, 130., n_unique=64, large=True, fast=True)
+    out['c5_per_gpu_share'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 5 / 8 GPUs: 32768 envs of 800-1200 walls, 64 distinct '
+                                          'plans tiled (one plan per env would be 32768 large plans: minutes of host-side generation)')
+    del c
+    torch.cuda.empty_cache()
+    c = world('headline, 460 plans', 4096, 4, 64, 130., legacy=True)
+    out['headline_460_plans'] = shape_entry(dev, c, steps, warmup, note="the headline shape on rounds 1-3's floorplan pool (the training "
+                                            "split of a 512-plan sample), for continuity with BENCH_r01..r03")
+    del c
+    torch.cuda.empty_cache()
+    return out
+
+
+def headline_env_step(dev, core, steps=40, warmup=8):
+    """Whole env.step() at the HEADLINE shape: random actions -> MomentumMovement + ms_physics (one launch, IMU reading
+    included) -> ms_render with the RGB, depth observations pooled by the kernel (subsample 1) -> obs dict; eager and as a
+    HIP graph. What an RL loop on this shape pays per step, next to the kernels-only `value`."""
+    from megastep_amd import arrdict, modules
+    mover, rgb, depth, imu = modules.MomentumMovement(core), modules.RGB(core), modules.Depth(core), modules.IMU(core)
+    N, A = core.n_envs, core.n_agents
+
+    def step(actions):
+        mover(arrdict.arrdict(actions=actions), imu=imu)
+        frame = modules.render(core, observers=(rgb, depth), fields=())
+        return arrdict.arrdict(rgb=rgb(frame), d=depth(frame), imu=imu())
+    acts = torch.randint(0, 7, (steps + warmup, N, A), device=dev.device)
+    for i in range(warmup):
+        step(acts[i])
+    dev.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(acts[warmup + i])
+    dev.sync()
+    eager = (time.perf_counter() - t0)/steps
+    static = acts[0].clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step(static)
+    dev.sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        static.copy_(acts[warmup + i])
+        g.replay()
+    dev.sync()
+    graphed = (time.perf_counter() - t0)/steps
+    return {'what': f'{N} envs x {A} agents x {core.res} rays: MomentumMovement + physics (+ IMU) in one launch, render with RGB + depth '
+                    'observations written by the kernel, random actions',
+            'ms_per_step': 1e3*eager, 'env_steps_per_s': N/eager, 'ms_per_step_hip_graph': 1e3*graphed, 'env_steps_per_s_hip_graph': N/graphed}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--envs', type=int, default=4096, help='envs per GPU')
+    ap.add_argument('--agents', type=int, default=4)
+    ap.add_argument('--res', type=int, default=64)
+    ap.add_argument('--fov', type=float, default=130.)
+    ap.add_argument('--large', action='store_true', help='800-1200 wall segments per env')
+    ap.add_argument('--unique', type=int, default=0, help='distinct floorplans per GPU, tiled (default, SURVEY 8(d): envs/4 for a '
+                                                         'multi-agent world, one per env for a single-agent one)')
+    ap.add_argument('--legacy-plans', action='store_true', help="rounds 1-3's pool: the training split of a 512-plan sample (460 plans)")
+    ap.add_argument('--depth-only', action='store_true', help="ask the renderer for `distances` alone (BASELINE config 2)")
+    ap.add_argument('--fast-build', action='store_true', help="draw textures, lights and spawns on the device (10^4+ envs)")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-env-fps', action='store_true', help="skip the whole-env.step() rates")
+    ap.add_argument('--no-shapes', action='store_true', help="skip the other BASELINE shapes (the `shapes` block)")
+    ap.add_argument('--env-fps', action='store_true', help='(default now; kept for old command lines)')
+    ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
+    ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
+    args = ap.parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args, sys.argv[1:] if argv is None else list(argv))
+
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world != max(args.gpus, 1):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python bench.py --gpus N starts them itself)')
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    distributed = world > 1
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get('BENCH_WATCHDOG_S'):       # where is it, if it is still running by then?
+        faulthandler.dump_traceback_later(float(os.environ['BENCH_WATCHDOG_S']), repeat=True)
+    n_unique = plan_count(args.envs, args.agents, args.unique)
+    extras = rank == 0 and world == 1 and not args.dry_run_cpu
+    # Floorplans first, on forked workers, before this process touches its GPU: the headline's pool (which the C3 / 512-ray
+    # shapes share) and, if the `shapes` block is wanted, C2's one-plan-per-env pool and the large maps.
+    world_geometries(args.envs, 1, 1, n_unique, args.large, args.legacy_plans)
+    if extras and not args.no_shapes:
+        world_geometries(4096, 1, 1, 4096)
+        world_geometries(4096, 1, 1, 64, large=True)
+        world_geometries(4096, 1, 1, legacy=True)
+    log('floorplans ready')
+    dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank)
+    device = dev.device
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # gloo: the ranks only meet in a barrier and a MAX of one float - envs are independent, RCCL stays out of it
+        dist.init_process_group('gloo')
+        barrier = dist.barrier
+    else:
+        barrier = lambda: None
+
+    core, _ = build_world(args.envs, args.agents, args.res, args.fov, device, seed=1, n_unique=n_unique, large=args.large,
+                          rank=rank, world=world, bake=not args.dry_run_cpu, fast=args.fast_build, legacy=args.legacy_plans)
+    N, A = core.n_envs, core.n_agents
+    scenery = core.scenery
+    log(f'world built: {N} envs on this rank')
+    fields = ('distances',) if args.depth_only else None
+    m = time_hot_path(dev, core, args.steps, args.warmup, barrier, rank, fields=fields, graph=not args.no_graph)
+    eager_runs, graph_runs, runs = m['eager_runs'], m['graph_runs'], m['runs']
+    step_ms, render_each = m['step_ms'], m['render_each']
+    eager_s = float(np.median(eager_runs))
+    render_ms = float(np.median(render_each))
+    log(f'eager leg: {1e3*eager_s/args.steps:.4f} ms/step (median of {len(eager_runs)} regions of {args.steps} steps)')
+    graph_s = None
+    if graph_runs is not None:
         graph_s = float(np.median(graph_runs))
         log(f'graph leg: {1e3*graph_s/args.steps:.4f} ms/step (median of {len(graph_runs)} replays of {args.steps} steps)')
 
     elapsed = graph_s if graph_s is not None else eager_s
-    runs = graph_runs if graph_runs is not None else eager_runs
     # every rank's own median region of the leg `value` comes from (before it waits for the others): an imbalance shows here
-    per_rank = [(N, 1e3*float(np.median(own[-len(runs):]))/args.steps)]
+    per_rank = [(N, m['own_ms_per_step'])]
     n_total = N
     if distributed:
         gathered = [None]*world
         dist.all_gather_object(gathered, per_rank[0])
         per_rank = gathered
         n_total = sum(n for n, _ in per_rank)
-    rb, pb = algorithmic_bytes(core)
+    rb, pb = algorithmic_bytes(core, fields)
     flops = all_pairs_flops(core)
     achieved = rb/(render_ms*1e-3)/1e9
     ms_per_step = 1e3*elapsed/args.steps
     value = n_total*args.steps/elapsed
     traffic, traffic_source = measured_traffic(args)
+    outputs = 'depth-only (distances)' if args.depth_only else 'RGBD'
 
     out = {
         'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {
-            'workload': f'{args.envs} envs x {A} agents x {args.res}-ray RGBD per GPU, fov {args.fov:g}, synthetic cubicasa floorplans'
+            'workload': f'{args.envs} envs x {A} agents x {args.res}-ray {outputs} per GPU, fov {args.fov:g}, synthetic cubicasa floorplans'
                         + (' (large maps)' if args.large else ''),
             'step': 'ms_physics + ms_render (C-ABI), per-step velocities from random momentum actions resident in HBM',
             'launch': 'the K timed steps replayed as one HIP graph' if graph_s is not None else 'one Python call per kernel (eager)',
             'envs_per_gpu': args.envs, 'envs_this_rank': N, 'envs_total': n_total, 'agents': A, 'res': args.res,
             'lines_per_env': scenery.lines.vals.shape[0]/N, 'lights_per_env': scenery.lights.vals.shape[0]/N,
+            'distinct_floorplans_per_gpu': 460 if args.legacy_plans else n_unique,
             'parallelism': f'env-sharded x{world} (contiguous slices balanced by lines x agents x rays), no collectives'},
         'agent_steps_per_sec': value*A,
         'per_rank': {'envs': [n for n, _ in per_rank], 'ms_per_step': [t for _, t in per_rank]},
@@ -530,7 +687,8 @@ def main(argv=None):
         'eager': {'value': n_total*args.steps/eager_s, 'ms_per_step': 1e3*eager_s/args.steps, 'timed_regions': int(len(eager_runs)),
                   'step_ms_hip_events': {'min': float(step_ms.min()), 'median': float(np.median(step_ms)), 'max': float(step_ms.max())}},
         'roofline': {
-            'kernel': 'ms_render = render_kernel<%s,1,0> (headings cached by ms_physics)' % {'pairs': 1, 'seq': 0}.get(os.environ.get('MEGASTEP_RENDER_IMPL', 'v2'), 2), 'bound': 'hbm', 'achieved': achieved,
+            'kernel': 'ms_render = render_kernel<2,1,%s> (headings cached by ms_physics)' % ('1,0' if args.depth_only else '0,1'),
+            'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
             'algorithmic_bytes_per_launch': rb, 'avg_launch_ms': render_ms,
@@ -544,13 +702,19 @@ def main(argv=None):
                      'peak_fp32_vector_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
                      'frac_of_peak': flops/(render_ms*1e-3)/1e12/FP32_VECTOR_PEAK_TFLOPS}},
     }
-    if rank == 0 and world == 1 and not args.dry_run_cpu:
+    if extras:
         if not args.no_cpu_baseline:
             out.update(cpu_baselines(core))
             log('cpu baselines done')
         if not args.no_env_fps:
-            del core, scenery, agents, views, hot
-            torch.cuda.empty_cache()
+            out['env_step_headline_shape'] = headline_env_step(dev, core)
+            log('env.step at the headline shape done')
+        del core, scenery
+        torch.cuda.empty_cache()
+        if not args.no_shapes:
+            out['shapes'] = other_shapes(dev)
+            log('other shapes done')
+        if not args.no_env_fps:
             out['env_step'] = env_step_fps(device)
             log('env-step rates done')
     if rank == 0:

@@ -986,12 +986,6 @@ constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair
 constexpr int MS_TELEMETRY_MAGIC = 0x7e1e7e1e;   // in workspace[5]: the caller wants the pair counters (workspace[3], [4])
 
 struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
-#ifndef MS_PERSISTENT
-#define MS_PERSISTENT 0
-#endif
-#if MS_PERSISTENT
-__device__ int g_cursor[8];
-#endif
 
 // The drawn (world-frame) model line `l` of env n: draw_kernel, kernels.cu:297-318.
 // sin/cos of a heading where it is not worth a copy of the code: (sin(pi x), cos(pi x)), as sincospi_f gives them
@@ -1058,16 +1052,10 @@ __device__ inline float sqrt_normal(const float x) {
 }
 
 struct Divisor { unsigned mul, sh1, sh2; };
-#ifndef MS_ORDER_EXPERIMENT
-#define MS_ORDER_EXPERIMENT 0          // 1: ms_debug_order() hands render_kernel an order to take its fans in and a place for their lives
-#endif
 struct RenderConsts {
     float x_clip, c_b;
     Divisor by_f, by_g, by_m;
     int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
-#if MS_ORDER_EXPERIMENT
-    const int* fan_order; unsigned* fan_cost;      // (experiment) dispatch slot -> fan; every wave's life in shader clocks
-#endif
 };
 __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     unsigned s = 0;
@@ -1234,7 +1222,12 @@ __host__ __device__ inline void ray_interval(float xa, float ya, float xb, float
 // LDS back the moment it is done instead of waiting for the slowest of four.
 // OBS = 1: any of the five per-ray outputs may be NULL, and pooled observations are written on request (the plain
 // instantiation stays within 80 VGPRs: six waves per SIMD)
-template <int IMPL, int RW, int OBS>
+// SHADE = 0 (with OBS = 1): the caller wants no colour - neither `screen` nor pooled RGB (modules.Depth reads distances
+// only, reference modules.py:170-184; BASELINE config 2 is depth-only).  Pass 3 is then not in the kernel at all: no
+// texel row, no texel and baked-light gathers, no filter, no dynamic lighting of rays that landed on an agent - and the
+// winning line itself is only fetched (for `locations`, `dots` or the first-sight books) if one of those is asked for:
+// a distances-only wave ends with the raycast, without a single dependent load behind it.
+template <int IMPL, int RW, int OBS, int SHADE = 1>
 // Occupancy knobs of the render kernel (A/B builds; the defaults are the product): waves per SIMD the register allocation
 // is held to, chunks of rows in flight, capacity of a wave's list of visible lines (which sizes its LDS block)
 #ifndef MS_WAVES
@@ -1262,7 +1255,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     //   4096 screen (192 x 4 B)  RGB staging
     // IMPL 2 lays its block out differently (see there): 6144 B
     PROBE_INIT
-    constexpr int LDS_PER_WAVE = (IMPL == 2 ? 24*MS_VCAP + 3072 : 4864) + 16*(MS_ORDER_EXPERIMENT != 0);
+    constexpr int LDS_PER_WAVE = (IMPL == 2 ? 24*MS_VCAP + 3072 : 4864);
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
@@ -1273,18 +1266,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
 
     // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
     // logical blocks so the fans of one env (and its lines) stay behind one L2.
-#if MS_PERSISTENT
-    // (-DMS_PERSISTENT=1, an experiment: as many one-wave workgroups as the chip holds at once, each taking fan after
-    // fan of its XCD's run from a cursor)
-    const int nb = n_fans, xcd = blockIdx.x & 7;
-    const int q8 = nb >> 3, r8 = nb & 7;
-    const int run0 = xcd < r8 ? xcd*(q8 + 1) : r8*(q8 + 1) + (xcd - r8)*q8, run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
-    for (;;) {
-    const int lb = run0 + __builtin_amdgcn_readfirstlane(lane == 0 ? atomicAdd(&g_cursor[xcd], 1) : 0);
-    if (lb >= run1) break;
-    __builtin_amdgcn_wave_barrier();
-    const int fan = lb;
-#else
     // (With one wave per workgroup the grid is exactly the fans - ms_render launches it so: the count comes from the
     // kernel's own arguments, not from the dispatch packet, and there is no early exit - either of which is a round trip
     // of its own before the loads below may even be asked for.)
@@ -1292,16 +1273,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
     const int lb = xcd*q8 + min(xcd, r8) + ix;      // (XCDs 0..r8-1 get a block more; no branch: a branch ends the stretch of
                                                     //  code hipcc gathers the kernel-argument loads of to its top)
-#if MS_ORDER_EXPERIMENT
-    const int fan = rc.fan_order[lb];          // (the experiment always passes an order)
-#if MS_ORDER_EXPERIMENT == 2
-    if (lane == 0) *reinterpret_cast<unsigned*>(&s_raw[wave][LDS_PER_WAVE - 16]) = (unsigned)clock64();
-#endif
-#else
     const int fan = lb*RW + wave;
-#endif
     if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
-#endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + WAVE - 1)/WAVE, F = A*G;
     const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
@@ -1678,7 +1651,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = MS_VCAP, P_CAP = 4096 < 64*MS_VCAP ? 4096 : 64*MS_VCAP;
         constexpr int O_INFO = 16*V_CAP, O_RAY = 24*V_CAP, O_NEAR = O_RAY + 512, O_QUEUE = O_NEAR + 256, O_BEST = O_QUEUE + 256;
-        static_assert(O_BEST + 3*512 + 512 + 16*(MS_ORDER_EXPERIMENT != 0) == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
+        static_assert(O_BEST + 3*512 + 512 == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][O_INFO]);
         // (direction and near plane in arrays of their own: at 8 and 4 bytes a ray, a window's reads - one ray per lane, the
         // rays mostly consecutive - touch every LDS bank once; as one 16-byte record per ray they were two-way conflicts)
@@ -2091,26 +2064,35 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     // asked for here, for every lane, from a row that exists (the env's first for a miss): unconditional loads are
     // the ones hipcc lets overlap.
     const LateArgs late = late_args();           // (see RenderArgs)
-    const int* const l_tex_widths = late->sc.textures_widths;
-    const int* const l_tex_starts = late->sc.textures_starts;
-    const float* const l_tex_vals = late->sc.textures_vals;
-    const float* const l_baked = late->sc.baked_vals;
+    constexpr bool COLOUR = SHADE != 0;
+    static_assert(COLOUR || OBS == 1, "without colour `screen` is NULL: the OBS instantiation");
+    // (uniform; constant-folded away in the colour instantiations)
+    const bool want_texel_row = COLOUR || (OBS && late->out.seen_stamp != nullptr);
+    const bool want_line = want_texel_row || late->out.locations != nullptr || late->out.dots != nullptr;
     const int row = min(max(nearest_idx, 0), max(L - 1, 0));
-    const float4 hw_mem = rows.row(row);
-    const int tex_w = l_tex_widths[base + row], tstart = l_tex_starts[base + row];
+    float4 hw_mem = make_float4(0.f, 0.f, 0.f, 0.f);
+    int tex_w = 1, tstart = 0;
+    if (want_line) hw_mem = rows.row(row);
+    if (want_texel_row) {
+        const int* const l_tex_widths = late->sc.textures_widths;
+        const int* const l_tex_starts = late->sc.textures_starts;
+        tex_w = l_tex_widths[base + row]; tstart = l_tex_starts[base + row];
+    }
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (__ballot((nearest_idx >= 0) & (nearest_idx < AF))) aw = agent_line(nearest_idx);
-    if (nearest_idx >= 0) {
-        hw = (nearest_idx < AF) ? aw : hw_mem;
-        const float vx = hw.z - hw.x, vy = hw.w - hw.y;
-        const float d = rx*vy - ry*vx;
-        const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
-        loc = (pqx*ry - pqy*rx)/d;
-        const float dtop = rx*vx + ry*vy;
-        const float dbot = rlen*sqrtf(vx*vx + vy*vy);
-        dt = dtop/(dbot + 1.e-6f);
+    if (want_line) {
+        float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (__ballot((nearest_idx >= 0) & (nearest_idx < AF))) aw = agent_line(nearest_idx);
+        if (nearest_idx >= 0) {
+            hw = (nearest_idx < AF) ? aw : hw_mem;
+            const float vx = hw.z - hw.x, vy = hw.w - hw.y;
+            const float d = rx*vy - ry*vx;
+            const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
+            loc = (pqx*ry - pqy*rx)/d;
+            const float dtop = rx*vx + ry*vy;
+            const float dbot = rlen*sqrtf(vx*vx + vy*vy);
+            dt = dtop/(dbot + 1.e-6f);
+        }
     }
     const size_t o = ((size_t)n*A + a)*R + r;
     const float dist = nearest_s*rlen;
@@ -2129,37 +2111,43 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
 
     // ---- pass 3: shade (kernels.cu:407-450)
     const bool is_hit = (nearest_idx >= 0) & (r < R);
-    const bool dynamic = is_hit & (nearest_idx < AF);
-    float intensity = 0.f;
-    // Rays that landed on an agent (dynamic) are lit from the lights (kernels.cu:432-436).  With a light grid
-    // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
-    // ray group is queued for dynlight_kernel, launched right behind this kernel.
-    [[maybe_unused]] unsigned light_telemetry = 0x80000000u;
-    if (__ballot(dynamic)) {
-        if (sc.lg_vals) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
-            const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
-                                 late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
-                                 late->sc.lg_list, late->sc.lg_pool};         // (fetched now: see RenderArgs)
-            intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
-                reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry);
-            PROBE_VAL(2, light_telemetry)
-        } else if (out.workspace) {
-            if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
-        }
-    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
-    // env's first line and throws the result away)
-    PROBE_AT(5, tex_w)                                                   // the winner's line and texel row have arrived
-    const Filt f = tex_filter(is_hit ? loc : 0.f, tex_w);
-    const float bk_l = l_baked[tstart + f.l], bk_r = l_baked[tstart + f.r];
-    const float* __restrict__ tl = l_tex_vals + 3*(size_t)(tstart + f.l);
-    const float* __restrict__ tr = l_tex_vals + 3*(size_t)(tstart + f.r);
-    const float tl0 = tl[0], tl1 = tl[1], tl2 = tl[2], tr0 = tr[0], tr1 = tr[1], tr2 = tr[2];
-    if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
+    [[maybe_unused]] Filt f = Filt{0, 0, 0.f, 0.f};
+    [[maybe_unused]] float intensity = 0.f;
+    [[maybe_unused]] float tl0 = 0.f, tl1 = 0.f, tl2 = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
+    if constexpr (COLOUR) {
+        const float* const l_tex_vals = late->sc.textures_vals;
+        const float* const l_baked = late->sc.baked_vals;
+        const bool dynamic = is_hit & (nearest_idx < AF);
+        // Rays that landed on an agent (dynamic) are lit from the lights (kernels.cu:432-436).  With a light grid
+        // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
+        // ray group is queued for dynlight_kernel, launched right behind this kernel.
+        [[maybe_unused]] unsigned light_telemetry = 0x80000000u;
+        if (__ballot(dynamic)) {
+            if (sc.lg_vals) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
+                const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
+                                     late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
+                                     late->sc.lg_list, late->sc.lg_pool};         // (fetched now: see RenderArgs)
+                intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
+                    reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry);
+                PROBE_VAL(2, light_telemetry)
+            } else if (out.workspace) {
+                if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
+            }
+        }
+        // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
+        // env's first line and throws the result away)
+        PROBE_AT(5, tex_w)                                                   // the winner's line and texel row have arrived
+        f = tex_filter(is_hit ? loc : 0.f, tex_w);
+        const float bk_l = l_baked[tstart + f.l], bk_r = l_baked[tstart + f.r];
+        const float* __restrict__ tl = l_tex_vals + 3*(size_t)(tstart + f.l);
+        const float* __restrict__ tr = l_tex_vals + 3*(size_t)(tstart + f.r);
+        tl0 = tl[0]; tl1 = tl[1]; tl2 = tl[2]; tr0 = tr[0]; tr1 = tr[1]; tr2 = tr[2];
+        if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
+    }
     if constexpr (OBS == 1) {
         if (late->out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
             bool fresh = false;
@@ -2188,43 +2176,47 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         }
     }
 
-    PROBE_AT(6, tl0)                                                     // ... its texels
-    if (is_hit) {
-        const float dn = 1 - dt*dt;
-        s0 = dn*intensity*(f.lw*tl0 + f.rw*tr0);
-        s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
-        s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
-    }
-    float* const o_screen = late->out.screen;
-    if (!OBS || o_screen) {
-        // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
-        s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int nfl = 3*(r_last - g*WAVE + 1);
-        float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + g*WAVE);
-        #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const int j = lane + k*WAVE;
-            if (j < nfl) MS_OUT_STORE(s_screen_w[j], &scr[j]);
+    if constexpr (COLOUR) {
+        PROBE_AT(6, tl0)                                                     // ... its texels
+        if (is_hit) {
+            const float dn = 1 - dt*dt;
+            s0 = dn*intensity*(f.lw*tl0 + f.rw*tr0);
+            s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
+            s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
+        }
+        float* const o_screen = late->out.screen;
+        if (!OBS || o_screen) {
+            // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
+            s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nfl = 3*(r_last - g*WAVE + 1);
+            float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + g*WAVE);
+            #pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int j = lane + k*WAVE;
+                if (j < nfl) MS_OUT_STORE(s_screen_w[j], &scr[j]);
+            }
         }
     }
     // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
     // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
-    if (OBS && (late->out.obs_rgb || late->out.obs_depth)) {
+    if (OBS && ((COLOUR && late->out.obs_rgb) || late->out.obs_depth)) {
         const int sub = late->out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
         float p0 = s0, p1 = s1, p2 = s2;
         float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
         for (int o2 = 1; o2 < sub; o2 <<= 1) {
-            p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE);
-            p2 += __shfl_xor(p2, o2, WAVE); pd += __shfl_xor(pd, o2, WAVE);
+            if constexpr (COLOUR) {
+                p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE); p2 += __shfl_xor(p2, o2, WAVE);
+            }
+            pd += __shfl_xor(pd, o2, WAVE);
         }
         if (((lane & (sub - 1)) == 0) & (r < R)) {
             const float fs = (float)sub;
             const int W = R/sub, px = r/sub;
             const size_t na = (size_t)n*A + a;
-            if (late->out.obs_rgb) {
+            if (COLOUR && late->out.obs_rgb) {
                 late->out.obs_rgb[(na*3 + 0)*W + px] = p0/fs;
                 late->out.obs_rgb[(na*3 + 1)*W + px] = p1/fs;
                 late->out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
@@ -2233,17 +2225,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         }
     }
     PROBE_DONE(fan)
-#if MS_ORDER_EXPERIMENT == 2
-    {
-        unsigned* const costs = late_args()->rc.fan_cost;
-        if (costs && lane == 0) costs[((size_t)n*A + a)*G + g] = (unsigned)clock64() - *reinterpret_cast<unsigned*>(&s_raw[wave][LDS_PER_WAVE - 16]);
-    }
-#endif
-#if MS_PERSISTENT
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3304,12 +3285,6 @@ void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, fl
     bake_wall_bins(p2(light_x, light_y), ax, ay, bx, by, *first, *count);
 }
 
-#if MS_ORDER_EXPERIMENT
-static const int* g_fan_order = nullptr;
-static unsigned* g_fan_cost = nullptr;
-int ms_debug_order(const int* order, unsigned* cost) { g_fan_order = order; g_fan_cost = cost; return MS_OK; }
-#endif
-
 #if MS_PROBE
 // (probe builds only, not part of the ABI) buf: device memory of capacity records of 11 32-bit words (8 stamps, HW_ID |
 // XCC_ID << 16, the real-time counter at the wave's start and end), or NULL to stop recording
@@ -3547,7 +3522,8 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // workspace is not needed at all); otherwise from render_prep_kernel, which also resets the workspace's counters.
     MsAgents agn = *ag;
     MsRender outn = *out;
-    const bool one_kernel = grid || sc->n_agents == 1;
+    const bool colour = out->screen || out->obs_rgb;                      // else: render_kernel<.,.,1,0>, which has no pass 3
+    const bool one_kernel = grid || sc->n_agents == 1 || !colour;        // (nothing to light without colour)
     if (ag->headings && one_kernel) {
         if ((uintptr_t)ag->headings % 16) return MS_EINVAL;
         outn.workspace = nullptr;
@@ -3563,7 +3539,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // dynlight_kernel reads the per-ray outputs back: only the one-kernel path can do without some of them
     const bool all_planes = out->indices && out->locations && out->dots && out->distances && out->screen;
     const bool pooled = out->obs_rgb || out->obs_depth || out->obs_centre || out->seen_stamp;
-    if ((!all_planes || pooled) && !(grid || sc->n_agents == 1)) return MS_EUNSUPPORTED;   // dynlight_kernel patches `screen` afterwards
+    if (colour && (!all_planes || pooled) && !(grid || sc->n_agents == 1)) return MS_EUNSUPPORTED;   // dynlight_kernel patches `screen` afterwards
     if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
     const bool obs = pooled || !all_planes;
     RenderConsts rc;
@@ -3573,33 +3549,24 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_g = divisor_of((unsigned)G);
     rc.by_m = divisor_of((unsigned)sc->n_model);
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
-#if MS_ORDER_EXPERIMENT
-    rc.fan_order = g_fan_order; rc.fan_cost = g_fan_cost;
-#endif
     constexpr int RW = 1;
-#if MS_PERSISTENT
-    static int* cursor = nullptr;
-    if (!cursor && hipGetSymbolAddress((void**)&cursor, HIP_SYMBOL(g_cursor)) != hipSuccess) return hip_fail(hipGetLastError());
-    if (hipMemsetAsync(cursor, 0, 8*sizeof(int), (hipStream_t)stream) != hipSuccess) return hip_fail(hipGetLastError());
-    const char* pw = getenv("MEGASTEP_PERSISTENT_WAVES");
-    const int rblocks = (int)(n_fans < (pw ? atoi(pw) : 6144) ? n_fans : (pw ? atoi(pw) : 6144));
-#else
     const int rblocks = (int)((n_fans + RW - 1)/RW);
-#endif
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
     const hipStream_t hs = (hipStream_t)stream;
 #define MS_LAUNCH_RENDER(I, O) \
-    hipLaunchKernelGGL((render_kernel<I, RW, O>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
+    hipLaunchKernelGGL((render_kernel<I, RW, O, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
 #if MS_AB_IMPLS
     if (seq) { if (obs) MS_LAUNCH_RENDER(0, 1); else MS_LAUNCH_RENDER(0, 0); }
     else if (pairs1) { if (obs) MS_LAUNCH_RENDER(1, 1); else MS_LAUNCH_RENDER(1, 0); }
     else
 #endif
-    { if (obs) MS_LAUNCH_RENDER(2, 1); else MS_LAUNCH_RENDER(2, 0); }
+    if (!colour)
+        hipLaunchKernelGGL((render_kernel<2, RW, 1, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
+    else { if (obs) MS_LAUNCH_RENDER(2, 1); else MS_LAUNCH_RENDER(2, 0); }
 #undef MS_LAUNCH_RENDER
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.
-    if (!grid && sc->n_agents > 1)
+    if (!grid && sc->n_agents > 1 && colour)
         hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, scn, *ag, *out, R);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);

@@ -133,11 +133,31 @@ def _plan(i, large):
     return _cache[key]
 
 
-def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE):
+def _make(key):
+    return key, floorplan(1000003*int(key[1]) + key[0], key[1])
+
+
+def prefetch(indices, large=False, workers=None):
+    """Generates the plans ``indices`` that are not cached yet on ``workers`` forked processes (a plan takes ~7 ms of
+    numpy on one core; the benchmark's Explorer-style worlds want thousands of distinct ones). Fork only: call it before
+    the process has touched its GPU. Same plans as the lazy path - a plan is a function of its index alone."""
+    import multiprocessing as mp
+    import os
+    todo = sorted({(int(i), bool(large)) for i in indices} - set(_cache))
+    workers = min(workers or (os.cpu_count() or 1), 32, max(len(todo)//16, 1))
+    if workers <= 1 or len(todo) < 64:
+        return
+    with mp.get_context('fork').Pool(workers) as pool:
+        for key, plan in pool.imap_unordered(_make, todo, chunksize=8):
+            _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if key[1] else "S"}{key[0]:04d}', **plan)
+
+
+def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0):
     """A deterministic sample of ``n_geometries`` floorplans; same arguments, same sample (reference:
     cubicasa.py:177-224). ``split`` is 90/10 ``training``/``test`` or ``all`` over ``n_unique`` plans; plans are
     generated lazily and repeat cyclically when more are asked for than the split holds. ``large`` and ``n_unique`` are
-    extensions for the big-map benchmark point and for cheap tests."""
+    extensions for the big-map benchmark point and for cheap tests; ``workers`` > 1 generates the missing plans on that
+    many forked processes first (see :func:`prefetch`)."""
     cutoff = int(.9*n_unique)
     order = np.random.RandomState(seed).permutation(n_unique)
     if split == 'training':
@@ -146,4 +166,6 @@ def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQU
         order = order[cutoff:]
     elif split != 'all':
         raise ValueError('Split must be train/test/all')
+    if workers and workers > 1:
+        prefetch(order[:n_geometries], large, workers)
     return [_plan(order[i % len(order)], large) for i in range(n_geometries)]

@@ -636,7 +636,9 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
 
     Extensions over the reference, all off by default: ``fields`` names the per-ray outputs that are wanted
-    (the others are neither written nor allocated), and ``pooled=dict(subsample=s, max_depth=d, rgb=True, depth=True)``
+    (the others are neither written nor allocated; a call that wants no colour - no ``screen``, no pooled RGB - runs an
+    instantiation of the kernel without the shading pass: ``fields=('distances',)`` is what ``modules.Depth`` reads,
+    reference modules.py:170-184), and ``pooled=dict(subsample=s, max_depth=d, rgb=True, depth=True)``
     has the kernel write the mean-pooled observations of ``modules.RGB`` / ``modules.Depth`` itself
     (``Render.obs_rgb`` (n, a, 3, res/s), ``Render.obs_depth`` (n, a, res/s)). ``out`` takes the :class:`Render` of an
     earlier call with the same arguments and writes into its tensors instead of allocating (the reference allocates
@@ -688,9 +690,11 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
     if any(f not in FIELDS for f in want):
         raise RuntimeError(f'fields must be among {FIELDS}')
     scenery._as_struct()
-    if a > 1 and scenery._lg[0] is None:
+    colour = 'screen' in want or (pooled is not None and pooled.get('rgb', True))
+    if a > 1 and scenery._lg[0] is None and colour:
         # no light grid (Scenery.LIGHT_GRID switched off): agent hits are lit by a second launch that reads all five
-        # planes back and patches `screen` - after any pooling. All planes then, and the caller pools.
+        # planes back and patches `screen` - after any pooling. All planes then, and the caller pools.  (Without colour
+        # there is nothing to light: the depth-only kernel serves such sceneries like any other.)
         want, pooled = FIELDS, None
     sub, max_depth, w = 1, 1., r
     n_rgb = n_depth = n_centre = 0

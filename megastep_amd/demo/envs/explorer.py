@@ -64,7 +64,9 @@ class SeenTexels:
 
 class Explorer:
 
-    def __init__(self, n_envs, *args, device='cuda', geometries=None, **kwargs):
+    def __init__(self, n_envs, *args, device='cuda', geometries=None, depth_only=False, **kwargs):
+        """``depth_only=True``: observations are depth + IMU, no RGB (BASELINE config 2's "64-ray depth-only"); the
+        renderer then runs without its shading pass."""
         if geometries is None:
             geometries = cubicasa.sample(n_envs)
         self.core = core.Core(scene.scenery(geometries, 1, device=device), *args, res=4*64, fov=130, **kwargs)
@@ -73,11 +75,13 @@ class Explorer:
 
         self._mover = modules.MomentumMovement(c)
         self._respawner = modules.RandomSpawns(geometries, c)
-        self._rgb = modules.RGB(c, n_agents=1, subsample=4)
+        self._rgb = None if depth_only else modules.RGB(c, n_agents=1, subsample=4)
         self._depth = modules.Depth(c, n_agents=1, subsample=4)
         self._imu = modules.IMU(c)
         self.action_space = self._mover.space
-        self.obs_space = dotdict.dotdict(rgb=self._rgb.space, d=self._depth.space, imu=self._imu.space)
+        self.obs_space = dotdict.dotdict(d=self._depth.space, imu=self._imu.space)
+        if not depth_only:
+            self.obs_space['rgb'] = self._rgb.space
 
         self._memory = SeenTexels(c.scenery, c.n_envs)
         self._lengths = self._memory.spare                                  # (cleared together with the books)
@@ -94,10 +98,13 @@ class Explorer:
     def _world(self, reset):
         # pooled RGB-D straight from the render kernel, which also keeps the books of the texels it sees: no per-ray
         # output is needed at all
-        frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=(), seen=self._memory.books)
-        pixels = self.core.res//self._rgb.subsample
+        observers = (self._depth,) if self._rgb is None else (self._rgb, self._depth)
+        frame = modules.render(self.core, observers=observers, fields=(), seen=self._memory.books)
+        pixels = self.core.res//self._depth.subsample
         reward = (self._memory.gained()/pixels).masked_fill_(reset, 0.)        # nothing for the frame after a respawn
-        obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu())
+        obs = arrdict.arrdict(d=self._depth(frame), imu=self._imu())
+        if self._rgb is not None:
+            obs['rgb'] = self._rgb(frame)
         return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
 
     @torch.no_grad()
@@ -118,6 +125,6 @@ class Explorer:
 
     def state(self, e=0):
         seen = self._memory.mask()[self._memory.texel_env == e]
-        return arrdict.arrdict(core=self.core.state(e), rgb=self._rgb.state(e), d=self._depth.state(e),
+        return arrdict.arrdict(core=self.core.state(e), **({} if self._rgb is None else dict(rgb=self._rgb.state(e))), d=self._depth.state(e),
                                potential=self._memory.count[e].clone(), seen=seen.clone(),
                                length=self._lengths[e].clone(), max_length=self._memory.count[e].add(EPISODE_SLACK).clone())

@@ -47,11 +47,18 @@ def _cells_touching_segment(a, b, pad, shape, res):
     i0, i1 = max(int(np.floor((y_top - hi[1])/res)), 0), min(int(np.floor((y_top - lo[1])/res)), H - 1)
     if j1 < j0 or i1 < i0:
         return None, (0, 0)
+    d = b - a
+    if abs(d[0]) < 1e-12 or abs(d[1]) < 1e-12:
+        # An axis-aligned segment (every wall of the synthetic floorplans): the slab test below separates into a test per
+        # column and a test per row - the same arithmetic on two short vectors instead of two (rows x columns) arrays.
+        j, i = np.arange(j0, j1 + 1), np.arange(i0, i1 + 1)
+        okx = _slab(a[0], d[0], j*res - pad, (j + 1)*res + pad)
+        oky = _slab(a[1], d[1], y_top - (i + 1)*res - pad, y_top - i*res + pad)
+        return oky[:, None] & okx[None, :], (i0, j0)
     jj, ii = np.meshgrid(np.arange(j0, j1 + 1), np.arange(i0, i1 + 1))
     xmin, xmax = jj*res - pad, (jj + 1)*res + pad
     ymin, ymax = y_top - (ii + 1)*res - pad, y_top - ii*res + pad
     # slab clipping of the segment against each grown cell
-    d = b - a
     t0, t1 = np.zeros(jj.shape), np.ones(jj.shape)
     ok = np.ones(jj.shape, bool)
     for p0, dd, mn, mx in ((a[0], d[0], xmin, xmax), (a[1], d[1], ymin, ymax)):
@@ -62,6 +69,14 @@ def _cells_touching_segment(a, b, pad, shape, res):
             t0 = np.maximum(t0, np.minimum(ta, tb))
             t1 = np.minimum(t1, np.maximum(ta, tb))
     return ok & (t0 <= t1), (i0, j0)
+
+
+def _slab(p0, dd, mn, mx):
+    """One axis of the slab test for a segment that does not move along the other: the cells (intervals mn..mx) it meets."""
+    if abs(dd) < 1e-12:
+        return (p0 >= mn) & (p0 <= mx)
+    ta, tb = (mn - p0)/dd, (mx - p0)/dd
+    return np.maximum(0., np.minimum(ta, tb)) <= np.minimum(1., np.maximum(ta, tb))
 
 
 def _inside(poly, x, y):
@@ -93,11 +108,57 @@ def masks(walls, spaces, res=RES):
             if blk is not None:
                 touched[i0:i0 + blk.shape[0], j0:j0 + blk.shape[1]] |= blk
         out[touched] = k + 1
-    for a, b in walls:
+    d = walls[:, 1] - walls[:, 0]
+    aligned = (np.abs(d) < 1e-12).any(1)
+    ii, jj = _cells_touching_aligned(walls[aligned], .01, shape, res)       # (all of a synthetic floorplan's walls)
+    out[ii, jj] = -1
+    for a, b in walls[~aligned]:
         blk, (i0, j0) = _cells_touching_segment(a, b, .01, shape, res)
         if blk is not None:
             out[i0:i0 + blk.shape[0], j0:j0 + blk.shape[1]][blk] = -1
     return out
+
+
+def _ragged_arange(first, count):
+    """(owner, value): for every k the values first[k] .. first[k] + count[k] - 1, laid end to end."""
+    owner = np.repeat(np.arange(len(count)), count)
+    return owner, np.arange(len(owner)) - np.repeat(np.cumsum(count) - count, count) + first[owner]
+
+
+def _cells_touching_aligned(walls, pad, shape, res):
+    """:func:`_cells_touching_segment` for many axis-aligned segments at once - the same tests, cell for cell, as flat
+    (rows, columns) of the touched cells (a floorplan's few hundred walls cost a few hundred tiny numpy calls each otherwise)."""
+    H, W = shape
+    if len(walls) == 0:
+        return np.zeros(0, int), np.zeros(0, int)
+    a, b = walls[:, 0], walls[:, 1]
+    d = b - a
+    lo, hi = np.minimum(a, b) - pad, np.maximum(a, b) + pad
+    y_top = H*res
+    j0 = np.maximum(np.floor(lo[:, 0]/res).astype(int), 0)
+    j1 = np.minimum(np.floor(hi[:, 0]/res).astype(int), W - 1)
+    i0 = np.maximum(np.floor((y_top - hi[:, 1])/res).astype(int), 0)
+    i1 = np.minimum(np.floor((y_top - lo[:, 1])/res).astype(int), H - 1)
+    nj, ni = np.maximum(j1 - j0 + 1, 0), np.maximum(i1 - i0 + 1, 0)
+    nj, ni = np.where(ni > 0, nj, 0), np.where(nj > 0, ni, 0)
+
+    def slab(p0, dd, mn, mx):                       # _slab, with the still-or-moving choice made per element
+        still = np.abs(dd) < 1e-12
+        safe = np.where(still, 1., dd)
+        ta, tb = (mn - p0)/safe, (mx - p0)/safe
+        return np.where(still, (p0 >= mn) & (p0 <= mx), np.maximum(0., np.minimum(ta, tb)) <= np.minimum(1., np.maximum(ta, tb)))
+
+    wj, j = _ragged_arange(j0, nj)
+    okx = slab(a[wj, 0], d[wj, 0], j*res - pad, (j + 1)*res + pad)
+    wi, i = _ragged_arange(i0, ni)
+    oky = slab(a[wi, 1], d[wi, 1], y_top - (i + 1)*res - pad, y_top - i*res + pad)
+    # the cells of a wall: its touched rows x its touched columns
+    wj, j, wi, i = wj[okx], j[okx], wi[oky], i[oky]
+    cols_of = np.bincount(wj, minlength=len(walls))
+    col_first = np.cumsum(cols_of) - cols_of
+    per_row = cols_of[wi]                                                   # every touched row meets all its wall's touched columns
+    row, k = _ragged_arange(np.zeros(len(wi), int), per_row)
+    return i[row], j[col_first[wi[row]] + k]
 
 
 def centroids(spaces):

@@ -7,7 +7,7 @@ tag=$1; shift
 shape="$@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-lean="--no-cpu-baseline --no-env-fps"
+lean="--no-cpu-baseline --no-env-fps --no-shapes"
 rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python bench.py --steps 100 --warmup 10 $lean $shape > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_write.log 2>&1
@@ -20,8 +20,8 @@ out, tag, shape = sys.argv[1], sys.argv[2], sys.argv[3:]
 import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096); ap.add_argument('--agents', type=int, default=4); ap.add_argument('--res', type=int, default=64)
-ap.add_argument('--large', action='store_true'); ap.add_argument('--unique', type=int, default=512); ap.add_argument('--fast-build', action='store_true')
-w = ap.parse_args(shape)
+ap.add_argument('--large', action='store_true'); ap.add_argument('--depth-only', action='store_true')
+w, _ = ap.parse_known_args(shape)
 KERNELS = r'(render_kernel|render_prep_kernel|physics_kernel|dynlight_kernel)'
 st = pd.read_csv(f'{out}/stats/bench_kernel_stats.csv')
 st = st[st.Name.str.contains('render_kernel|render_prep|physics_kernel|dynlight|bake_kernel|bake_sum|visibility|lightgrid|lightlist|wallgrid')]
@@ -37,7 +37,7 @@ for c, f in [('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write')]:
 # calibrated here on physics_kernel's 16 B/lane wall stream in round 2), WRITE_SIZE (KB) as reported.
 rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) for k in ('render_kernel', 'render_prep_kernel', 'dynlight_kernel'))
 pb = 2*1024*res['FETCH_SIZE'].get('physics_kernel', 0) + 1024*res['WRITE_SIZE'].get('physics_kernel', 0)
-json.dump({'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large},
+json.dump({'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large, 'depth_only': w.depth_only},
            'render_bytes_per_launch': rb, 'physics_bytes_per_launch': pb, 'raw_counters_KB': res,
            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph ' + ' '.join(shape)
                      + '; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'},
