@@ -53,6 +53,10 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: 256 CUs x 2.4 GHz x 256 flop/clk (packed FMA), the VALU ceiling SURVEY 8(d) names
 _T0 = time.perf_counter()
+# processes that generate floorplans (forked before the GPU is touched). None under a profiler: rocprofv3's counter
+# collection hangs on forked children (seen with --pmc), and a profile does not care how long the plans took
+PLAN_WORKERS = 0 if any('rocprof' in os.environ.get(k, '').lower() for k in ('LD_PRELOAD', 'ROCP_TOOL_LIBRARIES', 'HSA_TOOLS_LIB')) \
+    else min(os.cpu_count() or 1, 32)
 
 
 def log(msg):
@@ -74,7 +78,7 @@ def world_geometries(n_envs, world, seed, n_unique=512, large=False, legacy=Fals
     (`legacy`: the pool of rounds 1-3 - the training split of a 512-plan sample, 460 distinct - for a figure comparable
     with theirs.)  Plans that are not cached yet are generated on forked worker processes."""
     from megastep_amd import cubicasa
-    workers = min(os.cpu_count() or 1, 32)
+    workers = PLAN_WORKERS
     if legacy:
         pool = cubicasa.sample(min(512, n_envs), seed=seed + 1, n_unique=512, large=large, workers=workers)
     else:
@@ -597,7 +601,11 @@ def main(argv=None):
     ap.add_argument('--env-fps', action='store_true', help='(default now; kept for old command lines)')
     ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
     ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
+    ap.add_argument('--plan-workers', type=int, default=None, help='processes generating floorplans (0: in this process)')
     args = ap.parse_args(argv)
+    if args.plan_workers is not None:
+        global PLAN_WORKERS
+        PLAN_WORKERS = args.plan_workers
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         return launch_ranks(args, sys.argv[1:] if argv is None else list(argv))
 

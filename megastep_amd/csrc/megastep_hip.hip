@@ -61,6 +61,7 @@ thread_local int g_last_hip_error = 0;
 #endif
 #if MS_PROBE
 constexpr int PROBE_STAMPS = 8;        // a record: 8 stamps (low 32 bits of s_memtime), then where the wave ran
+constexpr int PROBE_WORDS = 16;        // ... the real-time counter at its start and end, and five numbers of the wave's choosing
 __device__ unsigned* g_probe = nullptr;                // one record per wave, indexed by the wave's number in its launch
 __device__ long long g_probe_cap = 0;
 // (one VGPR: lane k holds stamp k, the low 32 bits of s_memtime - a wave's record costs the kernel one register and no
@@ -74,7 +75,7 @@ struct Probe {
             if (lane == PROBE_STAMPS) v = ((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu) | ((unsigned)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) << 16);   // HW_ID, XCC_ID
             if (lane == PROBE_STAMPS + 1) v = real0;                    // s_memtime counts per XCD; the 100 MHz real-time counter is the chip's
             if (lane == PROBE_STAMPS + 2) v = (unsigned)wall_clock64();
-            if (lane <= PROBE_STAMPS + 2) g_probe[wave*(PROBE_STAMPS + 3) + lane] = v;
+            if (lane < PROBE_WORDS) g_probe[wave*PROBE_WORDS + lane] = v;     // (lanes 11..15: numbers left by PROBE_VAL)
         }
     }
 };
@@ -1691,8 +1692,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
 
         int n_pairs_total = 0, n_windows = 0;    // telemetry
         int n_list = 0, n_pairs = 0;             // lines and pairs in the list (wave-uniform)
+        int n_drains = 0, list_n = 0;            // how often the list has been worked off, and how long it was the last time
         // pass 2 over the list: windows of 64 pairs
         auto drain = [&]() {
+            n_drains++; list_n = n_list;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1889,6 +1892,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         }
         // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1
         const unsigned long long amb = __ballot(ambiguous);
+        PROBE_VAL(11, n_pairs_total) PROBE_VAL(12, n_drains == 1 ? list_n : -1) PROBE_VAL(13, __popcll(amb))
+#if MS_PROBE
+        const unsigned t_fold0 = (unsigned)clock64();
+        PROBE_VAL(15, t_fold0)                                               // (with stamp 3: how long passes 1 and 2 took)
+#endif
         // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
         // per wave on one address are 1.3 ms at 262144 waves
         if (out.workspace && lane == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
@@ -1898,6 +1906,76 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
             atomicAdd(&out.workspace[1], __popcll(amb));
             if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
         }
+        if (amb && n_drains == 1) {
+            // The usual case: the wave's list was worked off once, at the end, so all of it is still in LDS - every line
+            // a ray of this wave can hit (the exact cull arguments above), ray-independent half of the intersection
+            // ready, in LINE ORDER: the agents' lines in theirs, then the cell's vis list, which wallgrid_fill_kernel
+            // writes in ascending wall number and the arc cull only thins.  The reference's fold (kernels.cu:352-377)
+            // over the lines a ray does not hit is a no-op, so the literal fold over the list is the literal fold:
+            // lane = ray, one broadcast LDS read per line, no memory traffic and no chain of dependent chunk loads
+            // (the sweep over all the env's lines from memory below made such a wave the one its launch waited for:
+            // 10-26 us against a mean life of 6-9; profiles/r04_probe_*.txt).
+            const int rounds = (list_n + WAVE - 1)/WAVE;
+            if (10*__popcll(amb)*rounds <= list_n + 40) {
+                // a few such rays (nearly always one or two): lane = line of the list, 64 at a time, read from LDS once; per
+                // ray every line's hit at once, then the ray's hits - a handful - folded in line order through a scalar
+                // loop into the ray's state, which lives in the ray's own lane
+                float x = INFINITY;
+                int xi = -1;
+                for (int k0 = 0; k0 < list_n; k0 += WAVE) {
+                    const int k = min(k0 + lane, list_n - 1);
+                    const Cand cd = s_cand_w[k];
+                    const int line = s_info_w[k].y;
+                    const float cpv = cd.pqx*cd.vy - cd.pqy*cd.vx;               // cross(PQ, V)
+                    for (unsigned long long todo = amb; todo; todo &= todo - 1) {
+                        const int jr = __ffsll((long long)todo) - 1;
+                        const float jrx = readlane_f(rx, jr), jry = readlane_f(ry, jr), jnear = readlane_f(near, jr);
+                        const float d = jrx*cd.vy - jry*cd.vx;
+                        const float nt = cd.pqx*jry - cd.pqy*jrx;
+                        const float ad = fabsf(d);
+                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                        bool valid = false;
+                        float sv = 0.f;
+                        if ((k0 + lane < list_n) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                            sv = cpv/d;
+                            valid = jnear < sv;
+                        }
+                        unsigned long long m = __ballot(valid);
+                        if (m) {
+                            float xs = readlane_f(x, jr);
+                            int xis = __builtin_amdgcn_readlane(xi, jr);
+                            for (; m; m &= m - 1) {
+                                const int j = __ffsll((long long)m) - 1;
+                                const float sj = readlane_f(sv, j);
+                                if (sj < xs - 1.e-4f) { xs = sj; xis = __builtin_amdgcn_readlane(line, j); }
+                            }
+                            if (lane == jr) { x = xs; xi = xis; }
+                        }
+                    }
+                }
+                if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+            } else {
+                // many (a view along a stack of coincident walls): lane = ray, every line of the list in turn
+                float x = INFINITY;
+                int xi = -1;
+                #pragma unroll 4
+                for (int k = 0; k < list_n; k++) {
+                    const Cand cd = s_cand_w[k];
+                    const int line = s_info_w[k].y;
+                    if (ambiguous) {
+                        const float d = rx*cd.vy - ry*cd.vx;
+                        const float nt = cd.pqx*ry - cd.pqy*rx;
+                        const float ad = fabsf(d);
+                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                        if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                            if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = line; }
+                        }
+                    }
+                }
+                if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+            }
+        } else
         if (__popcll(amb) > 6) {
             // many such rays (a view full of coincident walls): every one of them walks the lines itself, lines
             // broadcast from LDS - but only the lines whose interval reaches one of these rays are looked at

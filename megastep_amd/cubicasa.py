@@ -133,8 +133,8 @@ def _plan(i, large):
     return _cache[key]
 
 
-def _make(key):
-    return key, floorplan(1000003*int(key[1]) + key[0], key[1])
+def _make(keys):
+    return [(key, floorplan(1000003*int(key[1]) + key[0], key[1])) for key in keys]
 
 
 def prefetch(indices, large=False, workers=None):
@@ -148,8 +148,14 @@ def prefetch(indices, large=False, workers=None):
     if workers <= 1 or len(todo) < 64:
         return
     with mp.get_context('fork').Pool(workers) as pool:
-        for key, plan in pool.imap_unordered(_make, todo, chunksize=8):
-            _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if key[1] else "S"}{key[0]:04d}', **plan)
+        chunks = [todo[i:i + 8] for i in range(0, len(todo), 8)]
+        results = pool.imap_unordered(_make, chunks)
+        try:
+            for _ in chunks:
+                for key, plan in results.next(timeout=60):           # (a pool that stalls is abandoned: the lazy path makes the rest)
+                    _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if key[1] else "S"}{key[0]:04d}', **plan)
+        except mp.TimeoutError:
+            pool.terminate()
 
 
 def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0):

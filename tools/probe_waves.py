@@ -12,7 +12,7 @@ os.environ['MEGASTEP_HIP_LIB'] = f'{root}/megastep_amd/csrc/libmegastep_hip_prob
 import numpy as np, torch, bench                                        # noqa: E402
 from megastep_amd import _lib, cuda, modules                             # noqa: E402
 
-WORDS, STAMPS = 11, 8
+WORDS, STAMPS = 16, 8
 NAMES = {'physics': ['start', 'agent state in', 'cell headers in', 'walls met', '', '', '', 'end'],
          'render': ['start', 'agent state in', '', 'first rows in', 'raycast done', 'winner row + texel row in', 'texels in', 'end']}
 
@@ -59,13 +59,28 @@ def analyse(name, rec, tick_ns, kernel_us):
                 print(f'   waves with {lo_}..{hi_ - 1} stopped agents: {int(m.sum())}, life mean {life[m].mean():.2f} p99 {np.quantile(life[m], .99):.2f}; pairs mean {extra[m, 0].mean():.1f} max {extra[m, 0].max()}; swept {int(extra[m, 1].sum())}')
     if name == 'render':                       # slot 2: 0 no ray on an agent; bit 31 some, settled by the grid's verdicts; else the work left
         v = rec[:, 2]
-        light = t[:, 5] - t[:, 4]
+        light = t[:, 5] - t[:, 4] if NAMES['render'][5] else 0.*t[:, 4]
         dyn, need = v != 0, (v != 0) & (v != 0x80000000)
         print(f'   waves with a ray on an agent: {int(dyn.sum())} ({light[dyn & ~need].mean():.2f} us from raycast to winner row, others {light[~dyn].mean():.2f}); '
               f'with open lights: {int(need.sum())} ({light[need].mean():.2f} us; rays {(v[need] & 127).mean():.1f}, of them without a list {((v[need] >> 7) & 127).mean():.2f}, '
               f'lists {((v[need] >> 14) & 15).mean():.2f}, rounds of pairs {((v[need] >> 18) & 127).mean():.2f}, lights {(v[need] >> 25).mean():.1f})')
         last = np.argsort(-end)[:12]
         print('   the 12 waves that end last (open rays, without list, lists, rounds, lights):', [(int(x & 127), int((x >> 7) & 127), int((x >> 14) & 15), int((x >> 18) & 127), int(x >> 25)) for x in v[last]])
+    if name == 'render':                       # words 11..13: pairs, length of the list if it is whole in LDS (-1: not), rays re-done by the literal fold; 15: clock before that fold
+        x = rec[:, 11:14].astype(np.int64)
+        x[:, 1] = x[:, 1].astype(np.int32)
+        raw = rec[:, :16].astype(np.int64)
+        pass12 = ((raw[:, 15] - raw[:, 3]).astype(np.int32))*tick_ns/1e3
+        fold = ((raw[:, 4] - raw[:, 15]).astype(np.int32))*tick_ns/1e3
+        order = np.argsort(-life)
+        print('   the 16 longest-lived waves (life, passes 1 + 2, fold us | pairs, list, folded rays):', [(round(float(life[i]), 1), round(float(pass12[i]), 1), round(float(fold[i]), 1)) + tuple(int(v) for v in x[i]) for i in order[:16]])
+        print(f'   all waves: pairs mean {x[:, 0].mean():.0f} p99 {np.quantile(x[:, 0], .99):.0f} max {x[:, 0].max()}; list mean {x[:, 1].mean():.0f} max {x[:, 1].max()}, not whole {int((x[:, 1] < 0).sum())}; '
+              f'passes 1 + 2 mean {pass12.mean():.2f} p99 {np.quantile(pass12, .99):.2f} us')
+        for lo_, hi_ in ((0, 1), (1, 2), (2, 7), (7, 65)):
+            mm = (x[:, 2] >= lo_) & (x[:, 2] < hi_)
+            if mm.any():
+                print(f'   waves with {lo_}..{hi_ - 1} folded rays: {int(mm.sum())}: life mean {life[mm].mean():.2f} p90 {np.quantile(life[mm], .9):.2f} max {life[mm].max():.2f} us; '
+                      f'passes 1 + 2 mean {pass12[mm].mean():.2f} max {pass12[mm].max():.2f}; resolution + fold mean {fold[mm].mean():.2f} max {fold[mm].max():.2f} us')
     slowest = np.argsort(-life)[:len(life)//100 + 1]
     print(f'   the slowest 1 %: starts at {np.median(start[slowest]):.1f} us (median), ' + ', '.join(
         f'{NAMES[name][a]}->{NAMES[name][b]} {np.mean(t[slowest, b] - t[slowest, a]):.2f}' for a, b in zip(used[:-1], used[1:])))
@@ -77,10 +92,13 @@ def main():
     ap.add_argument('--res', type=int, default=64); ap.add_argument('--large', action='store_true')
     ap.add_argument('--unique', type=int, default=512); ap.add_argument('--fast-build', action='store_true')
     ap.add_argument('--tick-ns', type=float, default=1/2.4, help='one s_memtime tick in ns')
+    ap.add_argument('--fov', type=float, default=130.); ap.add_argument('--depth-only', action='store_true')
     args = ap.parse_args()
+    if args.depth_only:                                                   # (no shading pass: those stamps are never taken)
+        NAMES['render'][5] = NAMES['render'][6] = ''
     h = _lib.lib()
     h.ms_debug_probe.argtypes = [C.c_void_p, C.c_longlong]
-    core, _ = bench.build_world(args.envs, args.agents, args.res, 130., torch.device('cuda'), seed=1, n_unique=args.unique,
+    core, _ = bench.build_world(args.envs, args.agents, args.res, args.fov, torch.device('cuda'), seed=1, n_unique=args.unique,
                                 large=args.large, fast=args.fast_build)
     N, A = core.n_envs, core.n_agents
     mover = modules.MomentumMovement(core)
@@ -100,7 +118,10 @@ def main():
                 torch.cuda.synchronize()
                 _lib.check(h.ms_debug_probe(buf.data_ptr(), cap))
             ev[0].record()
-            (cuda.physics if name == 'physics' else cuda.render)(core.scenery, core.agents)
+            if name == 'physics':
+                cuda.physics(core.scenery, core.agents)
+            else:
+                cuda.render(core.scenery, core.agents, fields=('distances',) if args.depth_only else None)
             ev[1].record()
             torch.cuda.synchronize()
             if record:

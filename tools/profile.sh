@@ -7,7 +7,7 @@ tag=$1; shift
 shape="$@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-lean="--no-cpu-baseline --no-env-fps --no-shapes"
+lean="--no-cpu-baseline --no-env-fps --no-shapes --plan-workers 0"
 rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python bench.py --steps 100 --warmup 10 $lean $shape > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_write.log 2>&1
