@@ -283,54 +283,8 @@ int ms_wallgrid_scan(const MsScenery* scenery, const MsWallGridParent* parent, c
 int ms_wallgrid_fill(const MsScenery* scenery, const int* reps, int n_reps, int max_cells,
                      const long long* bits_starts, const unsigned* bits, unsigned short* pool, unsigned* vis_entries,
                      float* near_rows, void* hip_stream);
-/* Host instantiation of render_kernel's pass 1 for one line (reference: the all-lines loop kernels.cu:352-377, which it
- * culls): pose = (x, y, sin, cos of the heading), line = (ax, ay, bx, by), `group` = which 64 rays of the agent's `res`:
- * rays first .. first + count - 1 of the group (0-based within it) are the only ones the kernel intersects with the line. */
-void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count);
-/* Host instantiation of the light grid's build (ms_bake; accelerates kernels.cu:238-268) for one cell c (row-major in a grid
- * of nx x ny cells of size `cell` from (ox, oy)), over n_walls walls (n_walls x 4 floats: ax, ay, bx, by) and n_lights
- * lights (n_lights x 3: x, y, intensity), HOST memory: words[4] = the lights' 2-bit verdicts as in lg_vals (0 unknown, 1 lit,
- * 2 dark); candidates = the (light, wall) pairs of the cell's list as in lg_pool (0x80000000 | light << 24 | wall), at most
- * max_candidates of them written; returns how many there are. */
-int ms_host_lightgrid_cell(const float* walls, int n_walls, const float* lights, int n_lights, float ox, float oy, int nx, int ny,
-                           float cell, int c, unsigned* words, unsigned* candidates, int max_candidates);
-/* Host restatement of how render_kernel's pass 2 settles a ray's nearest hit (reference: the order-dependent fold
- * kernels.cu:369-376): the n_hits hits (s[i] > near plane, line[i]) go through the kernel's three key slots in the order
- * `order` (a permutation of 0..n_hits-1), 64 to a window, lockstep within a window as a wavefront plays them.  Returns 1
- * when the slots cannot tell (the kernel then redoes the ray by the literal fold), else 0 with the hit in *nearest_s /
- * *nearest_line (-1: none). */
-int ms_host_fold_hits(const float* s, const int* line, int n_hits, const int* order, float* nearest_s, int* nearest_line);
-/* Host instantiation of ms_physics' reach cull in front of the agent-agent collision test (reference: kernels.cu:119-133,
- * 193-200), for CPU tests: me, other = (x, y, vx/fps, vy/fps); 1 = the pair cannot collide this step, the test is skipped. */
-int ms_host_agents_apart(const float* me, const float* other, float agent_radius);
-/* ... and of the reach cull in front of the agent-wall test (kernels.cu:135-171,202-205): agent = (x, y, vx/fps, vy/fps),
- * wall = (ax, ay, bx, by); 1 = the wall is beyond the agent's reach this step, the test is skipped.  (The host evaluates the
- * foot of the perpendicular with a true division, the kernel with v_rcp_f32: both are lower bounds on the distance.) */
-int ms_host_wall_beyond_reach(const float* agent, const float* wall, float agent_radius);
-/* ... and the reach itself, which also picks the tier of the cell's near list (wg_reach_lo, wg_reach) or the sweep. */
-float ms_host_wall_reach(const float* agent, float agent_radius);
-/* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
- * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
-int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);
-/* ... and of the scan of one whole cell (c, row-major in a grid of nx x ny cells of size `cell` from (ox, oy)) over
- * n_walls walls (n_walls x 4 floats, HOST memory): vis[t] = 1 where wall t goes on the cell's vis list, close[t] = 2 / 1
- * where it is within reach_lo / reach of the cell. */
-void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, int nx, int ny, float cell, int c,
-                           float near_plane, float reach_lo, float reach, unsigned char* vis, unsigned char* close);
-
-/* ... and of the arcs: the run of steps [*lo8, *hi8] (modulo 256) of directions wall w can be seen in from the cell; and
- * whether a wave whose rightmost / leftmost ray point along (right_x, right_y) / (left_x, left_y) would keep such a wall. */
-void ms_host_wall_arc(float x0, float y0, float x1, float y1, const float* w, int* lo8, int* hi8);
-int  ms_host_wedge_meets(float right_x, float right_y, float left_x, float left_y, int lo8, int hi8);
-
-/* Scalar helper exported for tests: sin(pi x), cos(pi x) exactly as the kernels evaluate them. */
-void ms_host_sincospi(float x, float* s, float* c);
-/* Helpers exported for tests of ms_bake's culling (host instantiations of the device functions): the angular bin
- * (of MS_BAKE_BINS around a light) a point falls in, and the circular run of bins [first, first + count) a wall can
- * shadow.  A wall obstructs a point from the light (kernels.cu:238-259) only if the point's bin is in the wall's run. */
-#define MS_BAKE_BINS 64
-int  ms_host_bake_point_bin(float light_x, float light_y, float x, float y);   /* -1: undecidable, test every wall */
-void ms_host_bake_wall_bins(float light_x, float light_y, float ax, float ay, float bx, float by, int* first, int* count);
+/* The host instantiations of the kernels' culls (ms_host_*) and the debug switches (ms_debug_*), which exist for the CPU
+ * tests and A/B runs only, are declared in megastep_hip_test.h: not part of the interface a maintainer binds. */
 
 #ifdef __cplusplus
 }

@@ -67,8 +67,8 @@ class MsRender(C.Structure):
                 ('seen_stamp', C.c_void_p), ('seen_epoch', C.c_void_p), ('seen_count', C.c_void_p)]
 
 
-#: every symbol include/megastep_hip.h declares
-SYMBOLS = ('ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
+#: every symbol include/megastep_hip.h (the boundary) and include/megastep_hip_test.h (test hooks) declare
+SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
            'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
@@ -79,7 +79,7 @@ def _source_hash():
     import hashlib
     h = hashlib.sha256()
     for path in (os.path.join(CSRC, 'megastep_hip.hip'), os.path.join(_HERE, '..', 'include', 'megastep_hip.h'),
-                 os.path.join(CSRC, 'Makefile')):
+                 os.path.join(_HERE, '..', 'include', 'megastep_hip_test.h'), os.path.join(CSRC, 'Makefile')):
         with open(path, 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
@@ -164,6 +164,10 @@ def lib():
         handle.ms_host_wedge_meets.restype = C.c_int
         handle.ms_host_ray_interval.argtypes = [_f32p, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _i32p, _i32p]
         handle.ms_host_ray_interval.restype = None
+        handle.ms_host_ray_interval_wide.argtypes = [_f32p, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, _i32p, _i32p]
+        handle.ms_host_ray_interval_wide.restype = None
+        handle.ms_debug_ray_groups.argtypes = [C.c_int]
+        handle.ms_debug_ray_groups.restype = C.c_int
         handle.ms_host_fold_hits.argtypes = [_f32p, _i32p, C.c_int, _i32p, _f32p, _i32p]
         handle.ms_host_fold_hits.restype = C.c_int
         handle.ms_host_lightgrid_cell.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,

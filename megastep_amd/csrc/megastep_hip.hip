@@ -41,7 +41,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../../include/megastep_hip.h"
+#include "../../include/megastep_hip_test.h"
 
 namespace {
 
@@ -52,6 +52,7 @@ constexpr int WG = 256;             // 4 waves per workgroup
 constexpr int WAVES = WG/WAVE;
 
 thread_local int g_last_hip_error = 0;
+int g_ray_groups = 0;                  // ms_debug_ray_groups: 0 = ms_render picks render_kernel's NG from the resolution
 
 // -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
 // time stamps (s_memtime at its start, at a few points where something it waited for has arrived, at its end) and of
@@ -1186,7 +1187,8 @@ __host__ __device__ inline void agent_frame(const float cs, const float sn, cons
 }
 template <int CLIP>
 __host__ __device__ inline void ray_interval(float xa, float ya, float xb, float yb, const bool live, const float x_clip,
-                                    const float c_a, const float c_b, const float g0, const float last_local, int& lo, int& len) {
+                                    const float c_a, const float c_b, const float g0, const float last_local, int& lo, int& len,
+                                    const float n_rays = 64.f) {
     const bool fa = xa >= x_clip, fb = xb >= x_clip;
     float ra, rb, marg;
     bool inc;
@@ -1209,7 +1211,7 @@ __host__ __device__ inline void ray_interval(float xa, float ya, float xb, float
         ra = fa ? fra : -edge; rb = fb ? frb : edge;
     }
     // fminf/fmaxf drop NaNs towards the wide side, so a doubtful line keeps the full range
-    const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), 64.f);
+    const float flo = fminf(fmaxf(fminf(ra, rb) - (marg + g0), 0.f), n_rays);
     const float fhi = fmaxf(fminf(fmaxf(ra, rb) + (marg - g0), last_local), -1.f);
     lo = (int)ceilf(flo);
     const int n_ = (int)floorf(fhi) - lo + 1;
@@ -1228,7 +1230,14 @@ __host__ __device__ inline void ray_interval(float xa, float ya, float xb, float
 // texel row, no texel and baked-light gathers, no filter, no dynamic lighting of rays that landed on an agent - and the
 // winning line itself is only fetched (for `locations`, `dots` or the first-sight books) if one of those is asked for:
 // a distances-only wave ends with the raycast, without a single dependent load behind it.
-template <int IMPL, int RW, int OBS, int SHADE = 1>
+// NG = 64-ray groups a wave serves (1, 2 or 4; IMPL 2 with one wave per workgroup).  At 128 rays and more an agent's
+// waves each repeated the agent-side half of the work - state, cell, vis list and its arc cull, the agents' lines,
+// pass 1 on every line their wedges share - and at 512 rays that was most of a wave's instructions on a chip whose
+// vector ALUs were 0.99 busy.  A wave of NG groups does it once for 64 NG consecutive rays: pass 1 turns a line into an
+// interval of all of them, pass 2 deals the (line, ray) pairs to the lanes whichever group the ray is in, and only the
+// per-ray ends of the kernel - ray set-up, resolution, shading, stores - run group after group.  (ms_render picks NG from
+// the resolution: 1 up to 64 rays - the headline's instantiation is what it was -, 2 up to 128, 4 beyond.)
+template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 // Occupancy knobs of the render kernel (A/B builds; the defaults are the product): waves per SIMD the register allocation
 // is held to, chunks of rows in flight, capacity of a wave's list of visible lines (which sizes its LDS block)
 #ifndef MS_WAVES
@@ -1243,7 +1252,7 @@ template <int IMPL, int RW, int OBS, int SHADE = 1>
 #ifndef MS_VCAP
 #define MS_VCAP 128
 #endif
-__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVES, MS_WAVES))) void render_kernel(
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1 ? MS_WAVES : NG == 2 ? 4 : 3, NG == 1 ? MS_WAVES : NG == 2 ? 5 : 3))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
@@ -1256,7 +1265,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     //   4096 screen (192 x 4 B)  RGB staging
     // IMPL 2 lays its block out differently (see there): 6144 B
     PROBE_INIT
-    constexpr int LDS_PER_WAVE = (IMPL == 2 ? 24*MS_VCAP + 3072 : 4864);
+    static_assert(NG == 1 || (IMPL == 2 && RW == 1 && (NG == 2 || NG == 4)), "several ray groups per wave: the product raycast, one wave per workgroup");
+    constexpr int NR = WAVE*NG;                  // rays per wave
+    constexpr int LDS_PER_WAVE = (IMPL == 2 ? 24*MS_VCAP + 2304*NG + 768 : 4864);
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
@@ -1277,10 +1288,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const int fan = lb*RW + wave;
     if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int G = (R + WAVE - 1)/WAVE, F = A*G;
+    const int G = (R + NR - 1)/NR, F = A*G;        // g: which run of NR rays of the agent's this wave casts
     const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
-    const int r = g*WAVE + lane;
-    const int r_last = min(g*WAVE + WAVE - 1, R - 1);
+    const int r0 = g*NR;
+    const int r = r0 + lane;                       // (this lane's ray in the wave's first group)
+    const int r_last = min(r0 + NR - 1, R - 1);
+    [[maybe_unused]] const int n_live = r_last - r0 + 1;
 
     const int L = sc.lines_widths[n];
     const int base = sc.lines_starts[n];
@@ -1380,21 +1393,28 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     }
     // --- ray setup (kernels.cu:334-344)
     const float Rf = (float)R;
-    const float uy = (Rf - 2*(float)r - 1)*half_screen/Rf;            // ray_y, kernels.cu:234-236
-    const float rx = cs*1.f - sn*uy, ry = sn*1.f + cs*uy;
+    auto ray_len = [&](const float rx_, const float ry_) {
 #if MS_SQRT_NORMAL
-    const float rlen = sqrt_normal(rx*rx + ry*ry);                      // (|r|^2 = (cos^2 + sin^2)(1 + uy^2): 1 to 1 + half_screen^2)
+        return sqrt_normal(rx_*rx_ + ry_*ry_);                          // (|r|^2 = (cos^2 + sin^2)(1 + uy^2): 1 to 1 + half_screen^2)
 #else
-    const float rlen = sqrtf(rx*rx + ry*ry);
+        return sqrtf(rx_*rx_ + ry_*ry_);
 #endif
-    const float near = agent_radius/rlen;
+    };
+    auto ray_of = [&](const int r_, float& rx_, float& ry_, float& rlen_, float& near_) {
+        const float uy = (Rf - 2*(float)r_ - 1)*half_screen/Rf;        // ray_y, kernels.cu:234-236
+        rx_ = cs*1.f - sn*uy; ry_ = sn*1.f + cs*uy;
+        rlen_ = ray_len(rx_, ry_);
+        near_ = agent_radius/rlen_;
+    };
+    float rx, ry, rlen, near;                                           // (the wave's first group's; the others' live in LDS)
+    ray_of(r, rx, ry, rlen, near);
 
     // Screen-space bookkeeping for the culling below.  In the agent frame (x' forward, y' left) a point
     // is seen at screen coordinate ys = y'/x', i.e. at the continuous ray index c_a - ys*c_b (ray_y inverted).
     // Nothing with x' below x_clip can be hit: a hit has x' = s > agent_radius/|ru| > 2 x_clip.
     const float c_a = 0.5f*(Rf - 1.f), c_b = rc.c_b;                      // c_b = R/2/half_screen
     const float x_clip = rc.x_clip;                                        // agent_radius/2/sqrt(1 + half_screen^2)
-    const float g0 = (float)(g*WAVE);
+    const float g0 = (float)r0;
     [[maybe_unused]] const int my_group = lane/GSIZE;
 
     float nearest_s = INFINITY;
@@ -1651,24 +1671,47 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         //               | near (64 x 4 B) | queue (128 x 2 B) | best, second, third (64 x 8 B each) | marks (4096 bits)
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = MS_VCAP, P_CAP = 4096 < 64*MS_VCAP ? 4096 : 64*MS_VCAP;
-        constexpr int O_INFO = 16*V_CAP, O_RAY = 24*V_CAP, O_NEAR = O_RAY + 512, O_QUEUE = O_NEAR + 256, O_BEST = O_QUEUE + 256;
-        static_assert(O_BEST + 3*512 + 512 == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
+        constexpr int O_INFO = 16*V_CAP, O_RAY = 24*V_CAP, O_NEAR = O_RAY + 512*NG, O_QUEUE = O_NEAR + 256*NG, O_BEST = O_QUEUE + 256;
+        static_assert(O_BEST + 3*512*NG + 512 == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
+        static_assert(P_CAP >= NR, "a line's pairs - one per ray of the wave at most - must fit an empty list");
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][O_INFO]);
         // (direction and near plane in arrays of their own: at 8 and 4 bytes a ray, a window's reads - one ray per lane, the
         // rays mostly consecutive - touch every LDS bank once; as one 16-byte record per ray they were two-way conflicts)
         float2* const s_ray_w = reinterpret_cast<float2*>(&s_raw[wave][O_RAY]);
         float* const s_near_w = reinterpret_cast<float*>(&s_raw[wave][O_NEAR]);
         unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST]);
-        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 512]);
-        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 1024]);
-        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][O_BEST + 1536]);
+        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 512*NG]);
+        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 1024*NG]);
+        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][O_BEST + 1536*NG]);
         s_ray_w[lane] = make_float2(rx, ry);
         s_near_w[lane] = near;
         s_best_w[lane] = ~0ull;
         s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
         s_second_w[lane] = ~0ull;
         s_third_w[lane] = ~0ull;
-        const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
+        // the run of directions of this wave's rays, from its rightmost ray (the last live one) to its leftmost (lane 0's of
+        // the first group)                    (pseudo_angle with the reciprocal the hardware offers: the margin is 10^4 of its roundings wide)
+        auto pseudo_angle_fast = [](const float x_, const float y_) {
+            const float pq_ = y_*__builtin_amdgcn_rcpf(fabsf(x_) + fabsf(y_));
+            return x_ < 0.f ? 2.f - pq_ : (pq_ < 0.f ? 4.f + pq_ : pq_);
+        };
+        const float pa_first = readlane_f(pseudo_angle_fast(rx, ry), 0);
+        float pa_last = readlane_f(pseudo_angle_fast(rx, ry), min(n_live, WAVE) - 1);
+        if constexpr (NG > 1) {
+            // the other groups' rays: directions and near planes into LDS, slots cleared (groups past the last ray too:
+            // harmless, and no pair ever names their rays)
+            #pragma unroll
+            for (int q = 1; q < NG; q++) {
+                float qx, qy, ql, qn;
+                ray_of(r + q*WAVE, qx, qy, ql, qn);
+                s_ray_w[q*WAVE + lane] = make_float2(qx, qy);
+                s_near_w[q*WAVE + lane] = qn;
+                s_best_w[q*WAVE + lane] = ~0ull; s_second_w[q*WAVE + lane] = ~0ull; s_third_w[q*WAVE + lane] = ~0ull;
+                const float pl = readlane_f(pseudo_angle_fast(qx, qy), min(max(n_live - q*WAVE, 1), WAVE) - 1);
+                if (n_live > q*WAVE) pa_last = pl;
+            }
+        }
+        const float last_local = (float)(r_last - r0);        // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection, and the conservative
         // interval [lo, lo + len) of this wave's rays that can hit it
         // a chunk's lines as they are in memory, lane = line (dead lanes get the last row, agent rows whatever the last
@@ -1687,7 +1730,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
             cd = Cand{pqx, pqy, w.z - w.x, w.w - w.y};                 // v = b - a
             float xa, ya, xb, yb;
             agent_frame(cs, sn, pqx, pqy, dbx, dby, xa, ya, xb, yb);
-            ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, live, x_clip, c_a, c_b, g0, last_local, lo, len);
+            ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, live, x_clip, c_a, c_b, g0, last_local, lo, len, (float)NR);
         };
 
         int n_pairs_total = 0, n_windows = 0;    // telemetry
@@ -1717,7 +1760,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
                 const int k = before + upto - 1;             // (past the last pair there are no marks: the last line, harmless)
                 before += __popcll(M);
                 const int2 info = s_info_w[k];
-                const int rr = (p + info.x) & 63;            // ray of this pair, wave-local (in range as it is for valid pairs)
+                const int rr = (p + info.x) & (NR - 1);      // ray of this pair, wave-local (in range as it is for valid pairs)
                 const Cand cd = s_cand_w[k];
                 const float2 ray = s_ray_w[rr];
                 const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
@@ -1764,6 +1807,31 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
             const int incl = wave_scan_add(len);
             const int chunk_pairs = __builtin_amdgcn_readlane(incl, 63);
             const int chunk_lines = __popcll(vm);
+            if constexpr (NG > 1) {
+                // 64 lines of up to 64 NG pairs each need not fit an empty list: those that do go in - a prefix of the
+                // batch, by the running count of pairs -, the list is worked off, and the rest follows
+                if (chunk_pairs > P_CAP) {
+                    int base = 0;                                            // pairs of the lines that are in already
+                    for (unsigned long long left = vm; left; ) {
+                        const int room = P_CAP - n_pairs;
+                        const bool fits = ((left >> lane) & 1ull) && (incl - base <= room);
+                        const unsigned long long fm = __ballot(fits);
+                        if (!fm || n_list + __popcll(fm) > V_CAP) { drain(); continue; }      // (a line alone always fits an empty list)
+                        const int upto = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(fm));   // the pairs of the batch up to its last line that fits
+                        if (fits) {
+                            const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
+                            const int first = n_pairs + incl - len - base;
+                            s_cand_w[k] = cd;
+                            s_info_w[k] = make_int2(lo - first, l);
+                            atomicOr(&s_mark_w[first >> 5], 1u << (first & 31));
+                        }
+                        n_list += __popcll(fm); n_pairs += upto - base;
+                        base = upto;
+                        left &= ~fm;
+                    }
+                    return;
+                }
+            }
             if ((n_list + chunk_lines > V_CAP) | (n_pairs + chunk_pairs > P_CAP)) drain();
             if (seen) {
                 const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
@@ -1799,14 +1867,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         const int AL = AF - own;                                             // agent lines among the items
         const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned*>(sc.wg_pool + wg_first), 0, listed ? 4*n_raw : 0, 0x00020000);
-        // the run of directions of this wave's rays, from its rightmost ray (the last live lane's) to its leftmost (lane 0's)
         int wa8, wb8;
-        {
-            // (pseudo_angle with the reciprocal the hardware offers: the margin is 10^4 of its roundings wide)
-            const float pq_ = ry*__builtin_amdgcn_rcpf(fabsf(rx) + fabsf(ry));
-            const float pa = rx < 0.f ? 2.f - pq_ : (pq_ < 0.f ? 4.f + pq_ : pq_);
-            wg_wedge(readlane_f(pa, r_last - g*WAVE), readlane_f(pa, 0), wa8, wb8);
-        }
+        wg_wedge(pa_last, pa_first, wa8, wb8);
         auto raw = [&](const int k0) {                                       // entries k0 + lane of the list (past its end: 0)
             return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(list_rsrc, 4*(k0 + lane), 0, 0);
         };
@@ -1870,74 +1932,174 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         }
         if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long best = s_best_w[lane], second = s_second_w[lane], third = s_third_w[lane];
-        bool ambiguous = false;
-        if (best != ~0ull) {                     // the resolution of IMPL 1, word for word
-            const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
-            const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
-            nearest_s = s1;
-            nearest_idx = i1;
-            if ((second != ~0ull) && !(s1 < s2 - 1.e-4f)) {
-                if ((third == ~0ull) || (s2 < s3 - 1.e-4f)) {
-                    const bool first_is_1 = i1 < i2;
-                    const float sa = first_is_1 ? s1 : s2, sb = first_is_1 ? s2 : s1;
-                    const int ia = first_is_1 ? i1 : i2, ib = first_is_1 ? i2 : i1;
-                    const bool b_wins = sb < sa - 1.e-4f;
-                    nearest_s = b_wins ? sb : sa;
-                    nearest_idx = b_wins ? ib : ia;
-                } else {
-                    ambiguous = true;
+        // The nearest hit of this lane's ray of the wave's group q from its three key slots, or - where they cannot tell - by
+        // the literal fold.  (rx, ry, near: that ray's; the first group's are in registers, the others' come from LDS.)
+        auto resolve_group = [&](const int q, const float rx, const float ry, const float near, float& nearest_s, int& nearest_idx) {
+            const unsigned long long best = s_best_w[q*WAVE + lane], second = s_second_w[q*WAVE + lane], third = s_third_w[q*WAVE + lane];
+            bool ambiguous = false;
+            if (best != ~0ull) {                     // the resolution of IMPL 1, word for word
+                const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
+                const int i1 = (int)(uint32_t)best, i2 = (int)(uint32_t)second;
+                nearest_s = s1;
+                nearest_idx = i1;
+                if ((second != ~0ull) && !(s1 < s2 - 1.e-4f)) {
+                    if ((third == ~0ull) || (s2 < s3 - 1.e-4f)) {
+                        const bool first_is_1 = i1 < i2;
+                        const float sa = first_is_1 ? s1 : s2, sb = first_is_1 ? s2 : s1;
+                        const int ia = first_is_1 ? i1 : i2, ib = first_is_1 ? i2 : i1;
+                        const bool b_wins = sb < sa - 1.e-4f;
+                        nearest_s = b_wins ? sb : sa;
+                        nearest_idx = b_wins ? ib : ia;
+                    } else {
+                        ambiguous = true;
+                    }
                 }
             }
-        }
-        // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1
-        const unsigned long long amb = __ballot(ambiguous);
-        PROBE_VAL(11, n_pairs_total) PROBE_VAL(12, n_drains == 1 ? list_n : -1) PROBE_VAL(13, __popcll(amb))
-#if MS_PROBE
-        const unsigned t_fold0 = (unsigned)clock64();
-        PROBE_VAL(15, t_fold0)                                               // (with stamp 3: how long passes 1 and 2 took)
-#endif
-        // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
-        // per wave on one address are 1.3 ms at 262144 waves
-        if (out.workspace && lane == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
-            atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
-        }
-        if (amb && out.workspace && lane == 0) {
-            atomicAdd(&out.workspace[1], __popcll(amb));
-            if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
-        }
-        if (amb && n_drains == 1) {
-            // The usual case: the wave's list was worked off once, at the end, so all of it is still in LDS - every line
-            // a ray of this wave can hit (the exact cull arguments above), ray-independent half of the intersection
-            // ready, in LINE ORDER: the agents' lines in theirs, then the cell's vis list, which wallgrid_fill_kernel
-            // writes in ascending wall number and the arc cull only thins.  The reference's fold (kernels.cu:352-377)
-            // over the lines a ray does not hit is a no-op, so the literal fold over the list is the literal fold:
-            // lane = ray, one broadcast LDS read per line, no memory traffic and no chain of dependent chunk loads
-            // (the sweep over all the env's lines from memory below made such a wave the one its launch waited for:
-            // 10-26 us against a mean life of 6-9; profiles/r04_probe_*.txt).
-            const int rounds = (list_n + WAVE - 1)/WAVE;
-            if (10*__popcll(amb)*rounds <= list_n + 40) {
-                // a few such rays (nearly always one or two): lane = line of the list, 64 at a time, read from LDS once; per
-                // ray every line's hit at once, then the ray's hits - a handful - folded in line order through a scalar
-                // loop into the ray's state, which lives in the ray's own lane
+            // The literal fold for the rays that need it (kernels.cu:352-377), as in IMPL 1
+            const unsigned long long amb = __ballot(ambiguous);
+            PROBE_VAL(11, n_pairs_total) PROBE_VAL(12, n_drains == 1 ? list_n : -1) PROBE_VAL(13, __popcll(amb))
+    #if MS_PROBE
+            const unsigned t_fold0 = (unsigned)clock64();
+            PROBE_VAL(15, t_fold0)                                               // (with stamp 3: how long passes 1 and 2 took)
+    #endif
+            // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
+            // per wave on one address are 1.3 ms at 262144 waves
+            if (out.workspace && lane == 0 && q == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
+                atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
+            }
+            if (amb && out.workspace && lane == 0) {
+                atomicAdd(&out.workspace[1], __popcll(amb));
+                if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
+            }
+            if (amb && n_drains == 1) {
+                // The usual case: the wave's list was worked off once, at the end, so all of it is still in LDS - every line
+                // a ray of this wave can hit (the exact cull arguments above), ray-independent half of the intersection
+                // ready, in LINE ORDER: the agents' lines in theirs, then the cell's vis list, which wallgrid_fill_kernel
+                // writes in ascending wall number and the arc cull only thins.  The reference's fold (kernels.cu:352-377)
+                // over the lines a ray does not hit is a no-op, so the literal fold over the list is the literal fold:
+                // lane = ray, one broadcast LDS read per line, no memory traffic and no chain of dependent chunk loads
+                // (the sweep over all the env's lines from memory below made such a wave the one its launch waited for:
+                // 10-26 us against a mean life of 6-9; profiles/r04_probe_*.txt).
+                const int rounds = (list_n + WAVE - 1)/WAVE;
+                if (10*(int)__popcll(amb)*rounds <= list_n + 40) {
+                    // a few such rays (nearly always one or two): lane = line of the list, 64 at a time, read from LDS once; per
+                    // ray every line's hit at once, then the ray's hits - a handful - folded in line order through a scalar
+                    // loop into the ray's state, which lives in the ray's own lane
+                    float x = INFINITY;
+                    int xi = -1;
+                    for (int k0 = 0; k0 < list_n; k0 += WAVE) {
+                        const int k = min(k0 + lane, list_n - 1);
+                        const Cand cd = s_cand_w[k];
+                        const int line = s_info_w[k].y;
+                        const float cpv = cd.pqx*cd.vy - cd.pqy*cd.vx;               // cross(PQ, V)
+                        for (unsigned long long todo = amb; todo; todo &= todo - 1) {
+                            const int jr = __ffsll((long long)todo) - 1;
+                            const float jrx = readlane_f(rx, jr), jry = readlane_f(ry, jr), jnear = readlane_f(near, jr);
+                            const float d = jrx*cd.vy - jry*cd.vx;
+                            const float nt = cd.pqx*jry - cd.pqy*jrx;
+                            const float ad = fabsf(d);
+                            const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                            bool valid = false;
+                            float sv = 0.f;
+                            if ((k0 + lane < list_n) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                                sv = cpv/d;
+                                valid = jnear < sv;
+                            }
+                            unsigned long long m = __ballot(valid);
+                            if (m) {
+                                float xs = readlane_f(x, jr);
+                                int xis = __builtin_amdgcn_readlane(xi, jr);
+                                for (; m; m &= m - 1) {
+                                    const int j = __ffsll((long long)m) - 1;
+                                    const float sj = readlane_f(sv, j);
+                                    if (sj < xs - 1.e-4f) { xs = sj; xis = __builtin_amdgcn_readlane(line, j); }
+                                }
+                                if (lane == jr) { x = xs; xi = xis; }
+                            }
+                        }
+                    }
+                    if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+                } else {
+                    // many (a view along a stack of coincident walls): lane = ray, every line of the list in turn
+                    float x = INFINITY;
+                    int xi = -1;
+                    #pragma unroll 4
+                    for (int k = 0; k < list_n; k++) {
+                        const Cand cd = s_cand_w[k];
+                        const int line = s_info_w[k].y;
+                        if (ambiguous) {
+                            const float d = rx*cd.vy - ry*cd.vx;
+                            const float nt = cd.pqx*ry - cd.pqy*rx;
+                            const float ad = fabsf(d);
+                            const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                            if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                                const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                                if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = line; }
+                            }
+                        }
+                    }
+                    if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+                }
+            } else
+            if (__popcll(amb) > 6) {
+                // many such rays (a view full of coincident walls): every one of them walks the lines itself, lines
+                // broadcast from LDS - but only the lines whose interval reaches one of these rays are looked at
                 float x = INFINITY;
                 int xi = -1;
-                for (int k0 = 0; k0 < list_n; k0 += WAVE) {
-                    const int k = min(k0 + lane, list_n - 1);
-                    const Cand cd = s_cand_w[k];
-                    const int line = s_info_w[k].y;
-                    const float cpv = cd.pqx*cd.vy - cd.pqy*cd.vx;               // cross(PQ, V)
+                for (int c0 = 0; c0 < L; c0 += WAVE) {
+                    Cand mine;
+                    int lo = 0, len = 0;
+                    line_math(fetch(c0), c0 + lane, c0 + lane < L, c0 < AF, c0 == 0, mine, lo, len);
+                    __builtin_amdgcn_wave_barrier();
+                    s_cand_w[lane] = mine;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (unsigned long long todo = __ballot(len > 0); todo; todo &= todo - 1) {
+                        const int j = __ffsll((long long)todo) - 1;
+                        int jlo = __builtin_amdgcn_readlane(lo, j) - q*WAVE, jhi = jlo + __builtin_amdgcn_readlane(len, j) - 1;   // in this group's lanes
+                        if ((jhi < 0) | (jlo >= WAVE)) continue;
+                        jlo = max(jlo, 0);
+                        const unsigned long long span = ((jhi >= 63) ? ~0ull : ((2ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull);
+                        if (!(span & amb)) continue;
+                        if (ambiguous & (lane >= jlo) & (lane <= jhi)) {
+                            const Cand cd = s_cand_w[j];
+                            const float d = rx*cd.vy - ry*cd.vx;
+                            const float nt = cd.pqx*ry - cd.pqy*rx;
+                            const float ad = fabsf(d);
+                            const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                            if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                                const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                                if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = c0 + j; }
+                            }
+                        }
+                    }
+                }
+                if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+            } else if (amb) {
+                float x = INFINITY;
+                int xi = -1;
+                for (int c0 = 0; c0 < L; c0 += WAVE) {
+                    const int l = c0 + lane;
+                    float pqx = 0.f, pqy = 0.f, vx = 0.f, vy = 0.f;
+                    float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c0 < AF) aw = agent_line(l);
+                    if (l < L) {
+                        float4 w = aw;                       // (not `l < AF ? aw : ln[l]`: hipcc turns that into a select of
+                        if (l >= AF) w = ln[l];              //  two ADDRESSES and parks aw in scratch memory - for every wave)
+                        pqx = w.x - pp.x; pqy = w.y - pp.y; vx = w.z - w.x; vy = w.w - w.y;
+                    }
                     for (unsigned long long todo = amb; todo; todo &= todo - 1) {
                         const int jr = __ffsll((long long)todo) - 1;
                         const float jrx = readlane_f(rx, jr), jry = readlane_f(ry, jr), jnear = readlane_f(near, jr);
-                        const float d = jrx*cd.vy - jry*cd.vx;
-                        const float nt = cd.pqx*jry - cd.pqy*jrx;
+                        const float d = jrx*vy - jry*vx;
+                        const float nt = pqx*jry - pqy*jrx;
                         const float ad = fabsf(d);
                         const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
                         bool valid = false;
                         float sv = 0.f;
-                        if ((k0 + lane < list_n) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                            sv = cpv/d;
+                        if ((l < L) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
+                            sv = (pqx*vy - pqy*vx)/d;
                             valid = jnear < sv;
                         }
                         unsigned long long m = __ballot(valid);
@@ -1947,107 +2109,31 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
                             for (; m; m &= m - 1) {
                                 const int j = __ffsll((long long)m) - 1;
                                 const float sj = readlane_f(sv, j);
-                                if (sj < xs - 1.e-4f) { xs = sj; xis = __builtin_amdgcn_readlane(line, j); }
+                                if (sj < xs - 1.e-4f) { xs = sj; xis = c0 + j; }
                             }
                             if (lane == jr) { x = xs; xi = xis; }
                         }
                     }
                 }
                 if (ambiguous) { nearest_s = x; nearest_idx = xi; }
-            } else {
-                // many (a view along a stack of coincident walls): lane = ray, every line of the list in turn
-                float x = INFINITY;
-                int xi = -1;
-                #pragma unroll 4
-                for (int k = 0; k < list_n; k++) {
-                    const Cand cd = s_cand_w[k];
-                    const int line = s_info_w[k].y;
-                    if (ambiguous) {
-                        const float d = rx*cd.vy - ry*cd.vx;
-                        const float nt = cd.pqx*ry - cd.pqy*rx;
-                        const float ad = fabsf(d);
-                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
-                        if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
-                            if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = line; }
-                        }
-                    }
-                }
-                if (ambiguous) { nearest_s = x; nearest_idx = xi; }
             }
-        } else
-        if (__popcll(amb) > 6) {
-            // many such rays (a view full of coincident walls): every one of them walks the lines itself, lines
-            // broadcast from LDS - but only the lines whose interval reaches one of these rays are looked at
-            float x = INFINITY;
-            int xi = -1;
-            for (int c0 = 0; c0 < L; c0 += WAVE) {
-                Cand mine;
-                int lo = 0, len = 0;
-                line_math(fetch(c0), c0 + lane, c0 + lane < L, c0 < AF, c0 == 0, mine, lo, len);
-                __builtin_amdgcn_wave_barrier();
-                s_cand_w[lane] = mine;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (unsigned long long todo = __ballot(len > 0); todo; todo &= todo - 1) {
-                    const int j = __ffsll((long long)todo) - 1;
-                    const int jlo = __builtin_amdgcn_readlane(lo, j), jhi = jlo + __builtin_amdgcn_readlane(len, j) - 1;
-                    const unsigned long long span = ((jhi >= 63) ? ~0ull : ((2ull << jhi) - 1ull)) & ~((1ull << jlo) - 1ull);
-                    if (!(span & amb)) continue;
-                    if (ambiguous & (lane >= jlo) & (lane <= jhi)) {
-                        const Cand cd = s_cand_w[j];
-                        const float d = rx*cd.vy - ry*cd.vx;
-                        const float nt = cd.pqx*ry - cd.pqy*rx;
-                        const float ad = fabsf(d);
-                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
-                        if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
-                            if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = c0 + j; }
-                        }
-                    }
-                }
+        };
+        if constexpr (NG == 1) {
+            resolve_group(0, rx, ry, near, nearest_s, nearest_idx);
+        } else {
+            // group after group; a group's answer goes back into its first key slot as (s bits << 32 | line) for the
+            // epilogue to pick up - the lists in LDS, which a literal fold reads, are gone by then (lighting scratch)
+            #pragma unroll 1
+            for (int q = 0; q*WAVE < n_live; q++) {
+                const float2 rq = s_ray_w[q*WAVE + lane];
+                float ns = INFINITY;
+                int ni = -1;
+                resolve_group(q, rq.x, rq.y, s_near_w[q*WAVE + lane], ns, ni);
+                s_best_w[q*WAVE + lane] = ((unsigned long long)f_bits(ns) << 32) | (unsigned)ni;
             }
-            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
-        } else if (amb) {
-            float x = INFINITY;
-            int xi = -1;
-            for (int c0 = 0; c0 < L; c0 += WAVE) {
-                const int l = c0 + lane;
-                float pqx = 0.f, pqy = 0.f, vx = 0.f, vy = 0.f;
-                float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c0 < AF) aw = agent_line(l);
-                if (l < L) {
-                    const float4 w = (l < AF) ? aw : ln[l];
-                    pqx = w.x - pp.x; pqy = w.y - pp.y; vx = w.z - w.x; vy = w.w - w.y;
-                }
-                for (unsigned long long todo = amb; todo; todo &= todo - 1) {
-                    const int jr = __ffsll((long long)todo) - 1;
-                    const float jrx = readlane_f(rx, jr), jry = readlane_f(ry, jr), jnear = readlane_f(near, jr);
-                    const float d = jrx*vy - jry*vx;
-                    const float nt = pqx*jry - pqy*jrx;
-                    const float ad = fabsf(d);
-                    const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
-                    bool valid = false;
-                    float sv = 0.f;
-                    if ((l < L) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                        sv = (pqx*vy - pqy*vx)/d;
-                        valid = jnear < sv;
-                    }
-                    unsigned long long m = __ballot(valid);
-                    if (m) {
-                        float xs = readlane_f(x, jr);
-                        int xis = __builtin_amdgcn_readlane(xi, jr);
-                        for (; m; m &= m - 1) {
-                            const int j = __ffsll((long long)m) - 1;
-                            const float sj = readlane_f(sv, j);
-                            if (sj < xs - 1.e-4f) { xs = sj; xis = c0 + j; }
-                        }
-                        if (lane == jr) { x = xs; xi = xis; }
-                    }
-                }
-            }
-            if (ambiguous) { nearest_s = x; nearest_idx = xi; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 #if MS_AB_IMPLS
@@ -2147,15 +2233,21 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     // (uniform; constant-folded away in the colour instantiations)
     const bool want_texel_row = COLOUR || (OBS && late->out.seen_stamp != nullptr);
     const bool want_line = want_texel_row || late->out.locations != nullptr || late->out.dots != nullptr;
-    const int row = min(max(nearest_idx, 0), max(L - 1, 0));
-    float4 hw_mem = make_float4(0.f, 0.f, 0.f, 0.f);
-    int tex_w = 1, tstart = 0;
-    if (want_line) hw_mem = rows.row(row);
-    if (want_texel_row) {
-        const int* const l_tex_widths = late->sc.textures_widths;
-        const int* const l_tex_starts = late->sc.textures_starts;
-        tex_w = l_tex_widths[base + row]; tstart = l_tex_starts[base + row];
-    }
+    // what depends on the winner's number alone: its row, its texel count and first texel
+    // (plain scalars in and out: as a struct by value this cost every wave 32 bytes of scratch memory)
+    auto winner_of = [&](const int nearest_idx, float4& hw_mem, int& tex_w, int& tstart) {
+        const int row = min(max(nearest_idx, 0), max(L - 1, 0));
+        hw_mem = make_float4(0.f, 0.f, 0.f, 0.f); tex_w = 1; tstart = 0;
+        if (want_line) hw_mem = rows.row(row);
+        if (want_texel_row) {
+            const int* const l_tex_widths = late->sc.textures_widths;
+            const int* const l_tex_starts = late->sc.textures_starts;
+            tex_w = l_tex_widths[base + row]; tstart = l_tex_starts[base + row];
+        }
+    };
+    // ... and the rest of a group's rays' lives: q = the group, r = this lane's ray of it, (rx, ry, rlen) = its direction
+    auto finish_group = [&](const int q, const int r, const float rx, const float ry, const float rlen,
+                            const float nearest_s, const int nearest_idx, const float4 hw_mem, const int tex_w, const int tstart) {
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
     if (want_line) {
@@ -2269,8 +2361,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nfl = 3*(r_last - g*WAVE + 1);
-            float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + g*WAVE);
+            const int nfl = 3*min(n_live - q*WAVE, WAVE);
+            float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + r0 + q*WAVE);
             #pragma unroll
             for (int k = 0; k < 3; k++) {
                 const int j = lane + k*WAVE;
@@ -2300,6 +2392,34 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
                 late->out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
             }
             if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd/fs;
+        }
+    }
+    };
+    if constexpr (NG == 1) {
+        float4 hw_mem; int tex_w, tstart;
+        winner_of(nearest_idx, hw_mem, tex_w, tstart);
+        finish_group(0, r, rx, ry, rlen, nearest_s, nearest_idx, hw_mem, tex_w, tstart);
+    } else {
+        // Group after group, one step ahead with the loads: while a group is shaded the next one's winner rows travel.
+        // (the rays' directions and the groups' answers where the raycast left them in LDS: see the block's layout there)
+        const float2* const s_ray_w = reinterpret_cast<const float2*>(&s_raw[wave][24*MS_VCAP]);
+        const unsigned long long* const s_best_w = reinterpret_cast<const unsigned long long*>(&s_raw[wave][24*MS_VCAP + 768*NG + 256]);
+        unsigned long long key = s_best_w[lane];
+        float4 n_hw; int n_tw, n_ts;
+        winner_of((int)(uint32_t)key, n_hw, n_tw, n_ts);
+        #pragma unroll 1
+        for (int q = 0; q*WAVE < n_live; q++) {
+            const float4 hw_mem = n_hw;
+            const int tex_w = n_tw, tstart = n_ts;
+            const float ns = bits_f((uint32_t)(key >> 32));
+            const int ni = (int)(uint32_t)key;
+            const float2 rq = s_ray_w[q*WAVE + lane];
+            if ((q + 1)*WAVE < n_live) {
+                key = s_best_w[(q + 1)*WAVE + lane];
+                winner_of((int)(uint32_t)key, n_hw, n_tw, n_ts);
+            }
+            finish_group(q, r + q*WAVE, rq.x, rq.y, ray_len(rq.x, rq.y), ns, ni, hw_mem, tex_w, tstart);
+            __builtin_amdgcn_wave_barrier();
         }
     }
     PROBE_DONE(fan)
@@ -3373,16 +3493,23 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
 }
 #endif
 
-void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count) {
+int ms_debug_ray_groups(int groups) { g_ray_groups = groups; return MS_OK; }
+
+void ms_host_ray_interval_wide(const float* pose, const float* line, int res, float fov, float agent_radius, int groups, int wave,
+                               int* first, int* count) {
     // (the launch-invariant values as ms_render works them out, the per-wave ones as render_kernel does)
     const float half_screen = tanf(3.14159265358979323846f/180.f*fov/2.);
     const float x_clip = 0.5f*agent_radius/sqrtf(1.f + half_screen*half_screen), c_b = 0.5f*(float)res/half_screen;
-    const float c_a = 0.5f*((float)res - 1.f), g0 = (float)(group*WAVE);
-    const int r_last = (group*WAVE + WAVE - 1 < res - 1) ? group*WAVE + WAVE - 1 : res - 1;
-    const float last_local = (float)(r_last - group*WAVE);
+    const int nr = WAVE*groups, r0 = wave*nr;
+    const float c_a = 0.5f*((float)res - 1.f), g0 = (float)r0;
+    const int r_last = (r0 + nr - 1 < res - 1) ? r0 + nr - 1 : res - 1;
+    const float last_local = (float)(r_last - r0);
     float xa, ya, xb, yb;
     agent_frame(pose[3], pose[2], line[0] - pose[0], line[1] - pose[1], line[2] - pose[0], line[3] - pose[1], xa, ya, xb, yb);
-    ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, true, x_clip, c_a, c_b, g0, last_local, *first, *count);
+    ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, true, x_clip, c_a, c_b, g0, last_local, *first, *count, (float)nr);
+}
+void ms_host_ray_interval(const float* pose, const float* line, int res, float fov, float agent_radius, int group, int* first, int* count) {
+    ms_host_ray_interval_wide(pose, line, res, fov, agent_radius, 1, group, first, count);
 }
 
 int ms_host_lightgrid_cell(const float* walls, int n_walls, const float* lights, int n_lights, float ox, float oy, int nx, int ny,
@@ -3570,7 +3697,16 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
-    const int G = (R + WAVE - 1)/WAVE;
+    // ray groups per wave (render_kernel's NG): one up to 64 rays, two up to 128, four beyond - an agent's waves share its
+    // side of the work instead of each repeating it.  (ms_debug_ray_groups: A/B runs and tests pin it.)
+    int ng = 1;                                                          // (measured: see DESIGN 3.6 - wider waves are not yet a gain)
+    if (g_ray_groups == 1 || g_ray_groups == 2 || g_ray_groups == 4) ng = g_ray_groups;
+#if MS_AB_IMPLS
+    if (getenv("MEGASTEP_RENDER_IMPL")) ng = 1;
+#endif
+    // (without a light grid the rays that land on an agent are lit by dynlight_kernel, which takes them by groups of 64)
+    if (!(sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f) && sc->n_agents > 1 && (out->screen || out->obs_rgb)) ng = 1;
+    const int G = (R + ng*WAVE - 1)/(ng*WAVE);
     const long long n_fans = (long long)sc->n_envs*sc->n_agents*G;
     if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
     // kernels.cu:22
@@ -3638,9 +3774,15 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     else if (pairs1) { if (obs) MS_LAUNCH_RENDER(1, 1); else MS_LAUNCH_RENDER(1, 0); }
     else
 #endif
-    if (!colour)
-        hipLaunchKernelGGL((render_kernel<2, RW, 1, 0>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc);
-    else { if (obs) MS_LAUNCH_RENDER(2, 1); else MS_LAUNCH_RENDER(2, 0); }
+#define MS_LAUNCH_RENDER_NG(O, S, NG_) \
+    hipLaunchKernelGGL((render_kernel<2, RW, O, S, NG_>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
+#define MS_LAUNCH_RENDER_OS(NG_) \
+    { if (!colour) MS_LAUNCH_RENDER_NG(1, 0, NG_); else if (obs) MS_LAUNCH_RENDER_NG(1, 1, NG_); else MS_LAUNCH_RENDER_NG(0, 1, NG_); }
+    if (ng == 4) MS_LAUNCH_RENDER_OS(4)
+    else if (ng == 2) MS_LAUNCH_RENDER_OS(2)
+    else MS_LAUNCH_RENDER_OS(1)
+#undef MS_LAUNCH_RENDER_OS
+#undef MS_LAUNCH_RENDER_NG
 #undef MS_LAUNCH_RENDER
     // without a grid: second launch.  With one agent per env no ray can land on an agent line (own lines sit
     // inside the near plane), so there is nothing to light.

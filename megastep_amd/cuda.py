@@ -20,6 +20,13 @@ from . import _lib
 _config = None
 
 
+def _ab_switches():
+    """A/B switches of the library that tools set through the environment (the library itself reads none on its hot path)."""
+    g = os.environ.get('MEGASTEP_RAY_GROUPS')
+    if g:
+        _lib.lib().ms_debug_ray_groups(int(g))           # 64-ray groups per render wave: 1, 2, 4 (default: by resolution)
+
+
 def initialize(agent_radius, res, fov, fps):
     """Sets the constants used by :func:`bake`, :func:`physics` and :func:`render` (reference: wrappers.cpp:53).
 
@@ -31,6 +38,7 @@ def initialize(agent_radius, res, fov, fps):
     if res <= 0 or fps <= 0 or agent_radius <= 0:
         raise RuntimeError('agent_radius, res and fps must be positive')
     _config = _lib.MsConfig(float(agent_radius), int(res), float(fov), float(fps))
+    _ab_switches()
 
 
 def _cfg():

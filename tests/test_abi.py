@@ -10,10 +10,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, 'include', 'megastep_hip.h')).read()
-    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(ms_[a-z_]+)\s*\(', text)))
+def declared_symbols(headers=('megastep_hip.h', 'megastep_hip_test.h')):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, 'include', h)).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+        names |= set(re.findall(r'\b(ms_[a-z_]+)\s*\(', text))
+    return sorted(names)
+
+
+def test_the_boundary_header_holds_no_test_hooks():
+    """include/megastep_hip.h is what a maintainer binds: the entry points that replace wrappers.cpp's, nothing else."""
+    assert not [n for n in declared_symbols(('megastep_hip.h',)) if n.startswith(('ms_host_', 'ms_debug_'))]
+    assert {'ms_bake', 'ms_physics', 'ms_render'} <= set(declared_symbols(('megastep_hip.h',)))
 
 
 def test_header_and_loader_agree():

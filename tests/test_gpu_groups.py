@@ -1,0 +1,119 @@
+"""render_kernel's NG - how many 64-ray groups one wave serves (1 up to 64 rays, 2 up to 128, 4 beyond; ms_render picks) -
+changes who does the work, never the result: every setting against the oracle and against the others, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.test_gpu_parity import _custom_world, _world
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(t):
+    return t.detach().cpu().numpy().view(np.int32)
+
+
+@pytest.fixture
+def groups():
+    from megastep_amd import _lib
+    h = _lib.lib()
+    yield h.ms_debug_ray_groups
+    h.ms_debug_ray_groups(0)
+
+
+def _same(a, b, what):
+    for f in ('indices', 'locations', 'dots', 'distances', 'screen'):
+        assert np.array_equal(_bits(getattr(a, f)), _bits(getattr(b, f))), (what, f)
+
+
+@pytest.mark.parametrize('n_agents,res,fov,large', [(4, 64, 130, False), (3, 100, 90, False), (4, 128, 70, False), (2, 256, 130, False),
+                                                    (1, 256, 130, True), (4, 512, 70, False), (2, 600, 160, False), (5, 129, 20, False), (1, 1, 90, False)])
+def test_every_number_of_ray_groups_per_wave_gives_the_oracles_render(groups, n_agents, res, fov, large):
+    from megastep_amd import cuda
+    c, _ = _world(3 if large else 6, n_agents, res, fov, seed=31, large=large)
+    rng = np.random.RandomState(4)
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c)
+    for step in range(2):
+        util.random_velocities(c, rng)
+        cuda.physics(c.scenery, c.agents)
+        ref.pull_agents(c)
+        want = ref.render()
+        frames = {}
+        for g in (0, 1, 2, 4):                                               # 0: as ms_render picks
+            groups(g)
+            frames[g] = cuda.render(c.scenery, c.agents)
+            util.assert_render_matches(c, frames[g], want)
+        for g in (1, 2, 4):
+            _same(frames[g], frames[0], (g, step))
+        # the pooled observations, the crosshair ids, the colourless instantiation and a partial set of planes too
+        if res % 4 == 0 and res >= 8:
+            pooled = {}
+            for g in (1, 2, 4):
+                groups(g)
+                p = cuda.render(c.scenery, c.agents, fields=('indices',), pooled=dict(subsample=4, max_depth=8., centre=True))
+                d = cuda.render(c.scenery, c.agents, fields=('distances', 'dots'), pooled=dict(subsample=4, max_depth=8., rgb=False))
+                pooled[g] = (p.obs_rgb.clone(), p.obs_depth.clone(), p.obs_centre.clone(), p.indices.clone(), d.obs_depth.clone(), d.distances.clone(), d.dots.clone())
+                assert np.array_equal(_bits(d.distances), _bits(frames[0].distances)) and np.array_equal(_bits(d.dots), _bits(frames[0].dots))
+            for g in (2, 4):
+                for x, y in zip(pooled[g], pooled[1]):
+                    assert np.array_equal(_bits(x.float()) if x.dtype != torch.float32 else _bits(x), _bits(y.float()) if y.dtype != torch.float32 else _bits(y)), g
+
+
+def test_stacks_of_coincident_walls_under_every_number_of_groups(groups):
+    """The literal folds - over the wave's list in LDS, ray after ray or lane = ray, and over every line of the env when the
+    list was worked off more than once - with 128 and 256 rays to a wave: views full of walls within the 1e-4 band of each
+    other (kernels.cu:369), in shuffled line order, 512 rays over 40 degrees so that a wave's 256 rays all see the stack; one
+    env with 150 such walls, whose (line, ray) pairs - 64 lines x 256 rays a batch - overflow the pair list several times."""
+    from megastep_amd import cuda
+    rng = np.random.RandomState(5)
+    offsets = np.array([0., 0., 2e-5, 5e-5, 9e-5, 1e-4, 1.1e-4, 2e-4, 3e-4, 1e-3])
+    envs, pos, ang = [], [], []
+    for e in range(24):
+        k = 150 if e == 0 else 70 if e == 1 else rng.randint(2, 9)
+        xs = 4. + rng.choice(offsets, k)*rng.choice([1, 1, -1], k) + rng.choice([0., 0., .5], k)
+        walls = [[[x, 1. + rng.uniform(-.2, .2)], [x, 3. + rng.uniform(-.2, .2)]] for x in xs]
+        if e % 3 == 0:
+            walls += [[[4., 3.], [2., 3.]], [[2., 3.], [2., 1.]], [[2., 1.], [4., 1.]]]
+        if e % 4 == 0:
+            walls += [walls[0], [walls[1][1], walls[1][0]]]
+        envs.append(np.array(walls)[rng.permutation(len(walls))])
+        pos.append([[rng.uniform(2.2, 3.9), rng.uniform(1.5, 2.5)]])
+        ang.append([rng.uniform(-20, 20)])
+    c = _custom_world(envs, 1, 512, 40, pos, ang)
+    ref = util.OracleWorld(c)
+    ref.bake(); ref.pull_baked(c); ref.pull_agents(c)
+    want = ref.render()
+    frames = {}
+    for g in (1, 2, 4):
+        groups(g)
+        frames[g] = cuda.render(c.scenery, c.agents, telemetry=True)
+        util.assert_render_matches(c, frames[g], want)
+        _, folded_rays, lane_parallel_waves = frames[g]._telemetry[:3].tolist()
+        assert folded_rays > 1000 and lane_parallel_waves > 5, (g, folded_rays, lane_parallel_waves)
+    _same(frames[2], frames[1], 2); _same(frames[4], frames[1], 4)
+
+
+def test_first_sight_books_under_every_number_of_groups(groups):
+    from megastep_amd import core, cubicasa, cuda, modules, scene
+    from megastep_amd.demo.envs import explorer
+    np.random.seed(8); torch.manual_seed(8)
+    gs = cubicasa.sample(8, n_unique=16)
+    c = core.Core(scene.scenery(gs, 1, random=np.random.RandomState(0)), res=256, fov=130)
+    modules.RandomSpawns(gs, c)(c.agent_full(True))
+    books = {g: explorer.SeenTexels(c.scenery, 8) for g in (1, 2, 4)}
+    rgb, depth = modules.RGB(c, subsample=4), modules.Depth(c, subsample=4)
+    rng = np.random.RandomState(1)
+    for step in range(5):
+        util.random_velocities(c, rng)
+        cuda.physics(c.scenery, c.agents)
+        obs = {}
+        for g in (1, 2, 4):
+            groups(g)
+            f = modules.render(c, observers=(rgb, depth), fields=(), seen=books[g].books)
+            obs[g] = (f.pooled_rgb.clone(), f.pooled_depth.clone())
+        for g in (2, 4):
+            assert torch.equal(books[g].stamp, books[1].stamp) and torch.equal(books[g].tally, books[1].tally)
+            assert torch.equal(obs[g][0], obs[1][0]) and torch.equal(obs[g][1], obs[1][1])
+    assert books[4].tally.min() > 20

@@ -288,6 +288,11 @@ def test_walls_the_cull_calls_beyond_reach_cannot_stop_the_agent(oracle):
     assert culled > n//4, 'and the cull does cull'
 
 
+def _groups_for(res):
+    """How many 64-ray groups a wave may be given at this resolution (render_kernel's NG; ms_debug_ray_groups)."""
+    return 4 if res > 128 else 2 if res > 64 else 1
+
+
 @pytest.mark.parametrize('res,fov', [(64, 130.), (512, 130.), (200, 60.), (7, 170.), (1, 90.), (128, 165.)])
 def test_no_ray_outside_a_lines_interval_hits_it(oracle, res, fov):
     """render_kernel's pass 1 turns a line into an interval of the wave's rays and intersects it with no others
@@ -324,14 +329,22 @@ def test_no_ray_outside_a_lines_interval_hits_it(oracle, res, fov):
         lib.ms_host_sincospi(float(np.float32(ang[e])/np.float32(180.)), C.byref(s_), C.byref(c_))
         pose = np.array([pos[e, 0], pos[e, 1], s_.value, c_.value], np.float32)
         line = walls[e].reshape(4)
-        for g in range((res + 63)//64):
-            lo, n = C.c_int(), C.c_int()
-            lib.ms_host_ray_interval(pose.ctypes.data_as(f32p), line.ctypes.data_as(f32p), res, fov, radius, g, C.byref(lo), C.byref(n))
-            rays = np.nonzero(idx[e, 64*g:64*g + 64] == M)[0]
-            hits += len(rays)
-            covered += n.value
-            assert n.value == 0 or (lo.value >= 0 and lo.value + n.value <= min(64, res - 64*g)), (e, g, lo.value, n.value)
-            assert len(rays) == 0 or (rays.min() >= lo.value and rays.max() < lo.value + n.value), (e, g, rays, lo.value, n.value, pose, line)
+        # a wave serves 64 rays, or - as ms_render picks above 64 rays - 128 or 256 of them (render_kernel's NG)
+        for groups in sorted({1, _groups_for(res)}):
+            W = 64*groups
+            for g in range((res + W - 1)//W):
+                lo, n = C.c_int(), C.c_int()
+                lib.ms_host_ray_interval_wide(pose.ctypes.data_as(f32p), line.ctypes.data_as(f32p), res, fov, radius, groups, g, C.byref(lo), C.byref(n))
+                if groups == 1:
+                    lo1, n1 = C.c_int(), C.c_int()
+                    lib.ms_host_ray_interval(pose.ctypes.data_as(f32p), line.ctypes.data_as(f32p), res, fov, radius, g, C.byref(lo1), C.byref(n1))
+                    assert (lo1.value, n1.value) == (lo.value, n.value)
+                rays = np.nonzero(idx[e, W*g:W*g + W] == M)[0]
+                assert n.value == 0 or (lo.value >= 0 and lo.value + n.value <= min(W, res - W*g)), (e, g, lo.value, n.value)
+                assert len(rays) == 0 or (rays.min() >= lo.value and rays.max() < lo.value + n.value), (e, groups, g, rays, lo.value, n.value, pose, line)
+                if groups == 1:
+                    hits += len(rays)
+                    covered += n.value
     assert hits > E*res//200, 'plenty of rays land on their wall'
     assert covered < 8*hits + E, 'and the intervals are not much wider than what they must hold'
 
@@ -461,8 +474,9 @@ def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fo
         r = np.arange(res, dtype=f32)
         uy = (f32(res) - f32(2)*r - f32(1))*half_screen/f32(res)           # ray_y, kernels.cu:234-236, in float32 as the kernel
         rx, ry = cs*f32(1) - sn*uy, sn*f32(1) + cs*uy
-        for g in range((res + 63)//64):
-            first, last = 64*g, min(64*g + 63, res - 1)
+        W = 64*_groups_for(res)                                              # the rays of one wave, as ms_render deals them
+        for g in range((res + W - 1)//W):
+            first, last = W*g, min(W*g + W - 1, res - 1)
             allowed = np.zeros((len(walls), last - first + 1), bool)
             for t in np.nonzero(vis)[0]:
                 lo8, hi8 = arcs[t]
@@ -470,8 +484,8 @@ def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fo
                 if not lib.ms_host_wedge_meets(float(rx[last]), float(ry[last]), float(rx[first]), float(ry[first]), lo8, hi8):
                     continue
                 lo, n = C.c_int(), C.c_int()
-                lib.ms_host_ray_interval(pose.ctypes.data_as(f32p), np.ascontiguousarray(walls[t].reshape(4)).ctypes.data_as(f32p),
-                                         res, fov, float(core.AGENT_RADIUS), g, C.byref(lo), C.byref(n))
+                lib.ms_host_ray_interval_wide(pose.ctypes.data_as(f32p), np.ascontiguousarray(walls[t].reshape(4)).ctypes.data_as(f32p),
+                                              res, fov, float(core.AGENT_RADIUS), W//64, g, C.byref(lo), C.byref(n))
                 allowed[t, lo.value:lo.value + n.value] = True
             hit = full[i, first:last + 1]
             for k in np.nonzero(hit >= M)[0]:
