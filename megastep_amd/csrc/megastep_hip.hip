@@ -2320,7 +2320,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
     }
     if constexpr (OBS == 1) {
         if (late->out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
-            bool fresh = false;
+            bool fresh = false, fresh_last = false;
+            const int last_env = sc.n_envs - 1;
             if (is_hit) {
                 const float wf = (float)tex_w;
                 const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
@@ -2331,9 +2332,18 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 // send a ray on to the exchange, where exactly one ray per texel sees the old stamp.
                 if (late->out.seen_stamp[tstart + along] != epoch)
                     fresh = atomicExch(&late->out.seen_stamp[tstart + along], epoch) != epoch;
+            } else if ((r < R) & (sc.n_texels_total > 0)) {
+                // A ray that missed.  The reference gives it texel index -1 (explorer.py:36) and then sets `_seen[-1]`
+                // (:47): the LAST texel of the whole scenery counts as seen from then on, to the credit of the last env,
+                // whichever env's ray it was.  Kept as it is - a drop-in hands out the reference's rewards.
+                const int last = sc.n_texels_total - 1;
+                const int epoch = late->out.seen_epoch[last_env];
+                if (late->out.seen_stamp[last] != epoch)
+                    fresh_last = atomicExch(&late->out.seen_stamp[last], epoch) != epoch;
             }
             const unsigned long long fm = __ballot(fresh);
             if (fm && lane == 0) atomicAdd(&late->out.seen_count[n], __popcll(fm));
+            if (__ballot(fresh_last) && lane == 0) atomicAdd(&late->out.seen_count[last_env], 1);
         }
         if (late->out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
             const int sub = late->out.obs_subsample, W = R/sub;

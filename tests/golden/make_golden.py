@@ -45,7 +45,103 @@ def import_reference():
     mods = {k: importlib.import_module(f'megastep.{k}') for k in ('core', 'ragged', 'scene', 'geometry', 'modules', 'spaces')}
     mods['arrdict'] = importlib.import_module('rebar.arrdict')
     mods['dotdict'] = importlib.import_module('rebar.dotdict')
+    # the demo envs (their package __init__ pulls in the RL stack: a shell instead, the two env modules from their files)
+    pkg.cubicasa = _stub('megastep.cubicasa', sample=None)
+    demo = _stub('megastep.demo'); demo.__path__ = [os.path.join(REF, 'megastep', 'demo')]
+    envs = _stub('megastep.demo.envs'); envs.__path__ = [os.path.join(REF, 'megastep', 'demo', 'envs')]
+    try:
+        import matplotlib
+        matplotlib.use('Agg')
+    except ImportError:
+        _stub('matplotlib'); _stub('matplotlib.pyplot')
+    for k in ('deathmatch', 'explorer'):
+        mods[k] = importlib.import_module(f'megastep.demo.envs.{k}')
     return mods, calls
+
+
+def env_glue(m, g):
+    """The demo envs' own arithmetic (deathmatch.py:54-80 `_observe` + `_shoot`, explorer.py:34-58 `_tex_indices` +
+    `_reward`), run UNBOUND on stand-ins for `self` that hold seeded tensors: what the hot path's outputs are turned
+    into. Inputs and outputs only."""
+    import torch
+    arrdict, dotdict = m['arrdict'], m['dotdict']
+    Deathmatch, Explorer = m['deathmatch'].Deathmatch, m['explorer'].Explorer
+    rng = np.random.RandomState(17)
+
+    # ---- Deathmatch: who is in whose crosshair, hits, wounds, strays
+    for tag, (F, A, res, sub) in {'a': (12, 4, 512, 4), 'b': (9, 3, 64, 2)}.items():
+        M = 8
+        idx = rng.randint(A*M, A*M + 300, (F, A, 1, res))                          # walls ...
+        idx[rng.uniform(size=idx.shape) < .1] = -1                                 # ... misses ...
+        on_agent = rng.uniform(size=idx.shape) < .35
+        idx[on_agent] = rng.randint(0, A*M, on_agent.sum())                        # ... and agents' lines, own included
+        idx = idx.astype(np.int32)
+        pos = rng.uniform(-2, 12, (F, A, 2)).astype(np.float32)
+        bounds = rng.uniform(5, 10, (F, 2)).astype(np.float32)
+        health, damage = rng.uniform(0, 1, (F, A)).astype(np.float32), rng.uniform(0, 1, (F, A)).astype(np.float32)
+
+        class Obs:                                                                  # RGB / Depth / IMU stand-ins
+            subsample = sub
+            def __call__(self, r=None):
+                return torch.zeros(1)
+        fake = type('FakeDeathmatch', (), {})()
+        fake.core = dotdict.dotdict(n_agents=A, device='cpu', scenery=dotdict.dotdict(model=torch.zeros((M, 2, 2))),
+                                    agents=dotdict.dotdict(positions=torch.as_tensor(pos)))
+        fake._rgb = fake._depth = fake._imu = Obs()
+        fake._bounds = torch.as_tensor(bounds)
+        fake._health, fake._damage = torch.as_tensor(health.copy()), torch.as_tensor(damage.copy())
+        fake._shoot = lambda opponents, fake=fake: Deathmatch._shoot(fake, opponents)
+        frame = arrdict.arrdict(indices=torch.as_tensor(idx))
+        m['deathmatch'].modules.render, real = (lambda core: frame), m['deathmatch'].modules.render
+        obs, hits = Deathmatch._observe(fake)
+        m['deathmatch'].modules.render = real
+        g[f'dm_{tag}_shape'] = np.array([F, A, res, sub, M])
+        g[f'dm_{tag}_indices'], g[f'dm_{tag}_positions'], g[f'dm_{tag}_bounds'] = idx, pos, bounds
+        g[f'dm_{tag}_health0'], g[f'dm_{tag}_damage0'] = health, damage
+        g[f'dm_{tag}_matchings'], g[f'dm_{tag}_hits'] = fake.matchings.numpy(), hits.numpy()
+        g[f'dm_{tag}_health'], g[f'dm_{tag}_damage'] = fake._health.numpy(), fake._damage.numpy()
+        g[f'dm_{tag}_obs_health'] = obs.health.numpy()
+
+    # ---- Explorer: the texel under each ray, what has been seen, the reward for seeing it first
+    N, R, sub = 5, 32, 4
+    n_lines = rng.randint(9, 14, N)
+    line_starts = np.cumsum(n_lines) - n_lines
+    tex_w = rng.randint(1, 9, n_lines.sum()).astype(np.int32)
+    tex_s = (np.cumsum(tex_w) - tex_w).astype(np.int32)
+    T = int(tex_w.sum())
+    tex_to_env = np.repeat(np.repeat(np.arange(N), n_lines), tex_w)
+    fake = type('FakeExplorer', (), {})()
+    fake.core = dotdict.dotdict(res=R, scenery=dotdict.dotdict(
+        lines=dotdict.dotdict(starts=torch.as_tensor(line_starts.astype(np.int32))),
+        textures=dotdict.dotdict(widths=torch.as_tensor(tex_w), starts=torch.as_tensor(tex_s))))
+    fake._rgb = dotdict.dotdict(subsample=sub)
+    fake._tex_to_env = torch.as_tensor(tex_to_env).long()
+    fake._seen = torch.full_like(fake._tex_to_env, False)
+    fake._potential = torch.zeros(N)
+    fake._tex_indices = lambda aux, fake=fake: Explorer._tex_indices(fake, aux)
+    frames = 10
+    g['ex_shape'] = np.array([N, R, sub, T, frames])
+    g['ex_line_starts'], g['ex_tex_widths'], g['ex_tex_starts'], g['ex_tex_to_env'] = line_starts, tex_w, tex_s, tex_to_env
+    idxs, locs, resets, tis, rewards, potentials, seens = [], [], [], [], [], [], []
+    for f in range(frames):
+        idx = np.stack([rng.randint(0, n_lines[e], (1, 1, R)) for e in range(N)]).astype(np.int32)
+        if f >= 6:
+            idx[rng.uniform(size=idx.shape) < .08] = -1              # (from frame 6 on some rays miss: explorer.py:36,47 index _seen[-1])
+        loc = rng.uniform(0, 1, idx.shape).astype(np.float32)
+        loc[rng.uniform(size=loc.shape) < .05] = 1.                 # the far end of a line
+        loc[idx < 0] = np.nan
+        reset = rng.uniform(size=N) < (.3 if f in (3, 7) else 0.)
+        # the order of Explorer.step (explorer.py:83-95): _reset forgets, then _observe looks and rewards
+        rt = torch.as_tensor(reset)
+        fake._seen[rt[fake._tex_to_env]] = False
+        fake._potential[rt] = 0
+        aux = arrdict.arrdict(indices=torch.as_tensor(idx), locations=torch.as_tensor(loc))
+        tis.append(Explorer._tex_indices(fake, aux).numpy())
+        reward = Explorer._reward(fake, aux, rt)
+        idxs.append(idx); locs.append(loc); resets.append(reset)
+        rewards.append(reward.numpy().copy()); potentials.append(fake._potential.numpy().copy()); seens.append(fake._seen.numpy().copy())
+    for k, v in dict(indices=idxs, locations=locs, resets=resets, tex_indices=tis, rewards=rewards, potentials=potentials, seen=seens).items():
+        g[f'ex_{k}'] = np.stack(v)
 
 
 def main():
@@ -158,6 +254,8 @@ def main():
     np.random.seed(4)
     sp = modules.RandomSpawns(geoms, fc, n_spawns=10)
     g['spawns_angles'], g['spawns_positions'] = sp._spawns.angles.numpy(), sp._spawns.positions.numpy()
+
+    env_glue(m, g)
 
     np.savez_compressed(OUT, **{k: np.asarray(v) for k, v in g.items()})
     print(f'wrote {OUT}: {len(g)} arrays, {os.path.getsize(OUT)} bytes')

@@ -227,3 +227,90 @@ def test_an_imu_reading_taken_inside_the_physics_launch_goes_stale_with_the_agen
     spawns = modules.RandomSpawns(3*[toys.box()], c)
     spawns(c.agent_full(True))                                           # a respawn with tensor ops: velocities are zero now
     assert c.agents._epoch > 0 and torch.equal(imu(), torch.zeros_like(fresh))
+
+
+# ---- the same, against the REFERENCE's own methods (tests/golden/make_golden.py: deathmatch.py:54-80 `_observe` + `_shoot`,
+# ---- explorer.py:34-58 `_tex_indices` + `_reward`, called unbound on stand-ins holding seeded tensors) ----------------------
+
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_host.npz'))
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_deathmatch_frame_equals_the_references_observe_and_shoot(tag):
+    """`crosshair_matrix` / `_exchange_fire` on the inputs the reference's `_observe` + `_shoot` were run on: the same
+    matchings, hits (the reward), health and damage. Also with the crosshair ids the render kernel writes (the two centre
+    pixels' agents) standing in for the full plane of hit lines."""
+    from megastep_amd import core, scene, toys, modules
+    from megastep_amd.demo.envs import deathmatch
+    g = _golden()
+    F, A, res, sub, M = (int(v) for v in g[f'dm_{tag}_shape'])
+    idx = torch.as_tensor(g[f'dm_{tag}_indices'])
+    np.testing.assert_array_equal(deathmatch.crosshair_matrix(idx, M, A, sub).numpy(), g[f'dm_{tag}_matchings'])
+    for from_centre in (False, True):
+        sc = scene.scenery(F*[toys.box()], A, device='cpu', bake=False)
+        assert sc.model.shape[0] == M
+        env = deathmatch.Deathmatch.__new__(deathmatch.Deathmatch)
+        env.core = core.Core(sc, res=res, fov=70)
+        env._rgb = modules.RGB(env.core, n_agents=1, subsample=sub)
+        env._bounds = torch.as_tensor(g[f'dm_{tag}_bounds'])
+        env._upper = env._bounds[:, None] + deathmatch.CLEARANCE
+        env._everyone = torch.arange(A)
+        env.core.agents.positions[:] = torch.as_tensor(g[f'dm_{tag}_positions'])
+        env._health, env._damage = torch.as_tensor(g[f'dm_{tag}_health0'].copy()), torch.as_tensor(g[f'dm_{tag}_damage0'].copy())
+        if from_centre:
+            # what render_kernel's obs_centre holds: for the two central observation pixels the agent their middle ray landed on
+            W = res//sub
+            mid = idx[:, :, 0, [(W//2 - 1)*sub + sub//2, (W//2)*sub + sub//2]]
+            centre = torch.where((mid >= 0) & (mid < A*M), torch.div(mid, M, rounding_mode='floor'), torch.full_like(mid, -1))
+            reward = env._exchange_fire(centre=centre)
+        else:
+            reward = env._exchange_fire(idx)
+        np.testing.assert_array_equal(env.matchings.numpy(), g[f'dm_{tag}_matchings'])
+        np.testing.assert_array_equal(reward.numpy(), g[f'dm_{tag}_hits'])
+        np.testing.assert_allclose(env._health.numpy(), g[f'dm_{tag}_health'], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(env._damage.numpy(), g[f'dm_{tag}_damage'], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(env._health.unsqueeze(-1).numpy(), g[f'dm_{tag}_obs_health'], rtol=0, atol=1e-6)
+    assert g[f'dm_{tag}_matchings'].any() and (g[f'dm_{tag}_hits'] > 0).any()
+
+
+def test_explorer_books_equal_the_references_tex_indices_and_reward():
+    """Ten frames the reference's `_tex_indices` + `_reward` were run on (respawns in two of them; from the seventh on
+    some rays miss): `texels_hit` names the same texel under every ray, and `SeenTexels` - the render kernel's part
+    played by hand, as it is written in render_kernel: stamp the texel under every ray with its env's epoch, count the
+    ones that did not carry it; a ray that MISSED stamps the scenery's last texel to the credit of the last env, which is
+    what the reference's `_seen[-1] = True` amounts to (explorer.py:36,47) - hands out the same rewards, potentials and
+    seen masks."""
+    from megastep_amd import dotdict
+    from megastep_amd.demo.envs import explorer
+    g = _golden()
+    N, R, sub, T, frames = (int(v) for v in g['ex_shape'])
+    tex_w, tex_s = torch.as_tensor(g['ex_tex_widths']), torch.as_tensor(g['ex_tex_starts'])
+    line_of_texel = torch.repeat_interleave(torch.arange(len(tex_w)), tex_w.long())
+    line_env = torch.as_tensor(np.searchsorted(g['ex_line_starts'], np.arange(len(tex_w)), side='right') - 1)
+    sc = dotdict.dotdict(lines=dotdict.dotdict(starts=torch.as_tensor(g['ex_line_starts'].astype(np.int32)), inverse=line_env.int()),
+                         textures=dotdict.dotdict(widths=tex_w, starts=tex_s, inverse=line_of_texel.int(), vals=torch.zeros((T, 3))))
+    books = explorer.SeenTexels(sc, N)
+    np.testing.assert_array_equal(books.texel_env.numpy(), g['ex_tex_to_env'])
+    assert (g['ex_indices'] < 0).any() and g['ex_resets'].any()
+    for f in range(frames):
+        frame = dotdict.dotdict(indices=torch.as_tensor(g['ex_indices'][f]), locations=torch.as_tensor(g['ex_locations'][f]))
+        texels = explorer.texels_hit(sc, frame)
+        np.testing.assert_array_equal(texels.unsqueeze(2).numpy(), g['ex_tex_indices'][f])
+        reset = torch.as_tensor(g['ex_resets'][f])
+        books.forget(reset)
+        # the kernel's part (render_kernel, `seen_stamp`)
+        env_of_ray = torch.arange(N)[:, None, None, None].expand_as(texels)
+        hit = texels >= 0
+        t = torch.where(hit, texels, torch.full_like(texels, T - 1))
+        e = torch.where(hit, env_of_ray, torch.full_like(env_of_ray, N - 1))
+        fresh = torch.zeros(T, dtype=torch.bool)
+        fresh[t.flatten()] = books.stamp[t.flatten()] != books.epoch[e.flatten()]
+        books.stamp[t.flatten()] = books.epoch[e.flatten()]
+        books.tally += torch.zeros(N, dtype=torch.int32).scatter_add_(0, books.texel_env[fresh], torch.ones(int(fresh.sum()), dtype=torch.int32))
+        reward = (books.gained()/(R//sub)).masked_fill_(reset, 0.)
+        np.testing.assert_allclose(reward.numpy(), g['ex_rewards'][f], rtol=0, atol=1e-6)
+        np.testing.assert_array_equal(books.count.numpy(), g['ex_potentials'][f])
+        np.testing.assert_array_equal(books.mask().numpy(), g['ex_seen'][f].astype(bool))
+    assert g['ex_seen'][-1][-1] and g['ex_potentials'][-1].min() > 10

@@ -266,7 +266,7 @@ def test_first_sight_bookkeeping_in_the_render_kernel():
         cuda.physics(c.scenery, c.agents)
         frame = modules.render(c, fields=('indices', 'locations'), seen=memory.books)
         texels = explorer.texels_hit(c.scenery, frame)
-        seen[texels[texels >= 0]] = True
+        seen[texels.flatten()] = True               # (as the reference does it: a miss, -1, marks the LAST texel - explorer.py:36,47)
         want = torch.zeros(16, device='cuda').scatter_add_(0, memory.texel_env, seen.float())
         assert torch.equal(memory.mask(), seen)
         torch.testing.assert_close(memory.count, want)
@@ -295,3 +295,37 @@ def test_env_steps_replayed_as_a_hip_graph():
     at_rest = env.core.agents.positions.clone()
     env.step(noop)
     assert (env.core.agents.positions - at_rest).norm(dim=-1).max() < 2e-3
+
+
+def test_rays_that_miss_mark_the_last_texel_like_the_reference():
+    """explorer.py:36,47: a missed ray's texel index is -1 and `_seen[-1] = True` marks the scenery's LAST texel, to the
+    credit of the last env. Open worlds - a lone wall per env, most rays see nothing - with and without colour, groups of
+    rays per wave pinned to 1 and 4: the books the kernel keeps equal the reference's formula on the full planes."""
+    from megastep_amd import _lib, cuda, modules
+    from megastep_amd.demo.envs import explorer
+    from tests.test_gpu_parity import _custom_world
+    walls = [np.array([[[3., 1.], [3., 2.]]]), np.array([[[2., 3.], [4., 3.]], [[4., 3.], [4., 3.5]]]), np.array([[[1., 1.], [1., 1.4]]])]
+    c = _custom_world(walls, 1, 256, 130, [[[2., 1.5]], [[3., 2.]], [[2., 2.]]], [[0.], [90.], [0.]])
+    T = c.scenery.textures.vals.shape[0]
+    depth, rgb = modules.Depth(c, subsample=4), modules.RGB(c, subsample=4)
+    for groups, observers in ((1, (rgb, depth)), (4, (depth,)), (0, (rgb, depth))):
+        _lib.lib().ms_debug_ray_groups(groups)
+        try:
+            memory = explorer.SeenTexels(c.scenery, 3)
+            seen = torch.zeros(T, dtype=torch.bool, device='cuda')
+            for step, angles in enumerate(([0., 90., 0.], [30., 60., 180.], [-40., 120., 90.])):
+                c.agents.angles[:] = torch.as_tensor(angles, device='cuda')[:, None]
+                if step == 2:
+                    which = torch.tensor([False, False, True], device='cuda')       # the last env forgets - its last texel too
+                    memory.forget(which)
+                    seen[which[memory.texel_env]] = False
+                full = modules.render(c, fields=('indices', 'locations'))
+                modules.render(c, observers=observers, fields=(), seen=memory.books)
+                texels = explorer.texels_hit(c.scenery, full)
+                assert (texels < 0).any() and (texels >= 0).any()
+                seen[texels.flatten()] = True
+                want = torch.zeros(3, device='cuda').scatter_add_(0, memory.texel_env, seen.float())
+                assert torch.equal(memory.mask(), seen) and bool(seen[-1])
+                torch.testing.assert_close(memory.count, want)
+        finally:
+            _lib.lib().ms_debug_ray_groups(0)
