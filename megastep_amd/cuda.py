@@ -222,6 +222,7 @@ class Scenery:
         self._geom = geom
         self._struct = None
         self._lg = None             # the light grid's tensors; made by _as_struct unless sharding carried one over
+        self._wg_sum = None         # checksum of the static walls the wall grid was built from
         self._wg = None             # the wall grid's tensors (cells, starts, geom, cell, reach, near, pool); made by bake()
         self._dev = None
 
@@ -421,11 +422,31 @@ class Scenery:
         near = torch.cat(nears + [torch.zeros((1, 4), dtype=torch.float32, device=dev)]) if final else None
         return _as_u32(cell_rows), starts, geom, pool, near, cells.to(torch.int32)
 
+    def _wall_checksum(self):
+        """A 64-bit checksum of the static walls' rows as they are now (their bits, position-weighted, summed modulo 2^64):
+        what the wall grid was built from, if taken when it was."""
+        ln = self._lines
+        af = self._n_agents*self._model.shape[0]
+        rows = ln.vals.reshape(-1, 4).view(torch.int32).long()
+        k = torch.arange(rows.shape[0], device=rows.device)
+        static = (k - ln.starts.long()[ln.inverse.long()]) >= af
+        weights = (2*k[:, None]*4 + 2*torch.arange(4, device=rows.device)[None] + 1)*0x9E3779B1     # odd, distinct per word
+        return int((rows*weights*static[:, None]).sum())
+
+    def check_wall_grid(self):
+        """Raises if the static walls are no longer the ones the wall grid was built from (see :func:`bake`): rays and
+        collisions that walk a stale grid silently miss the walls that moved. One reduction over the lines and a sync -
+        switched on for every :func:`render` / :func:`physics` call by ``MEGASTEP_CHECK_GRID=1`` (as the test suite runs)."""
+        if self._wg is not None and self._wg_sum != self._wall_checksum():
+            raise RuntimeError('static walls have been changed since cuda.bake() built the wall grid from them: bake again '
+                               '(or bake(wall_grid=False) to go without a grid)')
+
     def _build_wall_grid(self):
         """Builds the wall grid from the static walls as they are now (called by :func:`bake`): per floorplan a uniform
         grid, per cell the walls a ray from the cell can be decided by and the walls an agent in it can run into - first
         for cells WALL_GRID_COARSE times the size, whose lists are all that the cells proper then look at. Installs ``_wg``."""
         self._wg, self._struct = None, None
+        self._wg_sum = None
         if not self.WALL_GRID:
             return
         ln = self._lines
@@ -448,7 +469,11 @@ class Scenery:
                 hdr, starts, geom, pool, near, _ = level
                 self._wg = (hdr, starts, geom, float(cell), float(self.WALL_GRID_REACH[0]), float(self.WALL_GRID_REACH[1]),
                             float(self.WALL_GRID_NEAR), pool, near)
+                self._wg_sum = self._wall_checksum()
                 self._struct = None
+                if os.environ.get('MEGASTEP_VERBOSE'):
+                    size = sum(t.numel()*t.element_size() for t in (hdr, starts, geom, pool, near))
+                    print(f'megastep_amd: wall grid of {size/2**20:.0f} MiB for {int(usable.sum())} envs at {cell:g} m cells', flush=True)
                 return
 
     def _bake_plan(self):
@@ -546,7 +571,9 @@ def bake(scenery, scratch=True, wall_grid=True):
     allocation, no sharing between envs; same result). Baking also (re)builds the scenery's wall grid - the per-cell
     lists of walls that :func:`render` and :func:`physics` walk instead of every line of the env (include/megastep_hip.h,
     ``MsScenery.wg_*``) - from the walls as they are now: like the baked light it goes stale if static walls are moved
-    afterwards (bake again, or pass ``wall_grid=False`` to go without)."""
+    afterwards (bake again, or pass ``wall_grid=False`` to go without). ``Scenery.check_wall_grid()`` tells (it raises if
+    the walls are not the ones the grid was built from), and ``MEGASTEP_CHECK_GRID=1`` has every :func:`render` and
+    :func:`physics` call ask it first. HIP graphs captured before a re-bake hold pointers into the old grid: capture again."""
     dev = scenery._device()
     # bake uses none of the initialize() constants (kernels.cu:238-293), and scene.scenery() calls it before any Core
     # exists, so the config is optional here
@@ -628,6 +655,7 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
         _require_gpu(*used)
         ex = C.byref(x)
     progress = torch.empty_like(agents.angles) if out is None else out.progress      # `out`: an earlier call's Physics
+    _check_grid(scenery, dev)
     with _on(dev):
         _lib.check(_lib.lib().ms_step_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
                                               mv, ex, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
@@ -637,6 +665,14 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
 
 
 FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
+#: MEGASTEP_CHECK_GRID=1: every render / physics call first makes sure the static walls are still the ones the wall grid
+#: was built from (a reduction over the lines and a host sync per call - for debugging and the test suite, off by default)
+CHECK_GRID = os.environ.get('MEGASTEP_CHECK_GRID', '0') not in ('', '0')
+
+
+def _check_grid(scenery, dev):
+    if CHECK_GRID and scenery._wg is not None and not torch.cuda.is_current_stream_capturing():
+        scenery.check_wall_grid()
 
 
 def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None, seen=None):
@@ -655,7 +691,11 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
     pixels shows, or -1 (all that Deathmatch reads from ``indices``). ``seen=(stamp, epoch, count)`` - int32 tensors
     with one entry per texel, per env and per env - has the kernel do Explorer's first-sight bookkeeping: texels under
     this frame's rays get their env's epoch as stamp, those that did not carry it yet are added to ``count``.
-    ``telemetry=True`` (tests) takes the self-contained path whose scratch counters end up in ``Render._telemetry``."""
+    ``telemetry=True`` (tests) takes the self-contained path whose scratch counters end up in ``Render._telemetry``.
+
+    The contract the wall grid adds: hit indices come from the per-cell lists :func:`bake` made of the
+    static walls, so walls must not be moved in place afterwards without baking again - ``Scenery.check_wall_grid()`` /
+    ``MEGASTEP_CHECK_GRID=1`` detect it (the reference reads ``lines`` afresh every call and has no such rule)."""
     dev = scenery._device()
     _agents_on(agents, dev)
     n, a = agents.angles.shape
@@ -682,6 +722,7 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
         result._key = key
         if seen is not None:
             result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = (t.data_ptr() for t in seen)
+    _check_grid(scenery, dev)
     if telemetry:
         result._telemetry[5] = 0x7e1e7e1e                       # asks the kernels for their pair counters (tools/pair_stats.py)
     with _on(dev):

@@ -2,6 +2,9 @@ import os
 import sys
 import pytest
 
+# every render / physics call of the suite checks that the wall grid it walks was built from the walls as they are
+os.environ.setdefault('MEGASTEP_CHECK_GRID', '1')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

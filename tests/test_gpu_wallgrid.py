@@ -147,3 +147,28 @@ def test_more_agents_than_lanes_take_the_sweep():
     prog_ref, agents_ref = ref.physics()
     util.assert_physics_matches(c, p, prog_ref, agents_ref)
     assert (prog_ref[:, 64:] < 1).any() and (prog_ref < 1).mean() > .5
+
+
+def test_walls_moved_after_bake_are_caught():
+    """The contract the wall grid adds (cuda.render's docstring): its lists are a snapshot of the static walls. A wall
+    nudged in place afterwards would be walked past silently - `Scenery.check_wall_grid()`, which MEGASTEP_CHECK_GRID=1 (as
+    this suite runs) puts in front of every render and physics call, notices; baking again makes the world whole."""
+    from megastep_amd import cuda
+    c, _ = _world(4, 2, 64, 130., seed=3, n_unique=4)
+    assert cuda.CHECK_GRID and c.scenery._wg is not None
+    c.scenery.check_wall_grid()
+    cuda.render(c.scenery, c.agents); cuda.physics(c.scenery, c.agents)          # the agents' own rows change: not the grid's business
+    c.scenery.check_wall_grid()
+    af = c.scenery.n_agents*c.scenery.model.shape[0]
+    row = int(c.scenery.lines.starts[2]) + af + 5
+    c.scenery.lines.vals[row, 1, 0] += .25
+    with pytest.raises(RuntimeError, match='bake again'):
+        c.scenery.check_wall_grid()
+    with pytest.raises(RuntimeError, match='bake again'):
+        cuda.render(c.scenery, c.agents)
+    with pytest.raises(RuntimeError, match='bake again'):
+        cuda.physics(c.scenery, c.agents)
+    cuda.bake(c.scenery)
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c); ref.pull_agents(c)
+    util.assert_render_matches(c, cuda.render(c.scenery, c.agents), ref.render())

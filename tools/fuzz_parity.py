@@ -100,6 +100,11 @@ def one_fused(seed):
     want_stamp = torch.zeros(sc.textures.vals.shape[0], dtype=torch.int32, device='cuda')
     want_stamp[texel[hit]] = 1
     want_count = torch.stack([texel[e][hit[e]].unique().numel()*torch.ones((), dtype=torch.int32, device='cuda') for e in range(n_envs)])
+    if not hit.all():
+        # a ray that missed marks the scenery's LAST texel, to the credit of the last env (explorer.py:36,47: `_seen[-1] = True`)
+        if want_stamp[-1] == 0:
+            want_count[-1] += 1
+        want_stamp[-1] = 1
     fields = tuple(f for f in cuda.FIELDS if rng.rand() < .4)
     books = (torch.zeros_like(want_stamp), torch.ones(n_envs, dtype=torch.int32, device='cuda'), torch.zeros(n_envs, dtype=torch.int32, device='cuda'))
     fused = cuda.render(sc, c.agents, fields=fields, pooled=dict(subsample=sub, max_depth=max_depth, centre=True), seen=books)
