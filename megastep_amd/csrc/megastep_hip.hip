@@ -1058,6 +1058,7 @@ struct RenderConsts {
     float x_clip, c_b;
     Divisor by_f, by_g, by_m;
     int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
+    float inv_res;                 // 1/res where that is a power of two (x/res is then x*inv_res bit for bit), else 0
 };
 __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     unsigned s = 0;
@@ -1287,6 +1288,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                                                     //  code hipcc gathers the kernel-argument loads of to its top)
     const int fan = lb*RW + wave;
     if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
+#ifdef MS_PARK
+    // (-DMS_PARK=<shader clocks>, an experiment: every render wave sits out that long before it starts, as it would at the
+    // barrier of a single-launch step whose first wave does the env's physics - what do parked waves cost a launch?)
+    { const long long t0_ = clock64(); while (clock64() - t0_ < MS_PARK) __builtin_amdgcn_s_sleep(8); }
+#endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int G = (R + NR - 1)/NR, F = A*G;        // g: which run of NR rays of the agent's this wave casts
     const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
@@ -1401,7 +1407,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
 #endif
     };
     auto ray_of = [&](const int r_, float& rx_, float& ry_, float& rlen_, float& near_) {
-        const float uy = (Rf - 2*(float)r_ - 1)*half_screen/Rf;        // ray_y, kernels.cu:234-236
+        // ray_y, kernels.cu:234-236.  (At a power-of-two resolution - 64, 128, 256, 512: every shape anyone runs - the
+        // division by R only moves the exponent, and the product with 1/R is the correctly rounded quotient itself: one
+        // multiply for the dozen instructions of a division.  The numerator is at least half_screen in size: no underflow.)
+        const float num = (Rf - 2*(float)r_ - 1)*half_screen;
+        const float uy = rc.inv_res != 0.f ? num*rc.inv_res : num/Rf;
         rx_ = cs*1.f - sn*uy; ry_ = sn*1.f + cs*uy;
         rlen_ = ray_len(rx_, ry_);
         near_ = agent_radius/rlen_;
@@ -3773,6 +3783,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_g = divisor_of((unsigned)G);
     rc.by_m = divisor_of((unsigned)sc->n_model);
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
+    rc.inv_res = ((R & (R - 1)) == 0 && half_screen > 1e-3f) ? 1.f/(float)R : 0.f;
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);

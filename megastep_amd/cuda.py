@@ -223,6 +223,7 @@ class Scenery:
         self._struct = None
         self._lg = None             # the light grid's tensors; made by _as_struct unless sharding carried one over
         self._wg_sum = None         # checksum of the static walls the wall grid was built from
+        self._wg_weights = None
         self._wg = None             # the wall grid's tensors (cells, starts, geom, cell, reach, near, pool); made by bake()
         self._dev = None
 
@@ -424,14 +425,15 @@ class Scenery:
 
     def _wall_checksum(self):
         """A 64-bit checksum of the static walls' rows as they are now (their bits, position-weighted, summed modulo 2^64):
-        what the wall grid was built from, if taken when it was."""
+        what the wall grid was built from, if taken when it was. (The weights - zero for the agents' rows, which every
+        render rewrites - are made once per scenery: the check itself is one multiply-and-sum over the lines.)"""
         ln = self._lines
-        af = self._n_agents*self._model.shape[0]
-        rows = ln.vals.reshape(-1, 4).view(torch.int32).long()
-        k = torch.arange(rows.shape[0], device=rows.device)
-        static = (k - ln.starts.long()[ln.inverse.long()]) >= af
-        weights = (2*k[:, None]*4 + 2*torch.arange(4, device=rows.device)[None] + 1)*0x9E3779B1     # odd, distinct per word
-        return int((rows*weights*static[:, None]).sum())
+        if self._wg_weights is None:
+            af = self._n_agents*self._model.shape[0]
+            k = torch.arange(ln.vals.shape[0], device=ln.vals.device)
+            static = (k - ln.starts.long()[ln.inverse.long()]) >= af
+            self._wg_weights = ((8*k[:, None] + 2*torch.arange(4, device=k.device)[None] + 1)*0x9E3779B1)*static[:, None]   # odd, distinct per word
+        return int((ln.vals.reshape(-1, 4).view(torch.int32)*self._wg_weights).sum())
 
     def check_wall_grid(self):
         """Raises if the static walls are no longer the ones the wall grid was built from (see :func:`bake`): rays and

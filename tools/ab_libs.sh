@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 libs=$1; shift
 [ $# -eq 0 ] && set -- ""
-lean="--no-cpu-baseline --no-env-fps --steps 60 --warmup 5"
+lean="--no-cpu-baseline --no-env-fps --no-shapes --plan-workers 0 --steps 60 --warmup 5"
 for shape in "$@"; do for lib in $libs; do
   MEGASTEP_HIP_LIB=$PWD/megastep_amd/csrc/$lib.so timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/ab -o r --output-format csv -- python bench.py $lean $shape > gpurun_out/ab.log 2> gpurun_out/ab.err
   python - "$lib" "$shape" <<'PY'
