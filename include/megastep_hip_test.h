@@ -19,6 +19,9 @@ void ms_host_ray_interval_wide(const float* pose, const float* line, int res, fl
 /* Pins the number of 64-ray groups a render wave serves (1, 2, 4; 0 = ms_render picks it from the resolution: 1 up to 64
  * rays, 2 up to 128, 4 beyond).  Process-wide; for A/B runs and tests - every setting produces the same bits. */
 int ms_debug_ray_groups(int groups);
+/* Has ms_render's waves add their (line, ray) pair and pair-window counts to workspace[3] and [4] (two atomics per wave on
+ * one address: milliseconds at 10^5 waves - tools/pair_stats.py only).  Process-wide. */
+int ms_debug_pair_telemetry(int on);
 /* Host instantiation of the light grid's build (ms_bake; accelerates kernels.cu:238-268) for one cell c (row-major in a grid
  * of nx x ny cells of size `cell` from (ox, oy)), over n_walls walls (n_walls x 4 floats: ax, ay, bx, by) and n_lights
  * lights (n_lights x 3: x, y, intensity), HOST memory: words[4] = the lights' 2-bit verdicts as in lg_vals (0 unknown, 1 lit,

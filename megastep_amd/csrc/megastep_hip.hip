@@ -52,6 +52,7 @@ constexpr int WG = 256;             // 4 waves per workgroup
 constexpr int WAVES = WG/WAVE;
 
 thread_local int g_last_hip_error = 0;
+int g_pair_telemetry = 0;              // ms_debug_pair_telemetry
 int g_ray_groups = 0;                  // ms_debug_ray_groups: 0 = ms_render picks render_kernel's NG from the resolution
 
 // -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
@@ -445,9 +446,11 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     }
     if constexpr (MOVE == 1) {
         // modules.py:57-66,106-118: look the action up, turn its velocity delta into the global frame, blend
-        auto moved = [&](const int i, const float ang, float2& v, float& w) {
-            const long long act = min(max(mv.actions[i], 0ll), (long long)mv.n_actions - 1);
-            const float dx = mv.table[3*act], dy = mv.table[3*act + 1], dw = mv.table[3*act + 2];
+        // (the table - seven actions, three floats each - rides in the lanes of one register, asked for up front: looked
+        // up in memory by the action it would be a round trip behind the actions' own)
+        const bool small_table = 3*mv.n_actions <= WAVE;
+        const float tab = mv.table[min(lane, 3*mv.n_actions - 1)];
+        auto moved = [&](const int i, const float ang, float2& v, float& w, const float dx, const float dy, const float dw) {
             const float a_ = 0.017453292519943295f*ang;                 // np.pi/180*angles, in binary32 like torch
             const float s_ = sinf(a_), c_ = cosf(a_);
             const float gx = c_*dx - s_*dy, gy = s_*dx + c_*dy;
@@ -456,11 +459,20 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             ag.angvelocity[i] = w;
             reinterpret_cast<float2*>(ag.velocity)[i] = v;
         };
-        if (lane < A) moved(n*A + lane, my_ang, my_v, my_w);
+        {
+            // (every lane looks an action up - its agent's, or the last agent's again: the lanes exchange table entries, which
+            // only works among lanes that are all there)
+            const long long act = min(max(mv.actions[n*A + min(lane, A - 1)], 0ll), (long long)mv.n_actions - 1);
+            float dx, dy, dw;
+            if (small_table) { dx = __shfl(tab, 3*(int)act, WAVE); dy = __shfl(tab, 3*(int)act + 1, WAVE); dw = __shfl(tab, 3*(int)act + 2, WAVE); }
+            else { dx = mv.table[3*act]; dy = mv.table[3*act + 1]; dw = mv.table[3*act + 2]; }
+            if (lane < A) moved(n*A + lane, my_ang, my_v, my_w, dx, dy, dw);
+        }
         for (int t = lane + WAVE; t < A; t += WAVE) {                   // agents beyond the first 64: through memory
             float2 v = vel2[n*A + t];
             float w = ag.angvelocity[n*A + t];
-            moved(n*A + t, ag.angles[n*A + t], v, w);
+            const long long act = min(max(mv.actions[n*A + t], 0ll), (long long)mv.n_actions - 1);
+            moved(n*A + t, ag.angles[n*A + t], v, w, mv.table[3*act], mv.table[3*act + 1], mv.table[3*act + 2]);
         }
     }
     float4 my_box = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);   // (no agent: a box no finite wall touches)
@@ -985,7 +997,6 @@ __device__ inline float grid_light_intensity(
 constexpr int GROUPS = MS_GROUPS;     // ray groups (sub-wedges) per wave
 constexpr int GSIZE = WAVE/GROUPS;    // rays per group
 constexpr int PAIRS = 128;            // capacity of a wave's (wall, light) pair list in the dynamic-light pass
-constexpr int MS_TELEMETRY_MAGIC = 0x7e1e7e1e;   // in workspace[5]: the caller wants the pair counters (workspace[3], [4])
 
 struct Cand { float pqx, pqy, vx, vy; };     // ray-independent half of intersect(), read as one b128
 
@@ -1059,6 +1070,7 @@ struct RenderConsts {
     Divisor by_f, by_g, by_m;
     int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
     float inv_res;                 // 1/res where that is a power of two (x/res is then x*inv_res bit for bit), else 0
+    int telemetry;                 // ms_debug_pair_telemetry: pair / window counts into workspace[3], [4]
 };
 __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     unsigned s = 0;
@@ -1575,9 +1587,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         // for each such ray the lanes compute that ray's hits on their lines, and the hits are folded in
         // line order into the ray's own state, which lives in the ray's lane.
         const unsigned long long amb = __ballot(ambiguous);
-        // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
+        // pair telemetry for tools/pair_stats.py - only on request (ms_debug_pair_telemetry): two atomics
         // per wave on one address are 1.3 ms at 262144 waves
-        if (out.workspace && lane == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
+        if (out.workspace && lane == 0 && rc.telemetry) {
             atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
         }
         if (amb && out.workspace && lane == 0) {
@@ -1972,9 +1984,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
             const unsigned t_fold0 = (unsigned)clock64();
             PROBE_VAL(15, t_fold0)                                               // (with stamp 3: how long passes 1 and 2 took)
     #endif
-            // pair telemetry for tools/pair_stats.py - only on request (workspace[5] holds MS_TELEMETRY_MAGIC): two atomics
+            // pair telemetry for tools/pair_stats.py - only on request (ms_debug_pair_telemetry): two atomics
             // per wave on one address are 1.3 ms at 262144 waves
-            if (out.workspace && lane == 0 && q == 0 && out.workspace[5] == MS_TELEMETRY_MAGIC) {
+            if (out.workspace && lane == 0 && q == 0 && rc.telemetry) {
                 atomicAdd(&out.workspace[3], n_pairs_total); atomicAdd(&out.workspace[4], n_windows);
             }
             if (amb && out.workspace && lane == 0) {
@@ -2403,15 +2415,17 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
             pd += __shfl_xor(pd, o2, WAVE);
         }
         if (((lane & (sub - 1)) == 0) & (r < R)) {
-            const float fs = (float)sub;
+            // (the mean: a sum over a power-of-two count - the host checks - divided by it, which only moves the exponent;
+            // times the exact reciprocal is the same number for a twelfth of the instructions)
+            const float inv = 1.f/(float)sub;
             const int W = R/sub, px = r/sub;
             const size_t na = (size_t)n*A + a;
             if (COLOUR && late->out.obs_rgb) {
-                late->out.obs_rgb[(na*3 + 0)*W + px] = p0/fs;
-                late->out.obs_rgb[(na*3 + 1)*W + px] = p1/fs;
-                late->out.obs_rgb[(na*3 + 2)*W + px] = p2/fs;
+                late->out.obs_rgb[(na*3 + 0)*W + px] = p0*inv;
+                late->out.obs_rgb[(na*3 + 1)*W + px] = p1*inv;
+                late->out.obs_rgb[(na*3 + 2)*W + px] = p2*inv;
             }
-            if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd/fs;
+            if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd*inv;
         }
     }
     };
@@ -3514,6 +3528,7 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
 #endif
 
 int ms_debug_ray_groups(int groups) { g_ray_groups = groups; return MS_OK; }
+int ms_debug_pair_telemetry(int on) { g_pair_telemetry = on ? 1 : 0; return MS_OK; }
 
 void ms_host_ray_interval_wide(const float* pose, const float* line, int res, float fov, float agent_radius, int groups, int wave,
                                int* first, int* count) {
@@ -3784,6 +3799,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_m = divisor_of((unsigned)sc->n_model);
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
     rc.inv_res = ((R & (R - 1)) == 0 && half_screen > 1e-3f) ? 1.f/(float)R : 0.f;
+    rc.telemetry = g_pair_telemetry;
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);

@@ -725,12 +725,16 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
         if seen is not None:
             result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = (t.data_ptr() for t in seen)
     _check_grid(scenery, dev)
-    if telemetry:
-        result._telemetry[5] = 0x7e1e7e1e                       # asks the kernels for their pair counters (tools/pair_stats.py)
     with _on(dev):
         use_cache = agents._cached and not telemetry
-        _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
-                                        C.byref(result._struct), C.byref(cfg), _stream(dev)))
+        if telemetry:
+            _lib.lib().ms_debug_pair_telemetry(1)               # the kernels' pair counters too (tools/pair_stats.py)
+        try:
+            _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
+                                            C.byref(result._struct), C.byref(cfg), _stream(dev)))
+        finally:
+            if telemetry:
+                _lib.lib().ms_debug_pair_telemetry(0)
     return result
 
 
@@ -775,6 +779,5 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
         obs_centre = obs_centre.view(torch.int32)
     result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None, obs_centre)
     result._struct = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth, ptr(7))
-    result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel; read by the tests
-    result._telemetry.zero_()                                             # (once per allocation: word 5 is the telemetry request)
+    result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel (which zeroes it); read by the tests
     return result
