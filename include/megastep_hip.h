@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 10
+#define MS_ABI_VERSION 11
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -85,6 +85,11 @@ typedef struct MsScenery {
     unsigned*    lg_list;
     unsigned*    lg_pool;
     int          lg_pool_size;
+    /* Optional, with lg_pool: (lg_pool_size, 4) float32 - next to every candidate of lg_pool its wall's row as the shadow
+     * test wants it, (ax, ay, bx - ax, by - ay), written by ms_bake.  ms_render then has a list's walls in the trip that
+     * brings its candidates, instead of one trip later (the rays that need them are the ones a launch waits for).  NULL:
+     * ms_render fetches the rows from `lines` by the candidates' wall numbers. */
+    float*       lg_pool_rows;
     /* Optional sharing of static geometry between envs (NULL = every env on its own; no counterpart in the reference,
      * whose scene.py:75-100 and kernels.cu:270-293 redo identical floorplans env by env): env_geom[n] is the FIRST env
      * whose walls and light POSITIONS are bit-identical to env n's (itself for a representative).  Light intensities

@@ -715,7 +715,7 @@ struct LightScene {                   // what grid_light_intensity reads of an M
     int n_agents, n_model;
     const float* lights_vals; const int* lights_widths; const int* lights_starts;
     const unsigned* lg_vals; const int* lg_starts; const float* lg_geom; float lg_cell;
-    const unsigned* lg_list; const unsigned* lg_pool;
+    const unsigned* lg_list; const unsigned* lg_pool; const float4* lg_pool_rows;
 };
 
 // An env with more lights than the grid holds (it has no cells for such an env) is worked through group after group of
@@ -752,6 +752,9 @@ __device__ inline float grid_light_intensity(
         st.x = inside ? st_.x : 0u; st.y = inside ? st_.y : 0u; st.z = inside ? st_.z : 0u; st.w = inside ? st_.w : 0u;
         lst.x = inside ? lst_.x : 0u; lst.y = inside ? lst_.y : 0u;
     }
+#if defined(MS_LIGHT_ABLATE) && MS_LIGHT_ABLATE == 2
+    return __uint_as_float(st.x ^ lst.y) + Ii;                           // (ablation: the loads and the cell look-up only)
+#endif
     const bool shortcut = !MANY && __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
     // ---- the sum over the lights the grid proves unblocked, in light order.  Rays around one target mostly share
     // a cell, so: one pass per distinct verdict word set, scalar loop over its LIT bits (01 in the 2-bit fields)
@@ -782,11 +785,17 @@ __device__ inline float grid_light_intensity(
             has_unk |= (~(wd[k] | (wd[k] >> 1)) & valid) != 0u;
         }
     }
+#if defined(MS_LIGHT_ABLATE) && MS_LIGHT_ABLATE == 3
+    return part;                                                         // (ablation: up to the sum over the LIT lights)
+#endif
     // saturated: the reference's min(sum, 1) is exactly 1 whatever the unknown lights do (see dynlight_kernel)
     const bool saturated = dynamic & shortcut & (part >= 1.001f);
     const bool need = dynamic & !saturated & has_unk;
     // Everyone else is done: with no light left open the reference's in-order sum over the unblocked lights IS `part`
     if (!__ballot(need)) return MANY ? acc_in : (saturated ? 1.f : ms_min(part, 1.f));
+#if defined(MS_LIGHT_ABLATE) && MS_LIGHT_ABLATE == 4
+    return part;                                                         // (ablation: nothing done about open lights)
+#endif
     // (`telemetry`, for the probe build only: rays with open lights, of them without a list, lists, rounds of pairs, lights)
     telemetry = 0x80000000u | (unsigned)__popcll(__ballot(need)) | ((unsigned)min(ni, 63) << 25);
 
@@ -817,12 +826,17 @@ __device__ inline float grid_light_intensity(
             for (int c0 = 0; c0 < c; c0 += LG_PAIRS) {
                 const int nc = min(LG_PAIRS, c - c0);
                 {
-                    const unsigned e = sc.lg_pool[first + (unsigned)(c0 + min(lane, nc - 1))];
+                    const unsigned at = first + (unsigned)(c0 + min(lane, nc - 1));
+                    const unsigned e = sc.lg_pool[at];
                     const int i = (int)((e >> 24) & 63u);
-                    const float4 w = ln[AF + (int)(e & 0xffffffu)];
+                    // the candidate's wall as (a, b - a): from the pool's own copy, which arrives with the entry - or, for a
+                    // scenery baked without one, from the env's lines, a trip later
+                    float4 w;
+                    if (sc.lg_pool_rows) w = sc.lg_pool_rows[at];            // (uniform)
+                    else { const float4 u = ln[AF + (int)(e & 0xffffffu)]; w = make_float4(u.x, u.y, u.z - u.x, u.w - u.y); }
                     const float ix = __shfl(Ix, i, WAVE), iy = __shfl(Iy, i, WAVE);
                     __builtin_amdgcn_wave_barrier();                     // (the last batch's readers are through)
-                    if (lane < nc) s_pair[lane] = LightPair{w.x, w.y, w.z - w.x, w.w - w.y, ix, iy, i, 0};
+                    if (lane < nc) s_pair[lane] = LightPair{w.x, w.y, w.z, w.w, ix, iy, i, 0};
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2315,14 +2329,19 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
         // ray group is queued for dynlight_kernel, launched right behind this kernel.
         [[maybe_unused]] unsigned light_telemetry = 0x80000000u;
+#ifdef MS_NO_DYNLIGHT
+        if (dynamic) intensity = 1.f;            // (an ablation: what would free dynamic lighting buy? the picture is wrong)
+        if (false) {
+#else
         if (__ballot(dynamic)) {
+#endif
             if (sc.lg_vals) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
                 const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
                                      late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
-                                     late->sc.lg_list, late->sc.lg_pool};         // (fetched now: see RenderArgs)
+                                     late->sc.lg_list, late->sc.lg_pool, reinterpret_cast<const float4*>(late->sc.lg_pool_rows)};   // (fetched now: see RenderArgs)
                 intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
                     reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry);
                 PROBE_VAL(2, light_telemetry)
@@ -3137,7 +3156,10 @@ __global__ __launch_bounds__(WG) void lightlist_kernel(const MsScenery sc) {
                 for (int j = 0; j < staged; j++) {
                     if (!lg_touches(k, v, s_wall[j])) continue;
                     if (pass == 0) count++;
-                    else sc.lg_pool[first + written++] = 0x80000000u | ((unsigned)i << 24) | (unsigned)(w0 + j);
+                    else {
+                        if (sc.lg_pool_rows) reinterpret_cast<float4*>(sc.lg_pool_rows)[first + written] = s_wall[j];
+                        sc.lg_pool[first + written++] = 0x80000000u | ((unsigned)i << 24) | (unsigned)(w0 + j);
+                    }
                 }
             }
         }
@@ -3850,6 +3872,7 @@ int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
         if (!sc->lg_starts || !sc->lg_geom || !(sc->lg_cell > 0.f) || sc->lg_max_cells <= 0 || ((uintptr_t)sc->lg_vals % 16) ||
             ((uintptr_t)sc->lg_geom % 16)) return MS_EINVAL;
         if ((sc->lg_list != nullptr) != (sc->lg_pool != nullptr) || (sc->lg_pool && sc->lg_pool_size < 1) ||
+            (sc->lg_pool_rows && (!sc->lg_pool || ((uintptr_t)sc->lg_pool_rows % 16))) ||
             ((uintptr_t)sc->lg_list % 8)) return MS_EINVAL;
         const dim3 cells((sc->lg_max_cells + WG - 1)/WG, sc->n_envs);
         hipLaunchKernelGGL(lightgrid_kernel, cells, dim3(WG), 0, (hipStream_t)stream, *sc);

@@ -242,7 +242,9 @@ class Scenery:
                                textures=self._textures[s:t], model=self._model, baked=self._baked[s:t])
 
     LIGHT_GRID = True           # False: no light grid (ms_render's two-kernel path; tests)
-    LIGHT_GRID_CELL = .25
+    #: cell size of the light grid, metres. (0.25 -> 0.125 in round 4: half as many rays that land on an agent still have a
+    #: light the grid cannot call - the rays whose waves a launch ends up waiting for; four times the cells.)
+    LIGHT_GRID_CELL = float(os.environ.get('MEGASTEP_LIGHT_GRID_CELL', .125))     # (the environment switch is for A/B runs)
     LIGHT_GRID_POOL = 12        # pool words per cell (4 bytes each) for the candidate lists
 
     def _light_grid(self):
@@ -270,7 +272,8 @@ class Scenery:
         vals = torch.zeros((total + 1, 4), dtype=torch.int32, device=dev)     # (+ a row for rays outside the last env's grid to read)
         lists = torch.zeros((total + 1, 2), dtype=torch.int32, device=dev)
         pool = torch.zeros(min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1), dtype=torch.int32, device=dev)
-        return vals, starts.contiguous(), geom, cell, max(int(cells.max()), 1), lists, pool
+        rows = torch.zeros((pool.shape[0], 4), dtype=torch.float32, device=dev)      # the candidates' walls, next to their entries
+        return vals, starts.contiguous(), geom, cell, max(int(cells.max()), 1), lists, pool, rows
 
     def _wall_bounds(self):
         """(n_envs, 2) lower and upper corner of each env's static walls (finite coordinates only; 0, 0 without any)."""
@@ -295,7 +298,7 @@ class Scenery:
             if self._lg is None:
                 # (one agent per env: no ray ever lands on an agent line, so nothing would consult the grid)
                 wanted = self._n_agents > 1 and self.LIGHT_GRID
-                self._lg = self._light_grid() if wanted else (None, None, None, 0., 0, None, None)
+                self._lg = self._light_grid() if wanted else (None, None, None, 0., 0, None, None, None)
             lg = self._lg
             self._struct = _lib.MsScenery(
                 len(ln), self._n_agents, self._model.shape[0],
@@ -306,6 +309,7 @@ class Scenery:
                 ln.vals.shape[0], li.vals.shape[0], tx.vals.shape[0],
                 *(t.data_ptr() if t is not None else None for t in lg[:3]), lg[3], lg[4],
                 *(t.data_ptr() if t is not None else None for t in lg[5:7]), lg[6].shape[0] if lg[6] is not None else 0,
+                lg[7].data_ptr() if len(lg) > 7 and lg[7] is not None else None,
                 self._geom.data_ptr() if self._geom is not None else None, None, None, 0,
                 *self._wall_grid_fields(), self._model_radius)
         return self._struct

@@ -79,7 +79,8 @@ def _shard_light_grid(lg, start, stop, device, geom=None):
     """Envs [start, stop) of a baked light grid (cuda.Scenery._light_grid's tuple): the cells of the slice's
     representative envs (`geom`, slice-local; None = every env its own) back to back, the candidate lists repacked into
     a pool of their own (the parent's pool is filled in no particular order)."""
-    vals, starts, grid, cell, _, lists, pool = lg
+    vals, starts, grid, cell, _, lists, pool = lg[:7]
+    pool_rows = lg[7] if len(lg) > 7 else None
     dev = vals.device
     n = stop - start
     rep = torch.arange(n, device=dev) if geom is None else geom.long().to(dev)
@@ -96,11 +97,12 @@ def _shard_light_grid(lg, start, stop, device, geom=None):
     cell_of = torch.repeat_interleave(torch.arange(len(count), device=dev), count)
     take = rows[cell_of, 0] + (torch.arange(int(count.sum()), device=dev) - first[cell_of])
     sub_pool = torch.cat([count.sum()[None].to(pool.dtype), pool[take]])
+    sub_rows = None if pool_rows is None else torch.cat([torch.zeros_like(pool_rows[:1]), pool_rows[take]]).to(device).contiguous()
     sub_lists = torch.stack([torch.where(rows[:, 1] != 0, first + 1, torch.zeros_like(first)), rows[:, 1]], 1).to(torch.int32)
     pad = lambda t: torch.cat([t, torch.zeros_like(t[:1])])               # (the row rays outside the last env's grid read)
     return (pad(vals[src]).to(device).contiguous().clone(), new_starts[rep].to(torch.int32).to(device).contiguous(),
             sub_geom.to(device).contiguous().clone(), cell, max(int(cells.max()), 1), pad(sub_lists).to(device).contiguous(),
-            sub_pool.to(device).contiguous())
+            sub_pool.to(device).contiguous(), sub_rows)
 
 
 def max_over_ranks(seconds, device=None):

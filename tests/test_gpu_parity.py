@@ -187,7 +187,7 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
     evaluate the reference's obstructed() test against all walls."""
     c, _ = _world(6, 2, 64, 130, seed=3)
     sc = c.scenery
-    vals, starts, geom, cell, _, lists, pool = (t.cpu().numpy() if torch.is_tensor(t) else t for t in sc._lg)
+    vals, starts, geom, cell, _, lists, pool, pool_rows = (t.cpu().numpy() if torch.is_tensor(t) else t for t in sc._lg)
     pool = pool.astype(np.uint32)
     rng = np.random.RandomState(0)
     n_lit = n_dark = n_open = n_listed = n_cells = 0
@@ -215,6 +215,10 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
                     # an open light: the candidate walls alone must reproduce every point's verdict
                     mine = [int(c & 0xffffff) for c in cands if (int(c) >> 24) & 63 == i]
                     assert all(int(c) >> 31 for c in cands)
+                    # next to every candidate, its wall as (a, b - a): what the renderer reads instead of chasing the number
+                    kept = pool_rows[int(first):int(first) + len(cands)]
+                    w = walls[[int(c & 0xffffff) for c in cands]].reshape(-1, 4)
+                    assert np.array_equal(kept, np.concatenate([w[:, :2], w[:, 2:] - w[:, :2]], 1))
                     few = _obstructed(light[:2].astype(np.float32), pts, walls[mine]).any(1) if mine else np.zeros(len(pts), bool)
                     assert (few == blocked).all(), (e, cidx, i, 'candidate list misses a blocker')
                     n_open += 1
@@ -230,7 +234,7 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
     assert 0 < int(pool[0]) < len(pool)
 
 
-@pytest.mark.parametrize('res,fov,cell', [(64, 130, .25), (256, 70, 1.), (128, 100, .5)])
+@pytest.mark.parametrize('res,fov,cell', [(64, 130, .25), (256, 70, 1.), (128, 100, .5), (64, 130, .125)])
 def test_crowded_rooms_exercise_dynamic_lighting(monkeypatch, res, fov, cell):
     """Four agents packed into one room of each plan, looking at each other: many rays land on agents, under every
     mix of lit / shadowed / partly shadowed lights.  With coarser light-grid cells more lights stay open and the
@@ -238,7 +242,7 @@ def test_crowded_rooms_exercise_dynamic_lighting(monkeypatch, res, fov, cell):
     of (ray, candidate) pairs per batch."""
     from megastep_amd import cuda
     monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_CELL', cell)
-    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_POOL', 12 if cell == .25 else 200)
+    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_POOL', 12 if cell <= .25 else 200)
     c, geometries = _world(24, 4, res, fov, seed=5)
     rng = np.random.RandomState(2)
     pos = np.zeros((24, 4, 2), np.float32)

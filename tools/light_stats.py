@@ -15,7 +15,7 @@ loc = r.locations.reshape(N, A, R)
 AF = A*sc.model.shape[0]
 dyn = (idx >= 0) & (idx < AF)
 print('rays on agents: %.3f of rays; fans with any: %.3f' % (dyn.float().mean().item(), dyn.any(-1).float().mean().item()))
-vals, starts, geom, cell, _, lists, pool = sc._lg
+vals, starts, geom, cell, _, lists, pool = sc._lg[:7]
 print('pool: %d of %d words used; cells %d' % (int(pool[0]), len(pool), len(vals)))
 e, a, k = dyn.nonzero(as_tuple=True)
 lines = sc.lines.vals[sc.lines.starts.long()[e] + idx[e, a, k].long()]

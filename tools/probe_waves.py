@@ -81,6 +81,17 @@ def analyse(name, rec, tick_ns, kernel_us):
             if mm.any():
                 print(f'   waves with {lo_}..{hi_ - 1} folded rays: {int(mm.sum())}: life mean {life[mm].mean():.2f} p90 {np.quantile(life[mm], .9):.2f} max {life[mm].max():.2f} us; '
                       f'passes 1 + 2 mean {pass12[mm].mean():.2f} max {pass12[mm].max():.2f}; resolution + fold mean {fold[mm].mean():.2f} max {fold[mm].max():.2f} us')
+    if name == 'render' and NAMES['render'][5]:
+        # waves with rays to light: words 14, 12, 13, 11 = clocks at the lighting's start, when the lights' rows and the cell's
+        # verdicts are in, after the sum over the LIT lights, at its end (they overwrite the pair statistics of those waves)
+        v = rec[:, 2]
+        dyn, need = v != 0, (v != 0) & (v != 0x80000000)
+        raw = rec[:, :16].astype(np.int64)
+        d = lambda a, b: ((raw[:, a] - raw[:, b]).astype(np.int32))*tick_ns/1e3
+        for label, m in (('settled by the grid', dyn & ~need), ('with open lights', need)):
+            if m.any():
+                print(f'   lighting, waves {label} ({int(m.sum())}): raycast done -> start {d(14, 4)[m].mean():.2f}, -> rows in {d(12, 14)[m].mean():.2f}, '
+                      f'-> LIT sum done {d(13, 12)[m].mean():.2f}, -> end {d(11, 13)[m].mean():.2f}, -> texel row used {d(5, 11)[m].mean():.2f} us; life {life[m].mean():.2f} (others {life[~dyn].mean():.2f})')
     slowest = np.argsort(-life)[:len(life)//100 + 1]
     print(f'   the slowest 1 %: starts at {np.median(start[slowest]):.1f} us (median), ' + ', '.join(
         f'{NAMES[name][a]}->{NAMES[name][b]} {np.mean(t[slowest, b] - t[slowest, a]):.2f}' for a, b in zip(used[:-1], used[1:])))
