@@ -724,7 +724,12 @@ struct LightScene {                   // what grid_light_intensity reads of an M
 __device__ inline float grid_light_intensity(
         const LightScene sc, const MsAgents& ag, const int n, const int lane, const bool dynamic, const int nearest_idx,
         const float cx_l, const float cy_l, const int L, const float4* __restrict__ ln,
-        LightPair* s_pair, unsigned* s_shadow, unsigned& telemetry) {
+        LightPair* s_pair, unsigned* s_shadow, unsigned& telemetry, [[maybe_unused]] unsigned* clk = nullptr) {
+#if MS_PROBE
+#define LG_CLK(k, v) { asm volatile("" :: "v"(v)); clk[k] = (unsigned)clock64(); }
+#else
+#define LG_CLK(k, v)
+#endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
     const int n_lights = sc.lights_widths[n];
     const bool MANY = n_lights > WAVE;                                   // (uniform)
@@ -752,6 +757,7 @@ __device__ inline float grid_light_intensity(
         st.x = inside ? st_.x : 0u; st.y = inside ? st_.y : 0u; st.z = inside ? st_.z : 0u; st.w = inside ? st_.w : 0u;
         lst.x = inside ? lst_.x : 0u; lst.y = inside ? lst_.y : 0u;
     }
+    LG_CLK(0, st.x + __float_as_uint(Ii))                                // the lights' rows and the cell's verdicts have arrived
 #if defined(MS_LIGHT_ABLATE) && MS_LIGHT_ABLATE == 2
     return __uint_as_float(st.x ^ lst.y) + Ii;                           // (ablation: the loads and the cell look-up only)
 #endif
@@ -785,6 +791,7 @@ __device__ inline float grid_light_intensity(
             has_unk |= (~(wd[k] | (wd[k] >> 1)) & valid) != 0u;
         }
     }
+    LG_CLK(1, part)                                                      // ... the sum over the LIT lights is done
 #if defined(MS_LIGHT_ABLATE) && MS_LIGHT_ABLATE == 3
     return part;                                                         // (ablation: up to the sum over the LIT lights)
 #endif
@@ -2017,7 +2024,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 // (the sweep over all the env's lines from memory below made such a wave the one its launch waited for:
                 // 10-26 us against a mean life of 6-9; profiles/r04_probe_*.txt).
                 const int rounds = (list_n + WAVE - 1)/WAVE;
-                if (10*(int)__popcll(amb)*rounds <= list_n + 40) {
+                // (which of the two: lane = line costs ~55 instructions per ray and round of 64 lines, lane = ray ~25 per line -
+                // measured in the probe build; a wave with seven such rays and a hundred lines once took the second: 9 us)
+                if (2*(int)__popcll(amb)*rounds <= list_n + 16) {
                     // a few such rays (nearly always one or two): lane = line of the list, 64 at a time, read from LDS once; per
                     // ray every line's hit at once, then the ray's hits - a handful - folded in line order through a scalar
                     // loop into the ray's state, which lives in the ray's own lane
@@ -2342,8 +2351,16 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
                                      late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
                                      late->sc.lg_list, late->sc.lg_pool, reinterpret_cast<const float4*>(late->sc.lg_pool_rows)};   // (fetched now: see RenderArgs)
+#if MS_PROBE
+                unsigned lclk[2] = {0u, 0u};                     // (probe build: the lighting's own stamps - they take the places of the pair statistics)
+                PROBE_VAL(14, (unsigned)clock64())
+                intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
+                    reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry, lclk);
+                PROBE_VAL(12, lclk[0]) PROBE_VAL(13, lclk[1]) PROBE_VAL(11, (unsigned)clock64())
+#else
                 intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
                     reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry);
+#endif
                 PROBE_VAL(2, light_telemetry)
             } else if (out.workspace) {
                 if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
