@@ -163,9 +163,15 @@ def test_light_grid_shard_repacks_candidate_lists():
         wanted[c] = sorted(entries.tolist())
     pool[0] = len(pool) - 1
     to_i32 = lambda a: torch.tensor((np.asarray(a, np.int64) & 0xffffffff).astype(np.uint32).view(np.int32))
-    lg = (vals, starts, geom, .25, int(cells.max()), to_i32(lists), to_i32(pool))
+    # (next to every candidate its wall's row: here a row that names its entry, so that the repacking can be followed)
+    rows = torch.tensor(np.asarray(pool, np.float64)[:, None]*np.array([1., 2., 3., 4.]) % 1000, dtype=torch.float32)
+    lg = (vals, starts, geom, .25, int(cells.max()), to_i32(lists), to_i32(pool), rows)
     for start, stop in [(0, 2), (1, 4), (2, 3), (0, 4)]:
-        v, s, g, cell, mx, l, p = sharding._shard_light_grid(lg, start, stop, 'cpu')
+        v, s, g, cell, mx, l, p, pr = sharding._shard_light_grid(lg, start, stop, 'cpu')
+        assert pr.shape == (len(p), 4)
+        want_rows = torch.tensor(((p.long() & 0xffffffff).double().numpy()[:, None]*np.array([1., 2., 3., 4.])) % 1000, dtype=torch.float32)
+        assert torch.equal(pr[1:], want_rows[1:])                          # every entry still has its own row beside it
+        assert sharding._shard_light_grid(lg[:7], start, stop, 'cpu')[7] is None     # (a grid baked without rows shards without them)
         c0, c1 = int(starts[start]), int(starts[stop]) if stop < 4 else total
         assert torch.equal(v[:-1], vals[c0:c1]) and not v[-1].any() and torch.equal(g, geom[start:stop]) and cell == .25    # (+ the padding row)
         assert len(l) == len(v)
@@ -254,7 +260,7 @@ def test_shards_of_sceneries_with_shared_floorplans():
     vals = torch.arange(14*4, dtype=torch.int32).view(14, 4)
     lists = torch.zeros((14, 2), dtype=torch.int32)
     pool_ = torch.zeros(1, dtype=torch.int32)
-    v, s, g, cell, mx, l, p = sharding._shard_light_grid((vals, starts, grid, .25, 6, lists, pool_), 4, 7, 'cpu', shard.geom)
+    v, s, g, cell, mx, l, p, _ = sharding._shard_light_grid((vals, starts, grid, .25, 6, lists, pool_), 4, 7, 'cpu', shard.geom)
     assert s.tolist() == [0, 0, 4] and torch.equal(v[:-1], torch.cat([vals[6:10], vals[0:6]])) and torch.equal(g, grid[4:7])     # (v ends in a padding row)
 
 
