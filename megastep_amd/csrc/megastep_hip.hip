@@ -1917,6 +1917,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         };
         unsigned e_next[2] = {raw(0), raw(WAVE)};
         int raw_pos = 0, q_len = 0, al_left = AL;                            // (uniform)
+        // (without a list the queue's entries are simply the env's walls in their order: what stands at its front is
+        // counted here rather than read back from its 16-bit entries - an env may have more than 65536 walls, a list not)
+        int q_first = 0;
         for (;;) {
             // fill the queue from the list
             while ((raw_pos < n_raw) & (q_len <= Q_CAP - WAVE)) {
@@ -1948,7 +1951,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
             for (int kk = 0; kk < AHEAD; kk++) {
                 const int i = kk*WAVE + lane;
                 const int ai = al0 + i;                                      // as an agent-line item
-                const int qe = (int)s_queue_w[min(max(i - n_al, 0), Q_CAP - 1)];
+                const int q_at = min(max(i - n_al, 0), Q_CAP - 1);
+                const int qe = listed ? (int)s_queue_w[q_at] : q_first + q_at;
                 l_it[kk] = (i < n_al) ? ai + (ai >= own0 ? own : 0) : AF + qe;
                 w_it[kk] = rows.load(l_it[kk]*16, 0);
             }
@@ -1971,6 +1975,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 for (int j = 0; j < Q_CAP/WAVE; j++) if (j*WAVE + lane < q_len - q_used) s_queue_w[j*WAVE + lane] = keep_[j];
             }
             q_len -= q_used;
+            q_first += q_used;
             if ((raw_pos >= n_raw) & (q_len == 0) & (al_left == 0)) break;
         }
         if (n_pairs) drain();

@@ -14,7 +14,11 @@ class GraphedStep:
     """Wraps an env (``reset()``, ``step(decision)`` with ``decision.actions`` an integer tensor): the first ``step`` call
     warms the step up on a side stream, captures it, and from then on every call copies the actions into the captured
     input and replays the graph. The world it returns is the same arrdict of tensors every time, overwritten in place:
-    consume (or clone) it before the next step. Everything else is passed through to the env."""
+    consume (or clone) it before the next step. Everything else is passed through to the env.
+
+    The warm-up is real: the first ``step`` call advances the env ``warmup`` steps under its actions (their rewards and
+    resets are not returned) before the captured step runs for the first time - graph capture needs the step's
+    allocations to have happened once. Call it before the steps that count, or pass ``warmup=1``."""
 
     def __init__(self, env, warmup=3):
         self.env = env
@@ -32,17 +36,18 @@ class GraphedStep:
     @torch.no_grad()
     def step(self, decision):
         if self._graph is None:
-            self._actions = decision.actions.clone()
-            static = arrdict.arrdict(actions=self._actions)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                                  # (graph capture wants its warm-up elsewhere)
-                for _ in range(self._warmup):
-                    self.env.step(static)
-            torch.cuda.current_stream().wait_stream(side)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._world = self.env.step(static)
+            with torch.cuda.device(self.env.device):                      # (streams and graphs are made on the current device)
+                self._actions = decision.actions.clone()
+                static = arrdict.arrdict(actions=self._actions)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                              # (graph capture wants its warm-up elsewhere)
+                    for _ in range(max(self._warmup, 1)):
+                        self.env.step(static)
+                torch.cuda.current_stream().wait_stream(side)
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._world = self.env.step(static)
         self._actions.copy_(decision.actions)
         self._graph.replay()
         return self._world

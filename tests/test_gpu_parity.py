@@ -552,3 +552,29 @@ def test_steps_replayed_as_a_hip_graph_equal_the_same_steps_launched_one_by_one(
         got = (c.agents.angles, c.agents.positions, vel, state['p'].progress, state['r'].indices, state['r'].screen, c.scenery.lines.vals)
         for a, b in zip(got, want):
             assert torch.equal(torch.nan_to_num(a.float(), nan=-7.), torch.nan_to_num(b.float(), nan=-7.))
+
+
+def test_more_than_65536_walls_in_an_env():
+    """An env too large for the wall grid's 16-bit wall numbers gets no grid cells and meets its walls one after the other -
+    all of them: the 70 000th like the 7th (the queue the renderer feeds its batches from once kept 16-bit entries for this
+    path too, and walls past the 65 536th came back as their numbers modulo 65 536)."""
+    from megastep_amd import cuda
+    rng = np.random.RandomState(0)
+    n = 70_000
+    far = rng.uniform(40, 90, (n, 1, 2)) + np.concatenate([np.zeros((n, 1, 2)), rng.uniform(-.05, .05, (n, 1, 2))], 1)   # specks, far away
+    room = np.array([[[1., 1.], [5., 1.]], [[5., 1.], [5., 5.]], [[5., 5.], [1., 5.]], [[1., 5.], [1., 1.]]])
+    walls = np.concatenate([far[:66_000], room[:2], far[66_000:], room[2:]])
+    c = _custom_world([walls, room], 1, 64, 130, [[[3., 3.]], [[2., 2.]]], [[20.], [100.]])
+    assert c.scenery.lines.widths.tolist() == [n + 4 + 8, 4 + 8]
+    ref = util.OracleWorld(c)
+    ref.pull_baked(c)
+    for angle in (20., 200.):
+        c.agents.angles[0] = angle
+        ref.pull_agents(c)
+        r = cuda.render(c.scenery, c.agents)
+        util.assert_render_matches(c, r, ref.render())
+        assert int(r.indices[0].max()) > 66_000
+    util.random_velocities(c, rng, speed=30.)
+    ref.pull_agents(c)
+    p = cuda.physics(c.scenery, c.agents)
+    util.assert_physics_matches(c, p, *ref.physics())
