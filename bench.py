@@ -192,6 +192,13 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     out['explorer'] = {'fps': eager, 'fps_hip_graph': graphed,
                        'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU'}
     torch.cuda.empty_cache()
+    # BASELINE config 2 says "depth-only": the same env without the RGB observation - the renderer's colourless instantiation
+    env = Explorer(n_core_envs, device=device, geometries=geometries, depth_only=True)
+    eager, graphed = rate(env, n_core_envs)
+    del env
+    out['explorer_depth_only'] = {'fps': eager, 'fps_hip_graph': graphed,
+                                  'env': f'Explorer({n_core_envs}, depth_only=True): 1 agent, 256 rays -> 64 px D+IMU'}
+    torch.cuda.empty_cache()
     env = Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries)
     log('Deathmatch built')
     eager, graphed = rate(env, 4*n_core_envs)
@@ -276,7 +283,9 @@ def cpu_baselines(core, budget_s=8.):
     log(f'pure-PyTorch CPU step: {steps} steps of {n} envs in {dt:.1f}s')
     out['cpu_baseline'] = {
         'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': threads, 'kind': 'port', 'implementation': 'pure PyTorch (CPU tensors)',
-        'host_cores': cores, 'usable_cores': usable,
+        'host_cores': cores, 'usable_cores': usable, 'cores_used': threads,
+        'why_not_all_cores': 'the step is thousands of small tensor ops: past a few dozen intra-op threads each op spends its time '
+                             'waking threads up (256 threads turned one step into minutes); cpu_baseline_c uses every core',
         'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/torch_step.py, torch.set_num_threads({threads})'}
 
     n, scene, agents = _oracle_sample(core, 4096)
