@@ -326,7 +326,7 @@ class Scenery:
     #: the near plane its visibility lists allow for; how much memory it may take - beyond that the cells are doubled in
     #: size, twice at most, then it is left out
     WALL_GRID = os.environ.get('MEGASTEP_WALL_GRID', '1') != '0'       # (the environment switch is for A/B runs)
-    WALL_GRID_CELL = .25
+    WALL_GRID_CELL = float(os.environ.get('MEGASTEP_WALL_GRID_CELL', .25))        # (the environment switch is for A/B runs)
     WALL_GRID_REACH = (.7, 1.3)
     WALL_GRID_NEAR = .12
     WALL_GRID_BYTES = 8 << 30
