@@ -716,6 +716,7 @@ struct LightScene {                   // what grid_light_intensity reads of an M
     const float* lights_vals; const int* lights_widths; const int* lights_starts;
     const unsigned* lg_vals; const int* lg_starts; const float* lg_geom; float lg_cell;
     const unsigned* lg_list; const unsigned* lg_pool; const float4* lg_pool_rows;
+    unsigned by_m_mul, by_m_sh1, by_m_sh2;       // exact division by n_model (RenderConsts.by_m), worked out by the host
 };
 
 // An env with more lights than the grid holds (it has no cells for such an env) is worked through group after group of
@@ -740,7 +741,13 @@ __device__ inline float grid_light_intensity(
     const float4 geom = reinterpret_cast<const float4*>(sc.lg_geom)[n];
     float Ix = 0.f, Iy = 0.f, Ii = 0.f;          // lane i holds light i
     if (lane < ni) { Ix = lights[3*lane]; Iy = lights[3*lane + 1]; Ii = lights[3*lane + 2]; }
-    const int my_target = dynamic ? nearest_idx / sc.n_model : -1;
+    // (the agent a ray landed on: line / lines per agent, by the host's multiply-high constants - as a division by a kernel
+    // argument it is two dozen instructions and three registers of reciprocal that hipcc then holds across every loop)
+    int my_target = -1;
+    if (dynamic) {
+        const unsigned t_ = __umulhi(sc.by_m_mul, (unsigned)nearest_idx);
+        my_target = (int)((t_ + (((unsigned)nearest_idx - t_) >> sc.by_m_sh1)) >> sc.by_m_sh2);
+    }
 
     // ---- the grid's verdicts for this ray's cell (all zero = all unknown outside the grid)
     uint4 st = make_uint4(0u, 0u, 0u, 0u);
@@ -1286,7 +1293,7 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #ifndef MS_VCAP
 #define MS_VCAP 128
 #endif
-__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1 ? MS_WAVES : NG == 2 ? 4 : 3, NG == 1 ? MS_WAVES : NG == 2 ? 5 : 3))) void render_kernel(
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVES, MS_WAVES))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
@@ -1301,14 +1308,22 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
     PROBE_INIT
     static_assert(NG == 1 || (IMPL == 2 && RW == 1 && (NG == 2 || NG == 4)), "several ray groups per wave: the product raycast, one wave per workgroup");
     constexpr int NR = WAVE*NG;                  // rays per wave
-    constexpr int LDS_PER_WAVE = (IMPL == 2 ? 24*MS_VCAP + 2304*NG + 768 : 4864);
+    // (NG > 1: the list is shared by the wave's groups and must outlive their epilogues, whose scratch - the lighting's pair
+    // list and shadow words, the RGB staging - therefore sits in the per-group region behind it, O_EPI, not on top of it)
+    constexpr int O_EPI = (IMPL == 2 && NG > 1) ? 24*MS_VCAP + 256 : 0;
+    constexpr int LDS_PER_WAVE = IMPL != 2 ? 4864 : NG == 1 ? 24*MS_VCAP + 3072 : O_EPI + 3584;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
     // would otherwise keep env, agent, line count and every address derived from them in vector registers)
-    const int tid = threadIdx.x, wave = RW == 1 ? 0 : tid >> 6, lane = RW == 1 ? tid : tid & 63;
+    const int tid = threadIdx.x, wave = RW == 1 ? 0 : tid >> 6;
+    int lane = RW == 1 ? tid : tid & 63;         // (not const: see LANE_AFRESH)
+    // In a loop over a wave's ray groups hipcc hoists everything that depends on the lane alone - a dozen LDS addresses,
+    // masks, offsets - out of the loop and holds it in registers through all of it: 16-28 spilled to scratch memory at the
+    // 80 the kernel is held to.  Made opaque at the top of every iteration, the lane is worked with afresh each time.
+#define LANE_AFRESH asm volatile("" : "+v"(lane))
     Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);
-    float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][IMPL == 2 ? 0 : 4096]);   // (IMPL 2: the raycast is over by then)
+    float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][IMPL == 2 ? O_EPI : 4096]);   // (IMPL 2: the raycast is over by then)
 
     // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
     // logical blocks so the fans of one env (and its lines) stay behind one L2.
@@ -1348,6 +1363,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
     // drawn lines fall back to drawn_line()).  sin/cos run in binary64, so they are worth sharing.
     float ag_s = 0.f, ag_c = 0.f;
     float2 ag_p = make_float2(0.f, 0.f);
+    // (a lambda: a wave of several ray groups reads the agents afresh for every group rather than hold them in registers
+    // through a group's epilogue - hot lines, and four registers the lighting cannot spare)
+    auto load_agents = [&]() {
+    ag_s = 0.f; ag_c = 0.f; ag_p = make_float2(0.f, 0.f);
     const int lane_a = n*A + min(lane, A - 1);   // (lanes past the last agent re-read it: loads without a guard overlap)
     if (ag.headings) {
         const float4 h = reinterpret_cast<const float4*>(ag.headings)[lane_a];
@@ -1367,6 +1386,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         }
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
+    };
+    load_agents();
     constexpr int AHEAD = MS_AHEAD;              // chunks of lines in flight (IMPL 2)
 
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where
@@ -1419,6 +1440,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
             const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[cell_id];
             wg_first = inside ? hdr.x : 0u;
             wg_count = inside ? (int)hdr.y : -1;
+            if constexpr (NG > 1) {
+                // (said to be the same in every lane - it is: one header, read by all - so that what is counted in the loops
+                // over the list stays in scalar registers in the loops over the groups as well)
+                wg_first = (unsigned)__builtin_amdgcn_readfirstlane((int)wg_first);
+                wg_count = __builtin_amdgcn_readfirstlane(wg_count);
+            }
         }
     }
     // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
@@ -1460,6 +1487,210 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
     const float g0 = (float)r0;
     [[maybe_unused]] const int my_group = lane/GSIZE;
 
+    // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
+    // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
+    // asked for here, for every lane, from a row that exists (the env's first for a miss): unconditional loads are
+    // the ones hipcc lets overlap.
+    // (Defined here, in front of the raycast, so that a wave of several ray groups can run them group by group from inside
+    // it; they are CALLED at the wave's end, and it is there that they read their kernel arguments: see RenderArgs.)
+    constexpr bool COLOUR = SHADE != 0;
+    static_assert(COLOUR || OBS == 1, "without colour `screen` is NULL: the OBS instantiation");
+    // what depends on the winner's number alone: its row, its texel count and first texel
+    // (plain scalars in and out: as a struct by value this cost every wave 32 bytes of scratch memory)
+    auto winner_of = [&](const int nearest_idx, float4& hw_mem, int& tex_w, int& tstart) {
+        const LateArgs late = late_args();       // (see RenderArgs: read where it is used, at the wave's end)
+        // (uniform; constant-folded away in the colour instantiations)
+        const bool want_texel_row = COLOUR || (OBS && late->out.seen_stamp != nullptr);
+        const bool want_line = want_texel_row || late->out.locations != nullptr || late->out.dots != nullptr;
+        const int row = min(max(nearest_idx, 0), max(L - 1, 0));
+        hw_mem = make_float4(0.f, 0.f, 0.f, 0.f); tex_w = 1; tstart = 0;
+        if (want_line) hw_mem = rows.row(row);
+        if (want_texel_row) {
+            const int* const l_tex_widths = late->sc.textures_widths;
+            const int* const l_tex_starts = late->sc.textures_starts;
+            tex_w = l_tex_widths[base + row]; tstart = l_tex_starts[base + row];
+        }
+    };
+    // ... and the rest of a group's rays' lives: q = the group, r = this lane's ray of it, (rx, ry, rlen) = its direction
+    auto finish_group = [&](const int q, const int r, const float rx, const float ry, const float rlen,
+                            const float nearest_s, const int nearest_idx, const float4 hw_mem, const int tex_w, const int tstart) {
+    const LateArgs late = late_args();       // (see RenderArgs: read where it is used, at the wave's end)
+    // (uniform; constant-folded away in the colour instantiations)
+    const bool want_texel_row = COLOUR || (OBS && late->out.seen_stamp != nullptr);
+    const bool want_line = want_texel_row || late->out.locations != nullptr || late->out.dots != nullptr;
+    float loc = NAN, dt = NAN;
+    float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (want_line) {
+        float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (__ballot((nearest_idx >= 0) & (nearest_idx < AF))) aw = agent_line(nearest_idx);
+        if (nearest_idx >= 0) {
+            hw = (nearest_idx < AF) ? aw : hw_mem;
+            const float vx = hw.z - hw.x, vy = hw.w - hw.y;
+            const float d = rx*vy - ry*vx;
+            const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
+            loc = (pqx*ry - pqy*rx)/d;
+            const float dtop = rx*vx + ry*vy;
+            const float dbot = rlen*sqrtf(vx*vx + vy*vy);
+            dt = dtop/(dbot + 1.e-6f);
+        }
+    }
+    const size_t o = ((size_t)n*A + a)*R + r;
+    const float dist = nearest_s*rlen;
+    {
+        int* const o_indices = late->out.indices;
+        float* const o_locations = late->out.locations;
+        float* const o_dots = late->out.dots;
+        float* const o_distances = late->out.distances;
+        if (r < R) {
+            if (!OBS || o_indices) MS_OUT_STORE(nearest_idx, &o_indices[o]);
+            if (!OBS || o_locations) MS_OUT_STORE(loc, &o_locations[o]);
+            if (!OBS || o_dots) MS_OUT_STORE(dt, &o_dots[o]);
+            if (!OBS || o_distances) MS_OUT_STORE(dist, &o_distances[o]);
+        }
+    }
+
+    // ---- pass 3: shade (kernels.cu:407-450)
+    const bool is_hit = (nearest_idx >= 0) & (r < R);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    [[maybe_unused]] Filt f = Filt{0, 0, 0.f, 0.f};
+    [[maybe_unused]] float intensity = 0.f;
+    [[maybe_unused]] float tl0 = 0.f, tl1 = 0.f, tl2 = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
+    if constexpr (COLOUR) {
+        const float* const l_tex_vals = late->sc.textures_vals;
+        const float* const l_baked = late->sc.baked_vals;
+        const bool dynamic = is_hit & (nearest_idx < AF);
+        // Rays that landed on an agent (dynamic) are lit from the lights (kernels.cu:432-436).  With a light grid
+        // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
+        // ray group is queued for dynlight_kernel, launched right behind this kernel.
+        [[maybe_unused]] unsigned light_telemetry = 0x80000000u;
+#ifdef MS_NO_DYNLIGHT
+        if (dynamic) intensity = 1.f;            // (an ablation: what would free dynamic lighting buy? the picture is wrong)
+        if (false) {
+#else
+        if (__ballot(dynamic)) {
+#endif
+            if (sc.lg_vals) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
+                const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
+                                     late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
+                                     late->sc.lg_list, late->sc.lg_pool, reinterpret_cast<const float4*>(late->sc.lg_pool_rows),
+                                     rc.by_m.mul, rc.by_m.sh1, rc.by_m.sh2};   // (fetched now: see RenderArgs)
+#if MS_PROBE
+                unsigned lclk[2] = {0u, 0u};                     // (probe build: the lighting's own stamps - they take the places of the pair statistics)
+                PROBE_VAL(14, (unsigned)clock64())
+                intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
+                    reinterpret_cast<LightPair*>(&s_raw[wave][O_EPI]), reinterpret_cast<unsigned*>(&s_raw[wave][O_EPI + 2048]), light_telemetry, lclk);
+                PROBE_VAL(12, lclk[0]) PROBE_VAL(13, lclk[1]) PROBE_VAL(11, (unsigned)clock64())
+#else
+                intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
+                    reinterpret_cast<LightPair*>(&s_raw[wave][O_EPI]), reinterpret_cast<unsigned*>(&s_raw[wave][O_EPI + 2048]), light_telemetry);
+#endif
+                PROBE_VAL(2, light_telemetry)
+            } else if (out.workspace) {
+                if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
+            }
+        }
+        // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
+        // env's first line and throws the result away)
+        PROBE_AT(5, tex_w)                                                   // the winner's line and texel row have arrived
+        f = tex_filter(is_hit ? loc : 0.f, tex_w);
+        const float bk_l = l_baked[tstart + f.l], bk_r = l_baked[tstart + f.r];
+        const float* __restrict__ tl = l_tex_vals + 3*(size_t)(tstart + f.l);
+        const float* __restrict__ tr = l_tex_vals + 3*(size_t)(tstart + f.r);
+        tl0 = tl[0]; tl1 = tl[1]; tl2 = tl[2]; tr0 = tr[0]; tr1 = tr[1]; tr2 = tr[2];
+        if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
+    }
+    if constexpr (OBS == 1) {
+        if (late->out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
+            bool fresh = false, fresh_last = false;
+            const int last_env = sc.n_envs - 1;
+            if (is_hit) {
+                const float wf = (float)tex_w;
+                const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
+                const int epoch = late->out.seen_epoch[n];
+                // A look first: most texels in view were stamped frames ago, and an atomic that returns its old value
+                // costs a round trip to the L2 per lane (a launch of nothing but stamped texels: 70 -> 39 us at 4096
+                // envs x 256 rays).  Stamps only ever turn into the epoch during a launch, so a stale read can only
+                // send a ray on to the exchange, where exactly one ray per texel sees the old stamp.
+                if (late->out.seen_stamp[tstart + along] != epoch)
+                    fresh = atomicExch(&late->out.seen_stamp[tstart + along], epoch) != epoch;
+            } else if ((r < R) & (sc.n_texels_total > 0)) {
+                // A ray that missed.  The reference gives it texel index -1 (explorer.py:36) and then sets `_seen[-1]`
+                // (:47): the LAST texel of the whole scenery counts as seen from then on, to the credit of the last env,
+                // whichever env's ray it was.  Kept as it is - a drop-in hands out the reference's rewards.
+                const int last = sc.n_texels_total - 1;
+                const int epoch = late->out.seen_epoch[last_env];
+                if (late->out.seen_stamp[last] != epoch)
+                    fresh_last = atomicExch(&late->out.seen_stamp[last], epoch) != epoch;
+            }
+            const unsigned long long fm = __ballot(fresh);
+            if (fm && lane == 0) atomicAdd(&late->out.seen_count[n], __popcll(fm));
+            if (__ballot(fresh_last) && lane == 0) atomicAdd(&late->out.seen_count[last_env], 1);
+        }
+        if (late->out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
+            const int sub = late->out.obs_subsample, W = R/sub;
+            const int r1 = (W/2 - 1)*sub + sub/2, r2 = (W/2)*sub + sub/2;
+            if ((r == r1) | (r == r2)) {
+                int seen = -1;
+                if ((nearest_idx >= 0) & (nearest_idx < AF)) seen = div_by(nearest_idx, rc.by_m);
+                late->out.obs_centre[((size_t)n*A + a)*2 + (r == r2 ? 1 : 0)] = seen;
+            }
+        }
+    }
+
+    if constexpr (COLOUR) {
+        PROBE_AT(6, tl0)                                                     // ... its texels
+        if (is_hit) {
+            const float dn = 1 - dt*dt;
+            s0 = dn*intensity*(f.lw*tl0 + f.rw*tr0);
+            s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
+            s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
+        }
+        float* const o_screen = late->out.screen;
+        if (!OBS || o_screen) {
+            // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
+            s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nfl = 3*min(n_live - q*WAVE, WAVE);
+            float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + r0 + q*WAVE);
+            #pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int j = lane + k*WAVE;
+                if (j < nfl) MS_OUT_STORE(s_screen_w[j], &scr[j]);
+            }
+        }
+    }
+    // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
+    // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
+    if (OBS && ((COLOUR && late->out.obs_rgb) || late->out.obs_depth)) {
+        const int sub = late->out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
+        float p0 = s0, p1 = s1, p2 = s2;
+        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
+        for (int o2 = 1; o2 < sub; o2 <<= 1) {
+            if constexpr (COLOUR) {
+                p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE); p2 += __shfl_xor(p2, o2, WAVE);
+            }
+            pd += __shfl_xor(pd, o2, WAVE);
+        }
+        if (((lane & (sub - 1)) == 0) & (r < R)) {
+            // (the mean: a sum over a power-of-two count - the host checks - divided by it, which only moves the exponent;
+            // times the exact reciprocal is the same number for a twelfth of the instructions)
+            const float inv = 1.f/(float)sub;
+            const int W = R/sub, px = r/sub;
+            const size_t na = (size_t)n*A + a;
+            if (COLOUR && late->out.obs_rgb) {
+                late->out.obs_rgb[(na*3 + 0)*W + px] = p0*inv;
+                late->out.obs_rgb[(na*3 + 1)*W + px] = p1*inv;
+                late->out.obs_rgb[(na*3 + 2)*W + px] = p2*inv;
+            }
+            if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd*inv;
+        }
+    }
+    };
     float nearest_s = INFINITY;
     int nearest_idx = -1;
 
@@ -1714,24 +1945,33 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         //               | near (64 x 4 B) | queue (128 x 2 B) | best, second, third (64 x 8 B each) | marks (4096 bits)
         // ------------------------------------------------------------------------------------------
         constexpr int V_CAP = MS_VCAP, P_CAP = 4096 < 64*MS_VCAP ? 4096 : 64*MS_VCAP;
-        constexpr int O_INFO = 16*V_CAP, O_RAY = 24*V_CAP, O_NEAR = O_RAY + 512*NG, O_QUEUE = O_NEAR + 256*NG, O_BEST = O_QUEUE + 256;
-        static_assert(O_BEST + 3*512*NG + 512 == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
-        static_assert(P_CAP >= NR, "a line's pairs - one per ray of the wave at most - must fit an empty list");
+        // NG > 1 (several ray groups a wave, one after the other on ONE group's worth of per-ray state):
+        //   cand (V x 16 B) | info (V x 8 B: first ray | rays << 16 of the line's interval among the span's rays, line) | queue
+        //   | per group, O_EPI on: ray, near, best, second, third, marks as above | pinfo (V x 4 B: first ray - first pair of
+        //   the lines that have pairs with this group) | gk (V x 2 B: which lines those are)        - 6912 B, six waves a SIMD
+        constexpr int O_INFO = 16*V_CAP;
+        constexpr int O_QUEUE = NG == 1 ? 24*V_CAP + 768 : 24*V_CAP;
+        constexpr int O_RAY = NG == 1 ? 24*V_CAP : O_EPI, O_NEAR = O_RAY + 512, O_BEST = NG == 1 ? O_QUEUE + 256 : O_NEAR + 256;
+        constexpr int O_MARK = O_BEST + 1536, O_PINFO = O_MARK + 512, O_GK = O_PINFO + 4*V_CAP;
+        static_assert((NG == 1 ? O_MARK + 512 : O_GK + 2*V_CAP) == LDS_PER_WAVE && LDS_PER_WAVE >= 2560, "the LDS block: lists, rays, queue, three key slots, 4096 mark bits");
+        static_assert(NG == 1 || O_EPI + 2560 <= LDS_PER_WAVE, "the epilogue's scratch fits the per-group region");
         int2* const s_info_w = reinterpret_cast<int2*>(&s_raw[wave][O_INFO]);
         // (direction and near plane in arrays of their own: at 8 and 4 bytes a ray, a window's reads - one ray per lane, the
         // rays mostly consecutive - touch every LDS bank once; as one 16-byte record per ray they were two-way conflicts)
         float2* const s_ray_w = reinterpret_cast<float2*>(&s_raw[wave][O_RAY]);
         float* const s_near_w = reinterpret_cast<float*>(&s_raw[wave][O_NEAR]);
         unsigned long long* const s_best_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST]);
-        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 512*NG]);
-        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 1024*NG]);
-        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][O_BEST + 1536*NG]);
-        s_ray_w[lane] = make_float2(rx, ry);
-        s_near_w[lane] = near;
-        s_best_w[lane] = ~0ull;
-        s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
-        s_second_w[lane] = ~0ull;
-        s_third_w[lane] = ~0ull;
+        unsigned long long* const s_second_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 512]);
+        unsigned long long* const s_third_w = reinterpret_cast<unsigned long long*>(&s_raw[wave][O_BEST + 1024]);
+        unsigned* const s_mark_w = reinterpret_cast<unsigned*>(&s_raw[wave][O_MARK]);
+        if constexpr (NG == 1) {
+            s_ray_w[lane] = make_float2(rx, ry);
+            s_near_w[lane] = near;
+            s_best_w[lane] = ~0ull;
+            s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
+            s_second_w[lane] = ~0ull;
+            s_third_w[lane] = ~0ull;
+        }
         // the run of directions of this wave's rays, from its rightmost ray (the last live one) to its leftmost (lane 0's of
         // the first group)                    (pseudo_angle with the reciprocal the hardware offers: the margin is 10^4 of its roundings wide)
         auto pseudo_angle_fast = [](const float x_, const float y_) {
@@ -1740,21 +1980,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         };
         const float pa_first = readlane_f(pseudo_angle_fast(rx, ry), 0);
         float pa_last = readlane_f(pseudo_angle_fast(rx, ry), min(n_live, WAVE) - 1);
-        if constexpr (NG > 1) {
-            // the other groups' rays: directions and near planes into LDS, slots cleared (groups past the last ray too:
-            // harmless, and no pair ever names their rays)
-            #pragma unroll
-            for (int q = 1; q < NG; q++) {
-                float qx, qy, ql, qn;
-                ray_of(r + q*WAVE, qx, qy, ql, qn);
-                s_ray_w[q*WAVE + lane] = make_float2(qx, qy);
-                s_near_w[q*WAVE + lane] = qn;
-                s_best_w[q*WAVE + lane] = ~0ull; s_second_w[q*WAVE + lane] = ~0ull; s_third_w[q*WAVE + lane] = ~0ull;
-                const float pl = readlane_f(pseudo_angle_fast(qx, qy), min(max(n_live - q*WAVE, 1), WAVE) - 1);
-                if (n_live > q*WAVE) pa_last = pl;
-            }
-        }
-        const float last_local = (float)(r_last - r0);        // last live ray of this wave
+        // the rays a list is made for - the wave's (NG = 1), or one span of its groups after the other: first ray, last live
+        // ray counted from it, how many there are room for
+        [[maybe_unused]] const float last_local = (float)(r_last - r0);
+        float sp_g0 = g0, sp_last = (float)(r_last - r0), sp_nr = (float)WAVE;
         // pass 1 for one line (lane = line): the ray-independent half of the intersection, and the conservative
         // interval [lo, lo + len) of this wave's rays that can hit it
         // a chunk's lines as they are in memory, lane = line (dead lanes get the last row, agent rows whatever the last
@@ -1773,7 +2002,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
             cd = Cand{pqx, pqy, w.z - w.x, w.w - w.y};                 // v = b - a
             float xa, ya, xb, yb;
             agent_frame(cs, sn, pqx, pqy, dbx, dby, xa, ya, xb, yb);
-            ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, live, x_clip, c_a, c_b, g0, last_local, lo, len, (float)NR);
+            ray_interval<(MS_V2_OPTS & 2) ? 1 : 0>(xa, ya, xb, yb, live, x_clip, c_a, c_b, sp_g0, sp_last, lo, len, sp_nr);
         };
 
         int n_pairs_total = 0, n_windows = 0;    // telemetry
@@ -1803,7 +2032,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 const int k = before + upto - 1;             // (past the last pair there are no marks: the last line, harmless)
                 before += __popcll(M);
                 const int2 info = s_info_w[k];
-                const int rr = (p + info.x) & (NR - 1);      // ray of this pair, wave-local (in range as it is for valid pairs)
+                const int rr = (p + info.x) & 63;            // ray of this pair, wave-local (in range as it is for valid pairs)
                 const Cand cd = s_cand_w[k];
                 const float2 ray = s_ray_w[rr];
                 const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
@@ -1850,31 +2079,6 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
             const int incl = wave_scan_add(len);
             const int chunk_pairs = __builtin_amdgcn_readlane(incl, 63);
             const int chunk_lines = __popcll(vm);
-            if constexpr (NG > 1) {
-                // 64 lines of up to 64 NG pairs each need not fit an empty list: those that do go in - a prefix of the
-                // batch, by the running count of pairs -, the list is worked off, and the rest follows
-                if (chunk_pairs > P_CAP) {
-                    int base = 0;                                            // pairs of the lines that are in already
-                    for (unsigned long long left = vm; left; ) {
-                        const int room = P_CAP - n_pairs;
-                        const bool fits = ((left >> lane) & 1ull) && (incl - base <= room);
-                        const unsigned long long fm = __ballot(fits);
-                        if (!fm || n_list + __popcll(fm) > V_CAP) { drain(); continue; }      // (a line alone always fits an empty list)
-                        const int upto = __builtin_amdgcn_readlane(incl, 63 - __builtin_clzll(fm));   // the pairs of the batch up to its last line that fits
-                        if (fits) {
-                            const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fm, 0u));
-                            const int first = n_pairs + incl - len - base;
-                            s_cand_w[k] = cd;
-                            s_info_w[k] = make_int2(lo - first, l);
-                            atomicOr(&s_mark_w[first >> 5], 1u << (first & 31));
-                        }
-                        n_list += __popcll(fm); n_pairs += upto - base;
-                        base = upto;
-                        left &= ~fm;
-                    }
-                    return;
-                }
-            }
             if ((n_list + chunk_lines > V_CAP) | (n_pairs + chunk_pairs > P_CAP)) drain();
             if (seen) {
                 const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
@@ -1910,80 +2114,88 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         const int AL = AF - own;                                             // agent lines among the items
         const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned*>(sc.wg_pool + wg_first), 0, listed ? 4*n_raw : 0, 0x00020000);
-        int wa8, wb8;
-        wg_wedge(pa_last, pa_first, wa8, wb8);
         auto raw = [&](const int k0) {                                       // entries k0 + lane of the list (past its end: 0)
             return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(list_rsrc, 4*(k0 + lane), 0, 0);
         };
-        unsigned e_next[2] = {raw(0), raw(WAVE)};
-        int raw_pos = 0, q_len = 0, al_left = AL;                            // (uniform)
-        // (without a list the queue's entries are simply the env's walls in their order: what stands at its front is
-        // counted here rather than read back from its 16-bit entries - an env may have more than 65536 walls, a list not)
-        int q_first = 0;
-        for (;;) {
-            // fill the queue from the list
-            while ((raw_pos < n_raw) & (q_len <= Q_CAP - WAVE)) {
-                const unsigned e = e_next[0];
-                e_next[0] = e_next[1];
-                e_next[1] = raw(raw_pos + 2*WAVE);
-                const int k = raw_pos + lane;
-                const int idx = listed ? (int)(e & 0xffffu) : k;
+        // the walk over the items for rays whose directions run from `pa_right` to `pa_left`; every batch of lines goes to
+        // `admit_fn`, and `stop_fn` may call it off between batches
+        auto walk = [&](const float pa_right, const float pa_left, auto&& admit_fn, auto&& stop_fn) {
+            int wa8, wb8;
+            wg_wedge(pa_right, pa_left, wa8, wb8);
+            unsigned e_next[2] = {raw(0), raw(WAVE)};
+            int raw_pos = 0, q_len = 0, al_left = AL;                            // (uniform)
+            // (without a list the queue's entries are simply the env's walls in their order: what stands at its front is
+            // counted here rather than read back from its 16-bit entries - an env may have more than 65536 walls, a list not)
+            int q_first = 0;
+            for (;;) {
+                // fill the queue from the list
+                while ((raw_pos < n_raw) & (q_len <= Q_CAP - WAVE)) {
+                    const unsigned e = e_next[0];
+                    e_next[0] = e_next[1];
+                    e_next[1] = raw(raw_pos + 2*WAVE);
+                    const int k = raw_pos + lane;
+                    const int idx = listed ? (int)(e & 0xffffu) : k;
 #ifndef MS_ARC_CULL
-#define MS_ARC_CULL 1                                                        // (0: an A/B build that queues every listed wall)
+#define MS_ARC_CULL 1                                                            // (0: an A/B build that queues every listed wall)
 #endif
-                const bool keep = (k < n_raw) & (!listed | !MS_ARC_CULL | wg_arcs_meet((int)((e >> 16) & 255u), (int)(e >> 24), wa8, wb8));
-                const unsigned long long km = __ballot(keep);
-                if (keep) s_queue_w[q_len + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u))] = (unsigned short)idx;
-                q_len += __popcll(km);
-                raw_pos += WAVE;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // this batch's items: what is left of the agents' lines, then the queue
-            const int al0 = AL - al_left;                                    // the first agent-line item of this batch
-            const int n_al = min(al_left, AHEAD*WAVE);
-            const int n_items = n_al + min(q_len, AHEAD*WAVE - n_al);
-            const int q_used = n_items - n_al;
-            int l_it[AHEAD];
-            float4 w_it[AHEAD];
-            #pragma unroll
-            for (int kk = 0; kk < AHEAD; kk++) {
-                const int i = kk*WAVE + lane;
-                const int ai = al0 + i;                                      // as an agent-line item
-                const int q_at = min(max(i - n_al, 0), Q_CAP - 1);
-                const int qe = listed ? (int)s_queue_w[q_at] : q_first + q_at;
-                l_it[kk] = (i < n_al) ? ai + (ai >= own0 ? own : 0) : AF + qe;
-                w_it[kk] = rows.load(l_it[kk]*16, 0);
-            }
-            PROBE_VAL(2, 0)                                                  // (slot 2: what the dynamic lighting had to do)
-            PROBE_AT(3, w_it[0].x)                                           // ... the first chunk of rows
-            #pragma unroll
-            for (int kk = 0; kk < AHEAD; kk++) {
-                if (kk*WAVE >= n_items) continue;                            // uniform
-                admit(w_it[kk], l_it[kk], kk*WAVE + lane < n_items, kk*WAVE < n_al, al0 + kk*WAVE == 0);
-            }
-            al_left -= n_al;
-            // what the batch did not take of the queue moves to its front
-            __builtin_amdgcn_wave_barrier();
-            if (q_used < q_len) {
-                unsigned short keep_[Q_CAP/WAVE];
-                #pragma unroll
-                for (int j = 0; j < Q_CAP/WAVE; j++) keep_[j] = s_queue_w[min(q_used + j*WAVE + lane, Q_CAP - 1)];
+                    const bool keep = (k < n_raw) & (!listed | !MS_ARC_CULL | wg_arcs_meet((int)((e >> 16) & 255u), (int)(e >> 24), wa8, wb8));
+                    const unsigned long long km = __ballot(keep);
+                    if (keep) s_queue_w[q_len + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(km >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)km, 0u))] = (unsigned short)idx;
+                    q_len += __popcll(km);
+                    raw_pos += WAVE;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // this batch's items: what is left of the agents' lines, then the queue
+                const int al0 = AL - al_left;                                    // the first agent-line item of this batch
+                const int n_al = min(al_left, AHEAD*WAVE);
+                const int n_items = n_al + min(q_len, AHEAD*WAVE - n_al);
+                const int q_used = n_items - n_al;
+                int l_it[AHEAD];
+                float4 w_it[AHEAD];
                 #pragma unroll
-                for (int j = 0; j < Q_CAP/WAVE; j++) if (j*WAVE + lane < q_len - q_used) s_queue_w[j*WAVE + lane] = keep_[j];
+                for (int kk = 0; kk < AHEAD; kk++) {
+                    const int i = kk*WAVE + lane;
+                    const int ai = al0 + i;                                      // as an agent-line item
+                    const int q_at = min(max(i - n_al, 0), Q_CAP - 1);
+                    const int qe = listed ? (int)s_queue_w[q_at] : q_first + q_at;
+                    l_it[kk] = (i < n_al) ? ai + (ai >= own0 ? own : 0) : AF + qe;
+                    w_it[kk] = rows.load(l_it[kk]*16, 0);
+                }
+                PROBE_VAL(2, 0)                                                  // (slot 2: what the dynamic lighting had to do)
+                PROBE_AT(3, w_it[0].x)                                           // ... the first chunk of rows
+                #pragma unroll
+                for (int kk = 0; kk < AHEAD; kk++) {
+                    if (kk*WAVE >= n_items) continue;                            // uniform
+                    admit_fn(w_it[kk], l_it[kk], kk*WAVE + lane < n_items, kk*WAVE < n_al, al0 + kk*WAVE == 0);
+                }
+                al_left -= n_al;
+                // what the batch did not take of the queue moves to its front
+                __builtin_amdgcn_wave_barrier();
+                if (q_used < q_len) {
+                    unsigned short keep_[Q_CAP/WAVE];
+                    #pragma unroll
+                    for (int j = 0; j < Q_CAP/WAVE; j++) keep_[j] = s_queue_w[min(q_used + j*WAVE + lane, Q_CAP - 1)];
+                    __builtin_amdgcn_wave_barrier();
+                    #pragma unroll
+                    for (int j = 0; j < Q_CAP/WAVE; j++) if (j*WAVE + lane < q_len - q_used) s_queue_w[j*WAVE + lane] = keep_[j];
+                }
+                q_len -= q_used;
+                q_first += q_used;
+                if (((raw_pos >= n_raw) & (q_len == 0) & (al_left == 0)) || stop_fn()) break;
             }
-            q_len -= q_used;
-            q_first += q_used;
-            if ((raw_pos >= n_raw) & (q_len == 0) & (al_left == 0)) break;
+        };
+        if constexpr (NG == 1) {
+            walk(pa_last, pa_first, admit, [] { return false; });
+            if (n_pairs) drain();
         }
-        if (n_pairs) drain();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // The nearest hit of this lane's ray of the wave's group q from its three key slots, or - where they cannot tell - by
         // the literal fold.  (rx, ry, near: that ray's; the first group's are in registers, the others' come from LDS.)
+        bool list_whole = true;                  // (NG > 1) the list in LDS is all the span's lines
         auto resolve_group = [&](const int q, const float rx, const float ry, const float near, float& nearest_s, int& nearest_idx) {
-            const unsigned long long best = s_best_w[q*WAVE + lane], second = s_second_w[q*WAVE + lane], third = s_third_w[q*WAVE + lane];
+            const unsigned long long best = s_best_w[lane], second = s_second_w[lane], third = s_third_w[lane];
             bool ambiguous = false;
             if (best != ~0ull) {                     // the resolution of IMPL 1, word for word
                 const float s1 = bits_f((uint32_t)(best >> 32)), s2 = bits_f((uint32_t)(second >> 32)), s3 = bits_f((uint32_t)(third >> 32));
@@ -2019,7 +2231,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 atomicAdd(&out.workspace[1], __popcll(amb));
                 if (__popcll(amb) > 6) atomicAdd(&out.workspace[2], 1);
             }
-            if (amb && n_drains == 1) {
+            if (amb && (NG == 1 ? n_drains == 1 : list_whole)) {
                 // The usual case: the wave's list was worked off once, at the end, so all of it is still in LDS - every line
                 // a ray of this wave can hit (the exact cull arguments above), ray-independent half of the intersection
                 // ready, in LINE ORDER: the agents' lines in theirs, then the cell's vis list, which wallgrid_fill_kernel
@@ -2099,7 +2311,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
                 for (int c0 = 0; c0 < L; c0 += WAVE) {
                     Cand mine;
                     int lo = 0, len = 0;
-                    line_math(fetch(c0), c0 + lane, c0 + lane < L, c0 < AF, c0 == 0, mine, lo, len);
+                    line_math(fetch(c0), c0 + lane, c0 + lane < L, c0 < AF, NG == 1 && c0 == 0, mine, lo, len);   // (NG > 1: the model row is read where it is needed, not held)
                     __builtin_amdgcn_wave_barrier();
                     s_cand_w[lane] = mine;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2171,19 +2383,201 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
         if constexpr (NG == 1) {
             resolve_group(0, rx, ry, near, nearest_s, nearest_idx);
         } else {
-            // group after group; a group's answer goes back into its first key slot as (s bits << 32 | line) for the
-            // epilogue to pick up - the lists in LDS, which a literal fold reads, are gone by then (lighting scratch)
-            #pragma unroll 1
-            for (int q = 0; q*WAVE < n_live; q++) {
-                const float2 rq = s_ray_w[q*WAVE + lane];
+            // ------------------------------------------------------------------------------------------
+            // Several ray groups a wave.  What an agent's waves each did for themselves - its state, its cell, the vis
+            // list and its arc cull, the agents' lines, pass 1 on every line their wedges share - is done once, for a SPAN
+            // of groups: pass 1 turns a line into an interval [lo, lo + len) of all the span's rays, and the lines that
+            // have one go into the list with it.  Then group after group, on one group's worth of per-ray state: its rays
+            // set up, the list's intervals clipped to its 64 rays and the (line, ray) pairs numbered (a prefix sum over the
+            // list, 64 lines at a time; the lines that have pairs with the group are indexed), pass 2's windows, the
+            // resolution - its literal fold over the whole list - and the epilogue, whose scratch sits behind the list.
+            // A span is all the wave's groups; only if their lines do not fit the list (V_CAP) is it redone group by group,
+            // the list then being worked off whenever it is full, as with NG = 1.
+            // ------------------------------------------------------------------------------------------
+            int* const s_pinfo_w = reinterpret_cast<int*>(&s_raw[wave][O_PINFO]);
+            unsigned short* const s_gk_w = reinterpret_cast<unsigned short*>(&s_raw[wave][O_GK]);
+            const int n_groups = (n_live + WAVE - 1)/WAVE;
+            // pass 2 for the group whose rays are [lo_g, lo_g + 64) of the span's, over the list as it stands
+            auto pass2_group = [&](const int lo_g) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                int base = 0, nj = 0;                 // pairs numbered, lines indexed so far (uniform)
+                auto windows = [&]() {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    n_pairs_total += base; n_windows += (base + WAVE - 1)/WAVE;
+                    const unsigned long long my_marks = reinterpret_cast<const unsigned long long*>(s_mark_w)[lane];
+                    int before = 0;
+                    for (int p0 = 0; p0 < base; p0 += WAVE) {
+                        const unsigned mlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)my_marks, p0 >> 6);
+                        const unsigned mhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(my_marks >> 32), p0 >> 6);
+                        const unsigned long long M = ((unsigned long long)mhi << 32) | mlo;
+                        const unsigned long long Ms = M >> 1;
+                        const int upto = (int)(mlo & 1u) + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(Ms >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)Ms, 0u));
+                        const int p = p0 + lane;
+                        const bool valid = p < base;
+                        const int j = before + upto - 1;             // (past the last pair there are no marks: the last line, harmless)
+                        before += __popcll(M);
+                        const int k = (int)s_gk_w[j];
+                        const int rr = (p + s_pinfo_w[j]) & 63;      // ray of this pair, within the group
+                        const Cand cd = s_cand_w[k];
+                        const int line = s_info_w[k].y;
+                        const float2 ray = s_ray_w[rr];
+                        const float d = ray.x*cd.vy - ray.y*cd.vx;                   // cross(ru, v)
+                        const float nt = cd.pqx*ray.y - cd.pqy*ray.x;                // cross(PQ, ru)
+                        const float ad = fabsf(d);
+                        const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
+                        const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
+                        if (hit) {
+                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
+                            const bool beyond = s_near_w[rr] < sv;                   // beyond the near plane, kernels.cu:369
+                            if (beyond) {
+                                const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)line;
+                                const unsigned long long old = atomicMin(&s_best_w[rr], key);
+                                const unsigned oh = (unsigned)(old >> 32);
+                                if (oh != 0xffffffffu) {
+                                    const bool won = key < old;
+                                    const float so = bits_f(oh);
+                                    const float front = won ? sv : so, back = won ? so : sv;
+                                    if (back < front + 4.e-4f) {
+                                        const unsigned long long lose1 = won ? old : key;
+                                        const unsigned long long old2 = atomicMin(&s_second_w[rr], lose1);
+                                        const unsigned long long lose2 = old2 > lose1 ? old2 : lose1;
+                                        if (lose2 != ~0ull) atomicMin(&s_third_w[rr], lose2);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
+                    base = 0; nj = 0;
+                };
+                for (int k0 = 0; k0 < n_list; k0 += WAVE) {
+                    const int k = k0 + lane;
+                    const int iv = s_info_w[min(k, n_list - 1)].x;
+                    const int lo = iv & 0xffff, hi = lo + (iv >> 16);
+                    const int a0 = max(lo, lo_g), a1 = min(hi, lo_g + WAVE);
+                    const int len_g = (k < n_list) ? max(a1 - a0, 0) : 0;
+                    const unsigned long long vm = __ballot(len_g > 0);
+                    if (!vm) continue;                                               // uniform
+                    const int incl = wave_scan_add(len_g);
+                    const int total = __builtin_amdgcn_readlane(incl, 63);
+                    if (base + total > P_CAP) windows();                             // (64 lines x 64 rays always fit an empty numbering)
+                    if (len_g > 0) {
+                        const int j = nj + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                        const int first = base + incl - len_g;
+                        s_gk_w[j] = (unsigned short)k;
+                        s_pinfo_w[j] = (a0 - lo_g) - first;                          // pair p of the numbering is ray p + this, of the group's
+                        atomicOr(&s_mark_w[first >> 5], 1u << (first & 31));
+                    }
+                    base += total; nj += __popcll(vm);
+                }
+                if (base) windows();
+            };
+            // a group's rays into LDS, its slots and marks cleared
+            auto setup_group = [&](const int q, float& qx, float& qy, float& ql, float& qn) {
+                ray_of(r0 + q*WAVE + lane, qx, qy, ql, qn);
+                __builtin_amdgcn_wave_barrier();                                     // (whoever read the region last is through)
+                s_ray_w[lane] = make_float2(qx, qy);
+                s_near_w[lane] = qn;
+                s_best_w[lane] = ~0ull; s_second_w[lane] = ~0ull; s_third_w[lane] = ~0ull;
+                s_mark_w[lane] = 0u; s_mark_w[lane + WAVE] = 0u;
+            };
+            // the span's rays and the run of directions they cover: from its last live ray (lane 1 works it out) to its first
+            // (lane 0); returns the pseudo-angles in those two lanes
+            auto span_of = [&](const int q0, const int sp_n) {
+                const int sp_rays = min(n_live - q0*WAVE, sp_n*WAVE);
+                sp_g0 = (float)(r0 + q0*WAVE); sp_last = (float)(sp_rays - 1); sp_nr = (float)(sp_n*WAVE);
+                float wx, wy, wl_, wn_;
+                ray_of(r0 + q0*WAVE + (lane == 0 ? 0 : sp_rays - 1), wx, wy, wl_, wn_);
+                return pseudo_angle_fast(wx, wy);
+            };
+            // one group, once the list is what it is: pairs, nearest hits, everything behind them
+            auto group_rest = [&](const int q, const int q_rel, const float gx, const float gy) {
+                pass2_group(q_rel*WAVE);
+                list_n = n_list;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 float ns = INFINITY;
                 int ni = -1;
-                resolve_group(q, rq.x, rq.y, s_near_w[q*WAVE + lane], ns, ni);
-                s_best_w[q*WAVE + lane] = ((unsigned long long)f_bits(ns) << 32) | (unsigned)ni;
+                resolve_group(q_rel, gx, gy, s_near_w[lane], ns, ni);
+                LANE_AFRESH;
+                float4 hw_mem; int tex_w, tstart;
+                winner_of(ni, hw_mem, tex_w, tstart);
+                finish_group(q, r0 + q*WAVE + lane, gx, gy, ray_len(gx, gy), ns, ni, hw_mem, tex_w, tstart);
+                __builtin_amdgcn_wave_barrier();
+            };
+            // ---- all the wave's groups as one span
+            bool overflow = false;
+            {
+                const float pa = span_of(0, n_groups);
+                n_list = 0; list_whole = true;
+                // a batch of lines into the list, each with its interval of the span's rays
+                auto admit_shared = [&](const float4 w, const int l, const bool live, const bool agent_lines, const bool) {
+                    if (overflow) return;
+                    Cand cd;
+                    int lo = 0, len = 0;
+                    line_math(w, l, live, agent_lines, false, cd, lo, len);
+                    const bool seen = len > 0;
+                    const unsigned long long vm = __ballot(seen);
+                    if (!vm) return;                                                 // uniform
+                    const int chunk_lines = __popcll(vm);
+                    if (n_list + chunk_lines > V_CAP) { overflow = true; return; }   // the span's lines do not fit: group by group, then
+                    if (seen) {
+                        const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                        s_cand_w[k] = cd;
+                        s_info_w[k] = make_int2(lo | (len << 16), l);
+                    }
+                    n_list += chunk_lines;
+                };
+                walk(readlane_f(pa, 1), readlane_f(pa, 0), admit_shared, [&] { return overflow; });
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (!overflow) {
+                #pragma unroll 1
+                for (int q = 0; q < n_groups; q++) {
+                    LANE_AFRESH;
+                    if (q) load_agents();
+                    float gx, gy, gl, gn;
+                    setup_group(q, gx, gy, gl, gn);
+                    group_rest(q, q, gx, gy);
+                }
+            } else {
+                // ---- group by group (an env of dozens of agents, a cell with hundreds of walls in view): every group walks the
+                // items for itself, and a list that fills up is worked off into the group's slots and started afresh
+                #pragma unroll 1
+                for (int q = 0; q < n_groups; q++) {
+                    LANE_AFRESH;
+                    if (q) load_agents();
+                    const float pa = span_of(q, 1);
+                    float gx, gy, gl, gn;
+                    setup_group(q, gx, gy, gl, gn);
+                    n_list = 0; list_whole = true;
+                    auto admit_one = [&](const float4 w, const int l, const bool live, const bool agent_lines, const bool) {
+                        Cand cd;
+                        int lo = 0, len = 0;
+                        line_math(w, l, live, agent_lines, false, cd, lo, len);
+                        const bool seen = len > 0;
+                        const unsigned long long vm = __ballot(seen);
+                        if (!vm) return;                                             // uniform
+                        const int chunk_lines = __popcll(vm);
+                        if (n_list + chunk_lines > V_CAP) {
+                            pass2_group(0);                                          // its slots hold what the list so far had to say
+                            n_list = 0; list_whole = false;
+                        }
+                        if (seen) {
+                            const int k = n_list + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u));
+                            s_cand_w[k] = cd;
+                            s_info_w[k] = make_int2(lo | (len << 16), l);
+                        }
+                        n_list += chunk_lines;
+                    };
+                    walk(readlane_f(pa, 1), readlane_f(pa, 0), admit_one, [] { return false; });
+                    const float2 back = s_ray_w[lane];                               // (not held in registers through the walk)
+                    group_rest(q, 0, back.x, back.y);
+                }
+            }
         }
     }
 #if MS_AB_IMPLS
@@ -2273,229 +2667,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG == 1
 
     if constexpr (MS_ABLATE == 2 || MS_ABLATE == 3) { if (out.indices) out.indices[(size_t)fan*WAVE + lane] = nearest_idx + __float_as_int(nearest_s); return; }
     PROBE_AT(4, nearest_idx)                                             // the raycast is over
-    // ---- the winner's loc and dot, recomputed from the same inputs (kernels.cu:356-364,374-375)
-    // Everything the rest needs from memory about the winning line - its ends, its texel count and first texel - is
-    // asked for here, for every lane, from a row that exists (the env's first for a miss): unconditional loads are
-    // the ones hipcc lets overlap.
-    const LateArgs late = late_args();           // (see RenderArgs)
-    constexpr bool COLOUR = SHADE != 0;
-    static_assert(COLOUR || OBS == 1, "without colour `screen` is NULL: the OBS instantiation");
-    // (uniform; constant-folded away in the colour instantiations)
-    const bool want_texel_row = COLOUR || (OBS && late->out.seen_stamp != nullptr);
-    const bool want_line = want_texel_row || late->out.locations != nullptr || late->out.dots != nullptr;
-    // what depends on the winner's number alone: its row, its texel count and first texel
-    // (plain scalars in and out: as a struct by value this cost every wave 32 bytes of scratch memory)
-    auto winner_of = [&](const int nearest_idx, float4& hw_mem, int& tex_w, int& tstart) {
-        const int row = min(max(nearest_idx, 0), max(L - 1, 0));
-        hw_mem = make_float4(0.f, 0.f, 0.f, 0.f); tex_w = 1; tstart = 0;
-        if (want_line) hw_mem = rows.row(row);
-        if (want_texel_row) {
-            const int* const l_tex_widths = late->sc.textures_widths;
-            const int* const l_tex_starts = late->sc.textures_starts;
-            tex_w = l_tex_widths[base + row]; tstart = l_tex_starts[base + row];
-        }
-    };
-    // ... and the rest of a group's rays' lives: q = the group, r = this lane's ray of it, (rx, ry, rlen) = its direction
-    auto finish_group = [&](const int q, const int r, const float rx, const float ry, const float rlen,
-                            const float nearest_s, const int nearest_idx, const float4 hw_mem, const int tex_w, const int tstart) {
-    float loc = NAN, dt = NAN;
-    float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (want_line) {
-        float4 aw = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (__ballot((nearest_idx >= 0) & (nearest_idx < AF))) aw = agent_line(nearest_idx);
-        if (nearest_idx >= 0) {
-            hw = (nearest_idx < AF) ? aw : hw_mem;
-            const float vx = hw.z - hw.x, vy = hw.w - hw.y;
-            const float d = rx*vy - ry*vx;
-            const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
-            loc = (pqx*ry - pqy*rx)/d;
-            const float dtop = rx*vx + ry*vy;
-            const float dbot = rlen*sqrtf(vx*vx + vy*vy);
-            dt = dtop/(dbot + 1.e-6f);
-        }
-    }
-    const size_t o = ((size_t)n*A + a)*R + r;
-    const float dist = nearest_s*rlen;
-    {
-        int* const o_indices = late->out.indices;
-        float* const o_locations = late->out.locations;
-        float* const o_dots = late->out.dots;
-        float* const o_distances = late->out.distances;
-        if (r < R) {
-            if (!OBS || o_indices) MS_OUT_STORE(nearest_idx, &o_indices[o]);
-            if (!OBS || o_locations) MS_OUT_STORE(loc, &o_locations[o]);
-            if (!OBS || o_dots) MS_OUT_STORE(dt, &o_dots[o]);
-            if (!OBS || o_distances) MS_OUT_STORE(dist, &o_distances[o]);
-        }
-    }
-
-    // ---- pass 3: shade (kernels.cu:407-450)
-    const bool is_hit = (nearest_idx >= 0) & (r < R);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    [[maybe_unused]] Filt f = Filt{0, 0, 0.f, 0.f};
-    [[maybe_unused]] float intensity = 0.f;
-    [[maybe_unused]] float tl0 = 0.f, tl1 = 0.f, tl2 = 0.f, tr0 = 0.f, tr1 = 0.f, tr2 = 0.f;
-    if constexpr (COLOUR) {
-        const float* const l_tex_vals = late->sc.textures_vals;
-        const float* const l_baked = late->sc.baked_vals;
-        const bool dynamic = is_hit & (nearest_idx < AF);
-        // Rays that landed on an agent (dynamic) are lit from the lights (kernels.cu:432-436).  With a light grid
-        // this wave does it here, on the LDS the raycast no longer needs; without one they leave black and their
-        // ray group is queued for dynlight_kernel, launched right behind this kernel.
-        [[maybe_unused]] unsigned light_telemetry = 0x80000000u;
-#ifdef MS_NO_DYNLIGHT
-        if (dynamic) intensity = 1.f;            // (an ablation: what would free dynamic lighting buy? the picture is wrong)
-        if (false) {
-#else
-        if (__ballot(dynamic)) {
-#endif
-            if (sc.lg_vals) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const float cx_l = hw.x*(1 - loc) + hw.z*loc, cy_l = hw.y*(1 - loc) + hw.w*loc;   // kernels.cu:435
-                const LightScene scl{sc.n_agents, sc.n_model, late->sc.lights_vals, late->sc.lights_widths, late->sc.lights_starts,
-                                     late->sc.lg_vals, late->sc.lg_starts, late->sc.lg_geom, late->sc.lg_cell,
-                                     late->sc.lg_list, late->sc.lg_pool, reinterpret_cast<const float4*>(late->sc.lg_pool_rows)};   // (fetched now: see RenderArgs)
-#if MS_PROBE
-                unsigned lclk[2] = {0u, 0u};                     // (probe build: the lighting's own stamps - they take the places of the pair statistics)
-                PROBE_VAL(14, (unsigned)clock64())
-                intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
-                    reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry, lclk);
-                PROBE_VAL(12, lclk[0]) PROBE_VAL(13, lclk[1]) PROBE_VAL(11, (unsigned)clock64())
-#else
-                intensity = grid_light_intensity(scl, ag, n, lane, dynamic, nearest_idx, cx_l, cy_l, L, ln,
-                    reinterpret_cast<LightPair*>(&s_raw[wave][0]), reinterpret_cast<unsigned*>(&s_raw[wave][2048]), light_telemetry);
-#endif
-                PROBE_VAL(2, light_telemetry)
-            } else if (out.workspace) {
-                if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
-            }
-        }
-        // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
-        // env's first line and throws the result away)
-        PROBE_AT(5, tex_w)                                                   // the winner's line and texel row have arrived
-        f = tex_filter(is_hit ? loc : 0.f, tex_w);
-        const float bk_l = l_baked[tstart + f.l], bk_r = l_baked[tstart + f.r];
-        const float* __restrict__ tl = l_tex_vals + 3*(size_t)(tstart + f.l);
-        const float* __restrict__ tr = l_tex_vals + 3*(size_t)(tstart + f.r);
-        tl0 = tl[0]; tl1 = tl[1]; tl2 = tl[2]; tr0 = tr[0]; tr1 = tr[1]; tr2 = tr[2];
-        if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
-    }
-    if constexpr (OBS == 1) {
-        if (late->out.seen_stamp) {                                // explorer.py:34-58: which texels are seen for the first time
-            bool fresh = false, fresh_last = false;
-            const int last_env = sc.n_envs - 1;
-            if (is_hit) {
-                const float wf = (float)tex_w;
-                const int along = (int)ms_min(floorf(wf*loc), wf - 1);      // explorer.py:38-41
-                const int epoch = late->out.seen_epoch[n];
-                // A look first: most texels in view were stamped frames ago, and an atomic that returns its old value
-                // costs a round trip to the L2 per lane (a launch of nothing but stamped texels: 70 -> 39 us at 4096
-                // envs x 256 rays).  Stamps only ever turn into the epoch during a launch, so a stale read can only
-                // send a ray on to the exchange, where exactly one ray per texel sees the old stamp.
-                if (late->out.seen_stamp[tstart + along] != epoch)
-                    fresh = atomicExch(&late->out.seen_stamp[tstart + along], epoch) != epoch;
-            } else if ((r < R) & (sc.n_texels_total > 0)) {
-                // A ray that missed.  The reference gives it texel index -1 (explorer.py:36) and then sets `_seen[-1]`
-                // (:47): the LAST texel of the whole scenery counts as seen from then on, to the credit of the last env,
-                // whichever env's ray it was.  Kept as it is - a drop-in hands out the reference's rewards.
-                const int last = sc.n_texels_total - 1;
-                const int epoch = late->out.seen_epoch[last_env];
-                if (late->out.seen_stamp[last] != epoch)
-                    fresh_last = atomicExch(&late->out.seen_stamp[last], epoch) != epoch;
-            }
-            const unsigned long long fm = __ballot(fresh);
-            if (fm && lane == 0) atomicAdd(&late->out.seen_count[n], __popcll(fm));
-            if (__ballot(fresh_last) && lane == 0) atomicAdd(&late->out.seen_count[last_env], 1);
-        }
-        if (late->out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
-            const int sub = late->out.obs_subsample, W = R/sub;
-            const int r1 = (W/2 - 1)*sub + sub/2, r2 = (W/2)*sub + sub/2;
-            if ((r == r1) | (r == r2)) {
-                int seen = -1;
-                if ((nearest_idx >= 0) & (nearest_idx < AF)) seen = nearest_idx/sc.n_model;
-                late->out.obs_centre[((size_t)n*A + a)*2 + (r == r2 ? 1 : 0)] = seen;
-            }
-        }
-    }
-
-    if constexpr (COLOUR) {
-        PROBE_AT(6, tl0)                                                     // ... its texels
-        if (is_hit) {
-            const float dn = 1 - dt*dt;
-            s0 = dn*intensity*(f.lw*tl0 + f.rw*tr0);
-            s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
-            s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
-        }
-        float* const o_screen = late->out.screen;
-        if (!OBS || o_screen) {
-            // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
-            s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nfl = 3*min(n_live - q*WAVE, WAVE);
-            float* __restrict__ scr = o_screen + 3*(((size_t)n*A + a)*R + r0 + q*WAVE);
-            #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int j = lane + k*WAVE;
-                if (j < nfl) MS_OUT_STORE(s_screen_w[j], &scr[j]);
-            }
-        }
-    }
-    // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
-    // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
-    if (OBS && ((COLOUR && late->out.obs_rgb) || late->out.obs_depth)) {
-        const int sub = late->out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
-        float p0 = s0, p1 = s1, p2 = s2;
-        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
-        for (int o2 = 1; o2 < sub; o2 <<= 1) {
-            if constexpr (COLOUR) {
-                p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE); p2 += __shfl_xor(p2, o2, WAVE);
-            }
-            pd += __shfl_xor(pd, o2, WAVE);
-        }
-        if (((lane & (sub - 1)) == 0) & (r < R)) {
-            // (the mean: a sum over a power-of-two count - the host checks - divided by it, which only moves the exponent;
-            // times the exact reciprocal is the same number for a twelfth of the instructions)
-            const float inv = 1.f/(float)sub;
-            const int W = R/sub, px = r/sub;
-            const size_t na = (size_t)n*A + a;
-            if (COLOUR && late->out.obs_rgb) {
-                late->out.obs_rgb[(na*3 + 0)*W + px] = p0*inv;
-                late->out.obs_rgb[(na*3 + 1)*W + px] = p1*inv;
-                late->out.obs_rgb[(na*3 + 2)*W + px] = p2*inv;
-            }
-            if (late->out.obs_depth) late->out.obs_depth[na*W + px] = pd*inv;
-        }
-    }
-    };
     if constexpr (NG == 1) {
         float4 hw_mem; int tex_w, tstart;
         winner_of(nearest_idx, hw_mem, tex_w, tstart);
         finish_group(0, r, rx, ry, rlen, nearest_s, nearest_idx, hw_mem, tex_w, tstart);
-    } else {
-        // Group after group, one step ahead with the loads: while a group is shaded the next one's winner rows travel.
-        // (the rays' directions and the groups' answers where the raycast left them in LDS: see the block's layout there)
-        const float2* const s_ray_w = reinterpret_cast<const float2*>(&s_raw[wave][24*MS_VCAP]);
-        const unsigned long long* const s_best_w = reinterpret_cast<const unsigned long long*>(&s_raw[wave][24*MS_VCAP + 768*NG + 256]);
-        unsigned long long key = s_best_w[lane];
-        float4 n_hw; int n_tw, n_ts;
-        winner_of((int)(uint32_t)key, n_hw, n_tw, n_ts);
-        #pragma unroll 1
-        for (int q = 0; q*WAVE < n_live; q++) {
-            const float4 hw_mem = n_hw;
-            const int tex_w = n_tw, tstart = n_ts;
-            const float ns = bits_f((uint32_t)(key >> 32));
-            const int ni = (int)(uint32_t)key;
-            const float2 rq = s_ray_w[q*WAVE + lane];
-            if ((q + 1)*WAVE < n_live) {
-                key = s_best_w[(q + 1)*WAVE + lane];
-                winner_of((int)(uint32_t)key, n_hw, n_tw, n_ts);
-            }
-            finish_group(q, r + q*WAVE, rq.x, rq.y, ray_len(rq.x, rq.y), ns, ni, hw_mem, tex_w, tstart);
-            __builtin_amdgcn_wave_barrier();
-        }
     }
     PROBE_DONE(fan)
 }
@@ -3776,9 +3951,16 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
-    // ray groups per wave (render_kernel's NG): one up to 64 rays, two up to 128, four beyond - an agent's waves share its
-    // side of the work instead of each repeating it.  (ms_debug_ray_groups: A/B runs and tests pin it.)
-    int ng = 1;                                                          // (measured: see DESIGN 3.6 - wider waves are not yet a gain)
+    // ray groups per wave (render_kernel's NG): an agent's groups of 64 rays share the wave's list of walls instead of each
+    // wave building its own.  (ms_debug_ray_groups: A/B runs and tests pin it.)
+    // Measured: four groups pay for colourless requests of 256 rays and up whose groups see much the same walls
+    // (a wave's 256 rays within 40 degrees: 4096 x 4 x 512 rays over 70 degrees, 127.1 -> 116.7 us) or whose envs have walls
+    // enough that listing them is most of a wave's work (the large floorplans: 151.4 -> 137.9 us at 256 rays over 130
+    // degrees; the small ones lose there, 25.0 -> 32.6 us), while the launch still fills the machine; two groups never do,
+    // and with colour the wave's registers run out (spills) and the gain goes with them.
+    int ng = 1;
+    if (!(out->screen || out->obs_rgb) && R >= 4*WAVE && (long long)sc->n_envs*sc->n_agents*((R + 4*WAVE - 1)/(4*WAVE)) >= 4096 &&
+        (cfg->fov*(4*WAVE) <= 40.f*R || sc->n_lines_total >= 640LL*sc->n_envs)) ng = 4;
     if (g_ray_groups == 1 || g_ray_groups == 2 || g_ray_groups == 4) ng = g_ray_groups;
 #if MS_AB_IMPLS
     if (getenv("MEGASTEP_RENDER_IMPL")) ng = 1;

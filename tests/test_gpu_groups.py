@@ -117,3 +117,22 @@ def test_first_sight_books_under_every_number_of_groups(groups):
             assert torch.equal(books[g].stamp, books[1].stamp) and torch.equal(books[g].tally, books[1].tally)
             assert torch.equal(obs[g][0], obs[1][0]) and torch.equal(obs[g][1], obs[1][1])
     assert books[4].tally.min() > 20
+
+
+def test_the_shape_where_ms_render_picks_four_groups_itself(groups):
+    """ms_render's own choice (four groups: colourless, 256 rays and up within 40 degrees, 4096 waves and more) against one group, bit for bit,
+    at a shape on the far side of that rule - and the same shape with colour, where it stays with one."""
+    from megastep_amd import cuda
+    c, _ = _world(2048, 2, 256, 30, seed=8)
+    rng = np.random.RandomState(2)
+    for _ in range(2):
+        util.random_velocities(c, rng)
+        cuda.physics(c.scenery, c.agents)
+    got = {}
+    for g in (0, 1):
+        groups(g)
+        d = cuda.render(c.scenery, c.agents, fields=('indices', 'locations', 'dots', 'distances'), pooled=dict(subsample=4, max_depth=8., rgb=False, centre=True))
+        f = cuda.render(c.scenery, c.agents)
+        got[g] = [d.indices.clone(), d.locations.clone(), d.dots.clone(), d.distances.clone(), d.obs_depth.float().clone(), d.obs_centre.clone(), f.screen.clone(), f.distances.clone()]
+    for x, y in zip(got[0], got[1]):
+        assert np.array_equal(_bits(x), _bits(y))

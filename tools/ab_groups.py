@@ -11,7 +11,8 @@ SHAPES = {'c3': dict(n=4096, a=4, res=128, fov=70., u=1024), 'r256': dict(n=4096
           'c5': dict(n=32768, a=1, res=256, fov=130., u=64, large=True, fast=True)}
 dev = bench._Gpu(0)
 h = _lib.lib()
-for name in sys.argv[1:] or list(SHAPES):
+DEPTH = '--depth-only' in sys.argv
+for name in [a for a in sys.argv[1:] if not a.startswith('--')] or list(SHAPES):
     sh = SHAPES[name]
     core, _ = bench.build_world(sh['n'], sh['a'], sh['res'], sh['fov'], dev.device, seed=1, n_unique=sh['u'], large=sh.get('large', False),
                                 fast=sh.get('fast', False))
@@ -22,8 +23,8 @@ for name in sys.argv[1:] or list(SHAPES):
         h.ms_debug_ray_groups(g)
         core.agents.angles.copy_(start[0]); core.agents.positions.copy_(start[1])
         core.agents.velocity.zero_(); core.agents.angvelocity.zero_()
-        m = bench.time_hot_path(dev, core, 20, 5, eager_floor=.05, graph_floor=.15)
-        print(f'{name:12s} groups {g}: {1e3*np.median(m["runs"])/20:.4f} ms/step, render {1e3*np.median(m["render_each"]):.1f} us (HIP events, eager)', flush=True)
+        m = bench.time_hot_path(dev, core, 20, 5, fields=('distances',) if DEPTH else None, eager_floor=.05, graph_floor=.15)
+        print(f'{name:12s}{" depth-only" if DEPTH else ""} groups {g}: {1e3*np.median(m["runs"])/20:.4f} ms/step, render {1e3*np.median(m["render_each"]):.1f} us (HIP events, eager)', flush=True)
     h.ms_debug_ray_groups(0)
     del core
     torch.cuda.empty_cache()
