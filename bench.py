@@ -47,6 +47,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# A knob of the HIP runtime, read when libamdhip64 loads (so: before torch is imported): kernel arguments of kernels
+# launched one by one go into device memory instead of host memory that every wave's first scalar load then crosses the
+# fabric for. Measured on boxes where the default is off: the eager leg's render launch 37.6 -> 34.9 us by HIP
+# events, the eager step 58.7 -> 54.4 us, Deathmatch's eager env.step +15 %; the HIP-graph replays (`value`) keep their
+# arguments in device memory either way and do not move; the host pays per launch for it (Explorer's eager env.step, which
+# is bound by the host's launches, -18 %; its graph +3 %). Set it to 0 to see the other side.
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -692,6 +700,7 @@ def main(argv=None):
                         + (' (large maps)' if args.large else ''),
             'step': 'ms_physics + ms_render (C-ABI), per-step velocities from random momentum actions resident in HBM',
             'launch': 'the K timed steps replayed as one HIP graph' if graph_s is not None else 'one Python call per kernel (eager)',
+            'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
             'envs_per_gpu': args.envs, 'envs_this_rank': N, 'envs_total': n_total, 'agents': A, 'res': args.res,
             'lines_per_env': scenery.lines.vals.shape[0]/N, 'lights_per_env': scenery.lights.vals.shape[0]/N,
             'distinct_floorplans_per_gpu': 460 if args.legacy_plans else n_unique,

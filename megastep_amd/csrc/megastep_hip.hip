@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     // (NG > 1: the list is shared by the wave's groups and must outlive their epilogues, whose scratch - the lighting's pair
     // list and shadow words, the RGB staging - therefore sits in the per-group region behind it, O_EPI, not on top of it)
     constexpr int O_EPI = (IMPL == 2 && NG > 1) ? 24*MS_VCAP + 256 : 0;
-    constexpr int LDS_PER_WAVE = IMPL != 2 ? 4864 : NG == 1 ? 24*MS_VCAP + 3072 : O_EPI + 3584;
+    constexpr int LDS_PER_WAVE = IMPL != 2 ? 4864 : NG == 1 ? 24*MS_VCAP + 3072 : O_EPI + 2816 + 6*MS_VCAP;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
