@@ -16,9 +16,13 @@ void ms_host_ray_interval(const float* pose, const float* line, int res, float f
  * rays of the agent's; first / count within that run. */
 void ms_host_ray_interval_wide(const float* pose, const float* line, int res, float fov, float agent_radius, int groups, int wave,
                                int* first, int* count);
-/* Pins the number of 64-ray groups a render wave serves (1, 2, 4; 0 = ms_render picks it from the resolution: 1 up to 64
- * rays, 2 up to 128, 4 beyond).  Process-wide; for A/B runs and tests - every setting produces the same bits. */
+/* Pins the number of 64-ray groups a render wave serves (1, 2, 4; 0 = ms_render picks it from the request: DESIGN 3.6).
+ * Process-wide; for A/B runs and tests - every setting produces the same bits. */
 int ms_debug_ray_groups(int groups);
+/* A launch of waves of several groups ends with waves of one group for its last envs; their share, in rounds of the machine's
+ * wave slots' worth of the wide waves' work (< 0: ms_render's own, half a round; 0: none; large: every env), or, if
+ * envs >= 0, that many envs exactly.  Process-wide; A/B runs and tests - every setting produces the same bits. */
+int ms_debug_ray_group_tail(float rounds, int envs);
 /* Has ms_render's waves add their (line, ray) pair and pair-window counts to workspace[3] and [4] (two atomics per wave on
  * one address: milliseconds at 10^5 waves - tools/pair_stats.py only).  Process-wide. */
 int ms_debug_pair_telemetry(int on);

@@ -54,6 +54,8 @@ constexpr int WAVES = WG/WAVE;
 thread_local int g_last_hip_error = 0;
 int g_pair_telemetry = 0;              // ms_debug_pair_telemetry
 int g_ray_groups = 0;                  // ms_debug_ray_groups: 0 = ms_render picks render_kernel's NG from the resolution
+float g_tail_rounds = -1.f;            // ms_debug_ray_group_tail: < 0 = ms_render's own share of one-group waves at the end of a launch of wide ones
+int g_tail_envs = -1;                  //   ... >= 0: that many envs exactly
 
 // -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
 // time stamps (s_memtime at its start, at a few points where something it waited for has arrived, at its end) and of
@@ -1118,6 +1120,8 @@ struct Divisor { unsigned mul, sh1, sh2; };
 struct RenderConsts {
     float x_clip, c_b;
     Divisor by_f, by_g, by_m;
+    Divisor by_f1, by_g1;          // render_kernel's NG > 1: the waves of one ray group at the end of every XCD's blocks (see there),
+    int envs_lo, envs_rem, tail;   //   an XCD's envs (n_envs/8, the first n_envs % 8 XCDs one more) and how many of them those waves take
     int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
     float inv_res;                 // 1/res where that is a power of two (x/res is then x*inv_res bit for bit), else 0
     int telemetry;                 // ms_debug_pair_telemetry: pair / window counts into workspace[3], [4]
@@ -1356,7 +1360,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
     const int lb = xcd*q8 + min(xcd, r8) + ix;      // (XCDs 0..r8-1 get a block more; no branch: a branch ends the stretch of
                                                     //  code hipcc gathers the kernel-argument loads of to its top)
-    const int fan = lb*RW + wave;
+    const int fan = NG == 1 ? lb*RW + wave : b;       // (NG > 1: the blocks' own order, see below)
     if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
 #ifdef MS_PARK
     // (-DMS_PARK=<shader clocks>, an experiment: every render wave sits out that long before it starts, as it would at the
@@ -1364,11 +1368,36 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     { const long long t0_ = clock64(); while (clock64() - t0_ < MS_PARK) __builtin_amdgcn_s_sleep(8); }
 #endif
     const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int G = (R + NR - 1)/NR, F = A*G;        // g: which run of NR rays of the agent's this wave casts
-    const int n = div_by(fan, rc.by_f), rem = fan - n*F, a = div_by(rem, rc.by_g), g = rem - a*G;
-    const int r0 = g*NR;
+    // Which rays of which agent: NG == 1, fan = (env, agent, run of 64 rays).  NG > 1, an XCD's blocks are in two parts: waves
+    // of NG groups for its envs but the last rc.tail, and behind them waves of ONE group for those.  A wave of four groups
+    // lives four times as long, and a launch of a few rounds of those ends with the machine draining for most of one such
+    // life; the short waves are what the slots that come free take up then (ms_render sizes the second part: about half a
+    // round of the long ones' work).
+    int n, a, r0, span;
+    if constexpr (NG == 1) {
+        const int G = (R + WAVE - 1)/WAVE, F = A*G;   // g: which run of 64 rays of the agent's this wave casts
+        n = div_by(fan, rc.by_f); const int rem = fan - n*F; a = div_by(rem, rc.by_g); r0 = (rem - a*G)*WAVE; span = WAVE;
+    } else {
+        // (XCD x takes blocks x, x + 8, ...: it is given a contiguous run of envs - an eighth of them, the first N mod 8 XCDs one
+        // more - so that an env's waves and their lines stay behind one L2, its wide waves first and then the single ones of
+        // its last envs; an XCD with an env fewer than the others lets its last blocks go)
+        const int e_x = rc.envs_lo + (xcd < rc.envs_rem ? 1 : 0), first_x = xcd*rc.envs_lo + min(xcd, rc.envs_rem);
+        const int t_x = min(rc.tail, e_x);
+        const int Gw = (R + NR - 1)/NR, w_x = (e_x - t_x)*A*Gw;
+        const bool single = ix >= w_x;
+        const int f = single ? ix - w_x : ix;
+        const int G = single ? (R + WAVE - 1)/WAVE : Gw, F = A*G;
+        const Divisor df = Divisor{single ? rc.by_f1.mul : rc.by_f.mul, single ? rc.by_f1.sh1 : rc.by_f.sh1, single ? rc.by_f1.sh2 : rc.by_f.sh2};
+        const Divisor dg = Divisor{single ? rc.by_g1.mul : rc.by_g.mul, single ? rc.by_g1.sh1 : rc.by_g.sh1, single ? rc.by_g1.sh2 : rc.by_g.sh2};
+        const int nn = div_by(f, df), rem = f - nn*F;
+        if (nn >= (single ? t_x : e_x - t_x)) return;
+        a = div_by(rem, dg);
+        n = first_x + (single ? e_x - t_x : 0) + nn;
+        span = single ? WAVE : NR;
+        r0 = (rem - a*G)*span;
+    }
     const int r = r0 + lane;                       // (this lane's ray in the wave's first group)
-    const int r_last = min(r0 + NR - 1, R - 1);
+    const int r_last = min(r0 + span - 1, R - 1);
     [[maybe_unused]] const int n_live = r_last - r0 + 1;
 
     const int L = sc.lines_widths[n];
@@ -1473,7 +1502,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     // --- draw: the wave of ray group 0 publishes its agent's model lines (kernels.cu:316-317).
     // Nobody reads them back from memory in this launch: every wave re-derives the agent lines it
     // needs (same inputs, same operations, same bits), so there is no cross-wave ordering to keep.
-    if (g == 0) {
+    if (r0 == 0) {
         for (int m0 = 0; m0 < sc.n_model; m0 += WAVE) {
             const float4 w = agent_line_m(a*sc.n_model + m0 + lane, m0 == 0, mdl_draw);
             if (m0 + lane < sc.n_model) ln[a*sc.n_model + m0 + lane] = w;
@@ -1743,7 +1772,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         s_best_w[lane] = ~0ull;
         s_second_w[lane] = ~0ull;
         s_third_w[lane] = ~0ull;
-        const float last_local = (float)(r_last - g*WAVE);    // last live ray of this wave
+        const float last_local = (float)(r_last - r0);    // last live ray of this wave
         // pass 1 for one line (lane = line): the ray-independent half of the intersection into LDS, and the
         // conservative interval [lo, lo + len) of this wave's rays that can hit it
         auto line_setup = [&](const int c0, int& lo, int& len) {       // every lane comes in; dead ones leave with len 0
@@ -3769,6 +3798,7 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
 #endif
 
 int ms_debug_ray_groups(int groups) { g_ray_groups = groups; return MS_OK; }
+int ms_debug_ray_group_tail(float rounds, int envs) { g_tail_rounds = rounds; g_tail_envs = envs; return MS_OK; }
 int ms_debug_pair_telemetry(int on) { g_pair_telemetry = on ? 1 : 0; return MS_OK; }
 
 void ms_host_ray_interval_wide(const float* pose, const float* line, int res, float fov, float agent_radius, int groups, int wave,
@@ -3975,22 +4005,41 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const int R = cfg->res;
     // ray groups per wave (render_kernel's NG): an agent's groups of 64 rays share the wave's list of walls instead of each
     // wave building its own.  (ms_debug_ray_groups: A/B runs and tests pin it.)
-    // Measured: four groups pay for colourless requests of 256 rays and up whose groups see much the same walls
-    // (a wave's 256 rays within 40 degrees: 4096 x 4 x 512 rays over 70 degrees, 127.1 -> 116.7 us) or whose envs have walls
-    // enough that listing them is most of a wave's work (the large floorplans: 151.4 -> 137.9 us at 256 rays over 130
-    // degrees; the small ones lose there, 25.0 -> 32.6 us), while the launch still fills the machine; two groups never do,
-    // and with colour the wave's registers run out (spills) and the gain goes with them.
+    // Measured: four groups pay from 256 rays up - a quarter of the vector instructions saved without colour, a
+    // sixth with - IF the launch has two and a half rounds of such waves to fill the machine with and its last envs are left to
+    // waves of one group (below): 4096 x 4 x 512 rays 157.5 -> 146.7 us (colourless 127.4 -> 110.4), C5's share
+    // 216.7 -> 207.9 (152.8 -> 132.2); with a round or less of them - 4096 x 1 x 256 rays - a quarter is LOST.  Two groups
+    // never pay.
+    static int slots = 0;                                                // the machine's wave slots for this kernel
+    if (!slots) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = cus*4*MS_WAVES;
+    }
     int ng = 1;
-    if (!(out->screen || out->obs_rgb) && R >= 4*WAVE && (long long)sc->n_envs*sc->n_agents*((R + 4*WAVE - 1)/(4*WAVE)) >= 4096 &&
-        (cfg->fov*(4*WAVE) <= 40.f*R || sc->n_lines_total >= 640LL*sc->n_envs)) ng = 4;
+    if (R >= 4*WAVE && 2LL*sc->n_envs*sc->n_agents*((R + 4*WAVE - 1)/(4*WAVE)) >= 5LL*slots) ng = 4;   // (2.5 rounds, the one-group waves' half included)
     if (g_ray_groups == 1 || g_ray_groups == 2 || g_ray_groups == 4) ng = g_ray_groups;
 #if MS_AB_IMPLS
     if (getenv("MEGASTEP_RENDER_IMPL")) ng = 1;
 #endif
     // (without a light grid the rays that land on an agent are lit by dynlight_kernel, which takes them by groups of 64)
     if (!(sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f) && sc->n_agents > 1 && (out->screen || out->obs_rgb)) ng = 1;
+    // (NG > 1: waves of ng groups for every XCD's envs but its last `tail`, waves of one group for those - render_kernel has
+    // why.  Their share: g_tail_rounds rounds of the machine's wave slots' worth of the wide waves' work, half a round unless
+    // ms_debug_ray_group_tail says otherwise.)
+    int tail = 0;
+    const int G1 = (R + WAVE - 1)/WAVE;
+    const int envs_lo = sc->n_envs/8, envs_rem = sc->n_envs % 8, envs_hi = envs_lo + (envs_rem ? 1 : 0);
+    if (ng > 1) {
+        const double rounds = g_tail_rounds >= 0.f ? (double)g_tail_rounds : 0.5;
+        const long long tail_envs = g_tail_envs >= 0 ? g_tail_envs : (long long)ceil(rounds*slots*ng/((double)sc->n_agents*G1));
+        tail = (int)std::min<long long>((tail_envs + 7)/8, envs_hi);                        // per XCD
+        if (tail >= envs_hi && !(g_ray_groups > 1)) ng = 1;           // nothing left for the wide waves: the plain kernel
+    }
     const int G = (R + ng*WAVE - 1)/(ng*WAVE);
-    const long long n_fans = (long long)sc->n_envs*sc->n_agents*G;
+    // (NG > 1: every XCD as many blocks as the one with the most envs needs)
+    const long long n_fans = ng > 1 ? 8LL*((long long)(envs_hi - std::min(tail, envs_hi))*sc->n_agents*G + (long long)std::min(tail, envs_hi)*sc->n_agents*G1)
+                                    : (long long)sc->n_envs*sc->n_agents*G;
     if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
     // kernels.cu:22
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
@@ -4045,6 +4094,9 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.by_f = divisor_of((unsigned)(sc->n_agents*G));
     rc.by_g = divisor_of((unsigned)G);
     rc.by_m = divisor_of((unsigned)sc->n_model);
+    rc.by_f1 = divisor_of((unsigned)(sc->n_agents*G1));
+    rc.by_g1 = divisor_of((unsigned)G1);
+    rc.envs_lo = envs_lo; rc.envs_rem = envs_rem; rc.tail = tail;
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
     rc.inv_res = ((R & (R - 1)) == 0 && half_screen > 1e-3f) ? 1.f/(float)R : 0.f;
     rc.telemetry = g_pair_telemetry;

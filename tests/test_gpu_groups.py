@@ -18,8 +18,14 @@ def _bits(t):
 def groups():
     from megastep_amd import _lib
     h = _lib.lib()
-    yield h.ms_debug_ray_groups
+
+    def pin(g, tail_envs=0):
+        """g groups per wave for all but the last `tail_envs` envs, whose waves serve one (-1: as ms_render sizes that share)"""
+        h.ms_debug_ray_groups(g)
+        h.ms_debug_ray_group_tail(-1., tail_envs)
+    yield pin
     h.ms_debug_ray_groups(0)
+    h.ms_debug_ray_group_tail(-1., -1)
 
 
 def _same(a, b, what):
@@ -47,6 +53,11 @@ def test_every_number_of_ray_groups_per_wave_gives_the_oracles_render(groups, n_
             util.assert_render_matches(c, frames[g], want)
         for g in (1, 2, 4):
             _same(frames[g], frames[0], (g, step))
+        # a launch of wide waves that ends in one-group waves: for its last env, for all but its first, for every env
+        for g in (2, 4):
+            for tail in (1, c.n_envs - 1, c.n_envs, -1):
+                groups(g, tail)
+                _same(cuda.render(c.scenery, c.agents), frames[0], (g, step, tail))
         # the pooled observations, the crosshair ids, the colourless instantiation and a partial set of planes too
         if res % 4 == 0 and res >= 8:
             pooled = {}
@@ -120,19 +131,41 @@ def test_first_sight_books_under_every_number_of_groups(groups):
 
 
 def test_the_shape_where_ms_render_picks_four_groups_itself(groups):
-    """ms_render's own choice (four groups: colourless, 256 rays and up within 40 degrees, 4096 waves and more) against one group, bit for bit,
-    at a shape on the far side of that rule - and the same shape with colour, where it stays with one."""
+    """ms_render's own choice (four groups from 256 rays up when there are two and a half rounds of such waves, the last envs
+    left to one-group waves) against one group, bit for bit, at a shape on the far side of that rule, with and without colour."""
     from megastep_amd import cuda
-    c, _ = _world(2048, 2, 256, 30, seed=8)
+    c, _ = _world(4096, 4, 256, 70, seed=8)
     rng = np.random.RandomState(2)
     for _ in range(2):
         util.random_velocities(c, rng)
         cuda.physics(c.scenery, c.agents)
     got = {}
     for g in (0, 1):
-        groups(g)
+        groups(g, -1)
         d = cuda.render(c.scenery, c.agents, fields=('indices', 'locations', 'dots', 'distances'), pooled=dict(subsample=4, max_depth=8., rgb=False, centre=True))
         f = cuda.render(c.scenery, c.agents)
-        got[g] = [d.indices.clone(), d.locations.clone(), d.dots.clone(), d.distances.clone(), d.obs_depth.float().clone(), d.obs_centre.clone(), f.screen.clone(), f.distances.clone()]
+        p = cuda.render(c.scenery, c.agents, fields=(), pooled=dict(subsample=4, max_depth=8.))
+        got[g] = [d.indices.clone(), d.locations.clone(), d.dots.clone(), d.distances.clone(), d.obs_depth.float().clone(), d.obs_centre.clone(), f.screen.clone(),
+                  f.distances.clone(), p.obs_rgb.float().clone(), p.obs_depth.float().clone()]
     for x, y in zip(got[0], got[1]):
         assert np.array_equal(_bits(x), _bits(y))
+
+
+@pytest.mark.parametrize('n_envs', [21, 64, 9])
+def test_wide_and_single_waves_share_a_launch_whatever_the_envs_per_xcd(groups, n_envs):
+    """Every XCD's blocks: wide waves for its envs but the last few, one-group waves for those; XCDs with an env fewer than
+    the others let their spare blocks go.  Env counts that split unevenly over the eight, every size of that share."""
+    from megastep_amd import cuda
+    c, _ = _world(n_envs, 2, 320, 100, seed=12)
+    rng = np.random.RandomState(3)
+    util.random_velocities(c, rng)
+    cuda.physics(c.scenery, c.agents)
+    groups(1)
+    want = cuda.render(c.scenery, c.agents)
+    wantd = cuda.render(c.scenery, c.agents, fields=('distances', 'indices'))
+    for g in (2, 4):
+        for tail in (0, 1, 8, 9, 16, 17, n_envs, -1):
+            groups(g, tail)
+            _same(cuda.render(c.scenery, c.agents), want, (g, tail))
+            d = cuda.render(c.scenery, c.agents, fields=('distances', 'indices'))
+            assert np.array_equal(_bits(d.distances), _bits(wantd.distances)) and np.array_equal(_bits(d.indices), _bits(wantd.indices)), (g, tail)
