@@ -25,9 +25,9 @@ def _ab_switches():
     g = os.environ.get('MEGASTEP_RAY_GROUPS')
     if g:
         _lib.lib().ms_debug_ray_groups(int(g))           # 64-ray groups per render wave: 1, 2, 4 (default: by resolution)
-    t = os.environ.get('MEGASTEP_RAY_GROUP_TAIL')
-    if t:
-        _lib.lib().ms_debug_ray_group_tail(float(t), -1)     # the one-group waves at the end of a launch of wide ones, in rounds
+    t, e = os.environ.get('MEGASTEP_RAY_GROUP_TAIL'), os.environ.get('MEGASTEP_RAY_GROUP_TAIL_ENVS')
+    if t or e:                                           # the one-group waves at the end of a launch of wide ones: in rounds / in envs
+        _lib.lib().ms_debug_ray_group_tail(float(t) if t else -1., int(e) if e else -1)
 
 
 def initialize(agent_radius, res, fov, fps):
