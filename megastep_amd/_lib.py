@@ -78,15 +78,18 @@ SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_ray_gro
 def _source_hash():
     import hashlib
     h = hashlib.sha256()
-    for path in (os.path.join(CSRC, 'megastep_hip.hip'), os.path.join(_HERE, '..', 'include', 'megastep_hip.h'),
-                 os.path.join(_HERE, '..', 'include', 'megastep_hip_test.h'), os.path.join(CSRC, 'Makefile')):
+    import glob
+    # (the Makefile's SOURCES, in its order: the translation unit, the kernel files it includes, the two headers, itself)
+    for path in (os.path.join(CSRC, 'megastep_hip.hip'), *sorted(glob.glob(os.path.join(CSRC, 'kernels', '*.h'))),
+                 os.path.join(_HERE, '..', 'include', 'megastep_hip.h'), os.path.join(_HERE, '..', 'include', 'megastep_hip_test.h'),
+                 os.path.join(CSRC, 'Makefile')):
         with open(path, 'rb') as f:
             h.update(f.read())
     return h.hexdigest()
 
 
 def build(force=False):
-    """Compiles csrc/megastep_hip.hip for gfx950 with hipcc (cross-compiles without a GPU). The library is stale when
+    """Compiles csrc/megastep_hip.hip (and the csrc/kernels/*.h it includes) for gfx950 with hipcc (cross-compiles without a GPU). The library is stale when
     the hash of its sources differs from the one the Makefile recorded next to it (mtimes do not survive copies);
     concurrent callers (one rank per GPU) serialise on a lock file."""
     import fcntl
