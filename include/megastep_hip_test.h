@@ -19,6 +19,10 @@ void ms_host_ray_interval_wide(const float* pose, const float* line, int res, fl
 /* Pins the number of 64-ray groups a render wave serves (1, 2, 4; 0 = ms_render picks it from the request: DESIGN 3.6).
  * Process-wide; for A/B runs and tests - every setting produces the same bits. */
 int ms_debug_ray_groups(int groups);
+/* Pins the number of envs a physics wave takes side by side (physics_kernel's PACK; 0 = ms_step_physics picks it from the
+ * world's size, 1 = one, k = k where k x n_agents <= 64 and there is a wall grid, else one).  Process-wide; A/B runs and
+ * tests - every setting produces the same bits. */
+int ms_debug_physics_pack(int envs);
 /* A launch of waves of several groups ends with waves of one group for its last envs; their share, in rounds of the machine's
  * wave slots' worth of the wide waves' work (< 0: ms_render's own, half a round; 0: none; large: every env), or, if
  * envs >= 0, that many envs exactly.  Process-wide; A/B runs and tests - every setting produces the same bits. */

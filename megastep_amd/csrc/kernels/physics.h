@@ -23,16 +23,26 @@ constexpr int PHYS_PAIRS = (PHYS_FEW + 1)*WAVE;   // capacity of a wave's (wall,
 
 // MOVE = 1: the movement modules' velocity update runs first (MsMovement), on the state this wave is loading anyway
 // EXTRA = 1: the environment's bookkeeping (MsStepExtras: lifespans, respawns, IMU) runs in the same launch
-template <int MOVE, int EXTRA>
+// PACK = 1: a wave takes `pack_envs` consecutive envs side by side (ms_step_physics: worlds of several rounds of waves with a
+//   wall grid and few agents per env - 32768 envs of one agent are 5.3 rounds of waves with a lane or two at work; eight envs
+//   to a wave they are two thirds of one).  The (N, A) arrays are row-major, so the wave's agents are consecutive rows of
+//   every one of them: lane = agent as before, `A` the wave's agents (pack_envs x n_agents <= 64), and only what is per env -
+//   who can run into whom, whose cell lists, which env falls back to meeting all its walls - looks at lane / n_agents.
+template <int MOVE, int EXTRA, int PACK = 0>
 __global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex) {
+        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex, const int pack_envs) {
     PROBE_INIT
     extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
     __shared__ float4 s_wall[PHYS_PAIRS];        // walls near ...
     __shared__ int s_tag[PHYS_PAIRS];            // ... this agent
-    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    const int lane = threadIdx.x, n = blockIdx.x;                        // the host launches one wave per env
+    const int A1 = sc.n_agents, AF = sc.n_agents*sc.n_model;            // agents per env
+    const int lane = threadIdx.x;
+    const int n = PACK ? blockIdx.x*pack_envs : blockIdx.x;              // the host launches one wave per env (PACK: per pack_envs envs; n: the first)
+    const int E = PACK ? min(pack_envs, sc.n_envs - n) : 1;
+    const int A = PACK ? A1*E : A1;                                      // the wave's agents: rows nA .. nA + A - 1 of every (N, A) array
+    const int nA = n*A1;
+    [[maybe_unused]] const int lane_env = PACK ? min(lane/A1, E - 1) : 0;
     float4* s_task = s_dyn;
     float4* s_box = s_task + A;
     float* s_reach2 = reinterpret_cast<float*>(s_box + A);
@@ -52,8 +62,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     // (the env's row of the wall grid, asked for with its other rows - where it is used, once the agents' positions are
     // known, it would be one more round trip; unconditionally: without a grid ms_step_physics points the two at rows
     // that exist)
-    const float4 wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n];
-    const int wg_start_n = sc.wg_starts[n];
+    const float4 wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n + lane_env];   // (PACK: the lane's env's, not the wave's)
+    const int wg_start_n = sc.wg_starts[n + lane_env];
     float4 w[PHYS_AHEAD];
     #pragma unroll
     for (int k = 0; k < PHYS_AHEAD; k++) w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     float2 my_p, my_v;
     float my_w, my_ang;
     my_p = make_float2(0.f, 0.f); my_v = make_float2(0.f, 0.f); my_w = 0.f; my_ang = 0.f;
-    if (lane < A) { my_p = pos2[n*A + lane]; my_v = vel2[n*A + lane]; my_w = ag.angvelocity[n*A + lane]; my_ang = ag.angles[n*A + lane]; }
+    if (lane < A) { my_p = pos2[nA + lane]; my_v = vel2[nA + lane]; my_w = ag.angvelocity[nA + lane]; my_ang = ag.angles[nA + lane]; }
 
     // the spawn pose of agent i, if it is to be respawned (modules.py:321-326)
     auto spawn_pose = [&](const int i, float2& p, float& ang) {
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     };
     if constexpr (EXTRA == 1) {
         for (int t = lane; t < A; t += WAVE) {
-            const int i = n*A + t;
+            const int i = nA + t;
             bool reset = ex.respawn_mask && ex.respawn_mask[i];
             if (ex.lifespans) {                                          // modules.py:361-366
                 int life = ex.lifespans[i] + 1;
@@ -117,23 +127,23 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
         {
             // (every lane looks an action up - its agent's, or the last agent's again: the lanes exchange table entries, which
             // only works among lanes that are all there)
-            const long long act = min(max(mv.actions[n*A + min(lane, A - 1)], 0ll), (long long)mv.n_actions - 1);
+            const long long act = min(max(mv.actions[nA + min(lane, A - 1)], 0ll), (long long)mv.n_actions - 1);
             float dx, dy, dw;
             if (small_table) { dx = __shfl(tab, 3*(int)act, WAVE); dy = __shfl(tab, 3*(int)act + 1, WAVE); dw = __shfl(tab, 3*(int)act + 2, WAVE); }
             else { dx = mv.table[3*act]; dy = mv.table[3*act + 1]; dw = mv.table[3*act + 2]; }
-            if (lane < A) moved(n*A + lane, my_ang, my_v, my_w, dx, dy, dw);
+            if (lane < A) moved(nA + lane, my_ang, my_v, my_w, dx, dy, dw);
         }
         for (int t = lane + WAVE; t < A; t += WAVE) {                   // agents beyond the first 64: through memory
-            float2 v = vel2[n*A + t];
-            float w = ag.angvelocity[n*A + t];
-            const long long act = min(max(mv.actions[n*A + t], 0ll), (long long)mv.n_actions - 1);
-            moved(n*A + t, ag.angles[n*A + t], v, w, mv.table[3*act], mv.table[3*act + 1], mv.table[3*act + 2]);
+            float2 v = vel2[nA + t];
+            float w = ag.angvelocity[nA + t];
+            const long long act = min(max(mv.actions[nA + t], 0ll), (long long)mv.n_actions - 1);
+            moved(nA + t, ag.angles[nA + t], v, w, mv.table[3*act], mv.table[3*act + 1], mv.table[3*act + 2]);
         }
     }
     float4 my_box = make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);   // (no agent: a box no finite wall touches)
     float my_reach = 0.f;
     for (int t = lane; t < A; t += WAVE) {
-        const float2 pp = (t == lane) ? my_p : pos2[n*A + t], mm = (t == lane) ? my_v : vel2[n*A + t];
+        const float2 pp = (t == lane) ? my_p : pos2[nA + t], mm = (t == lane) ? my_v : vel2[nA + t];
         const P2 p0 = p2(pp.x, pp.y);
         const P2 v0 = p2(mm.x, mm.y)/fps;
         const float reach = wall_reach(p0, v0, agent_radius);
@@ -151,8 +161,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     // ... and the agent-agent tests (kernels.cu:193-200), one ordered pair per lane
     // (behind agents_apart(): agents of one env are mostly rooms apart, and then no lane of the wave goes into the test at
     // all - a fifth of a physics wave's instructions)
-    for (int i = lane; i < A*A; i += WAVE) {
-        const int t = i / A, d1 = i - t*A;
+    for (int i = lane; i < A*A1; i += WAVE) {                            // (t, one of its env's agents)
+        const int t = i / A1, d1 = (PACK ? (t / A1)*A1 : 0) + i - t*A1;
         if (d1 != t) {
             const float4 me = s_task[t], o = s_task[d1];
             if (!agents_apart(me, o, agent_radius)) {
@@ -205,7 +215,13 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             count = ok ? (int)((my_reach <= sc.wg_reach_lo) ? (hdr.w & 0xffffu) : (hdr.w >> 16)) : 0;
         }
         PROBE_AT(2, count)                                                   // ... the cells' headers
-        if (!__ballot(!ok)) {
+        const unsigned long long uncovered = __ballot(!ok);
+        [[maybe_unused]] const unsigned long long env_lanes = A1 >= WAVE ? ~0ull : (1ull << A1) - 1ull;
+        if constexpr (PACK == 1) {
+            // (an env with an agent its lists do not cover meets all its walls, further down; the wave's other envs go by theirs)
+            if (uncovered & (env_lanes << (lane_env*A1))) count = 0;
+        }
+        if (PACK == 1 || !uncovered) {
             swept = false;
             const int incl = wave_scan_add(count);
             const int excl = incl - count;
@@ -241,6 +257,20 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
                 }
             }
             if (cnt) flush();
+            if constexpr (PACK == 1) {
+                for (int e = 0; e < E; e++) {
+                    if (!((uncovered >> (e*A1)) & env_lanes)) continue;
+                    // (rare, and plain: every wall of the env to every agent of it - meet() has the reach cull on the true
+                    // distance in front of the exact test, which is all the sweep's boxes stand in for)
+                    const int Le = sc.lines_widths[n + e];
+                    const LineRows rows_e(reinterpret_cast<const float4*>(sc.lines_vals) + sc.lines_starts[n + e], Le);
+                    for (int l0 = AF; l0 < Le; l0 += WAVE) {
+                        const float4 u = rows_e.chunk(lane, l0);
+                        if (l0 + lane < Le)
+                            for (int t = e*A1; t < (e + 1)*A1; t++) meet(u, t);
+                    }
+                }
+            }
         } else {
             #pragma unroll
             for (int k = 0; k < PHYS_AHEAD; k++) w[k] = rows.chunk(lane, AF + k*WAVE);
@@ -312,7 +342,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     float2* pos2w = reinterpret_cast<float2*>(ag.positions);
     float2* vel2w = reinterpret_cast<float2*>(ag.velocity);
     for (int t = lane; t < A; t += WAVE) {
-        const int i = n*A + t;
+        const int i = nA + t;
         const float x = bits_f(s_prog[t]);
         float2 p = my_p, v = my_v;
         float w_ = my_w, ang = my_ang;

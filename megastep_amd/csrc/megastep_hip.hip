@@ -58,6 +58,7 @@ constexpr int WAVES = WG/WAVE;
 thread_local int g_last_hip_error = 0;
 int g_pair_telemetry = 0;              // ms_debug_pair_telemetry
 int g_ray_groups = 0;                  // ms_debug_ray_groups: 0 = ms_render picks render_kernel's NG from the resolution
+int g_physics_pack = 0;                 // ms_debug_physics_pack: 0 = ms_step_physics picks the envs a physics wave takes side by side, k >= 1 = k
 float g_tail_rounds = -1.f;            // ms_debug_ray_group_tail: < 0 = ms_render's own share of one-group waves at the end of a launch of wide ones
 int g_tail_envs = -1;                  //   ... >= 0: that many envs exactly
 
@@ -166,6 +167,7 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
 #endif
 
 int ms_debug_ray_groups(int groups) { g_ray_groups = groups; return MS_OK; }
+int ms_debug_physics_pack(int envs) { g_physics_pack = envs; return MS_OK; }
 int ms_debug_ray_group_tail(float rounds, int envs) { g_tail_rounds = rounds; g_tail_envs = envs; return MS_OK; }
 int ms_debug_pair_telemetry(int on) { g_pair_telemetry = on ? 1 : 0; return MS_OK; }
 
@@ -328,8 +330,19 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
         if (ex->lifespans && (!ex->max_lifespans || !ex->fresh_max)) return MS_EINVAL;
         if (ex->imu && !(ex->imu_ang_scale == ex->imu_ang_scale && ex->imu_speed_scale == ex->imu_speed_scale)) return MS_EINVAL;
     }
-    // per env: 2 float4 + a float + an unsigned per agent, rounded up to whole float4s
-    const size_t slice = ((sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents + 15)/16;
+    // Envs per wave (physics_kernel's PACK), with a wall grid (without one an env's walls are streamed, and there is nothing to
+    // put side by side) and while a wave's agents stay within half its lanes: as many as bring the launch down to about 4096
+    // waves - 32768 envs of one agent are 5.3 rounds of waves with a lane or two at work each: 30.2 us; eight to a wave 9.7
+    // (four 13.6, sixteen 10.2); 16384 x 4 agents 22.2 -> 13.3, 8192 x 4 13.4 -> 10.2 - and two even at 4096 envs, where one
+    // round of short waves becomes half a round of waves twice as busy (8.7 -> 8.2 us, one agent per env 7.1 -> 6.4; four: 6.7).
+    int pack = 1;
+    if (sc->wg_cells && sc->n_agents <= 16) {
+        pack = sc->n_envs > 6144 ? std::min((sc->n_envs + 4095)/4096, 16) : sc->n_envs >= 3072 ? 2 : 1;
+        pack = std::max(std::min(pack, WAVE/2/sc->n_agents), 1);
+    }
+    if (g_physics_pack >= 1) pack = (sc->wg_cells && g_physics_pack*sc->n_agents <= WAVE) ? g_physics_pack : 1;
+    // per wave: 2 float4 + a float + an unsigned per agent, rounded up to whole float4s
+    const size_t slice = ((sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents*pack + 15)/16;
     if (slice*16 > 56*1024) return MS_EUNSUPPORTED;
     const MsMovement no_move{nullptr, nullptr, 0, 0.f};
     const MsStepExtras no_extras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
@@ -338,13 +351,15 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
     MsScenery scn = *sc;
     if (!sc->wg_cells) { scn.wg_geom = sc->lines_vals; scn.wg_starts = sc->lines_starts; }   // (rows the kernel may read: see there)
     const hipStream_t hs = (hipStream_t)stream;
-    // one wavefront per env (several envs per wave, one after the other: 2 -> +25 %, 4 -> +85 % at 4096 envs)
-#define MS_LAUNCH_PHYSICS(M, E) \
-    hipLaunchKernelGGL((physics_kernel<M, E>), dim3(sc->n_envs), dim3(WAVE), slice*16, hs, scn, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv)
-    if (mv && ex) MS_LAUNCH_PHYSICS(1, 1);
-    else if (ex) MS_LAUNCH_PHYSICS(0, 1);
-    else if (mv) MS_LAUNCH_PHYSICS(1, 0);
-    else MS_LAUNCH_PHYSICS(0, 0);
+    // one wavefront per env (several envs per wave, one AFTER the other: 2 -> +25 %, 4 -> +85 % at 4096 envs; side by side: PACK)
+#define MS_LAUNCH_PHYSICS_P(M, E, P) \
+    hipLaunchKernelGGL((physics_kernel<M, E, P>), dim3((sc->n_envs + pack - 1)/pack), dim3(WAVE), slice*16, hs, scn, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, pack)
+#define MS_LAUNCH_PHYSICS(M, E) { if (pack > 1) MS_LAUNCH_PHYSICS_P(M, E, 1); else MS_LAUNCH_PHYSICS_P(M, E, 0); }
+    if (mv && ex) MS_LAUNCH_PHYSICS(1, 1)
+    else if (ex) MS_LAUNCH_PHYSICS(0, 1)
+    else if (mv) MS_LAUNCH_PHYSICS(1, 0)
+    else MS_LAUNCH_PHYSICS(0, 0)
+#undef MS_LAUNCH_PHYSICS_P
 #undef MS_LAUNCH_PHYSICS
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);

@@ -25,6 +25,9 @@ def _ab_switches():
     g = os.environ.get('MEGASTEP_RAY_GROUPS')
     if g:
         _lib.lib().ms_debug_ray_groups(int(g))           # 64-ray groups per render wave: 1, 2, 4 (default: by resolution)
+    k = os.environ.get('MEGASTEP_PHYSICS_PACK')
+    if k:
+        _lib.lib().ms_debug_physics_pack(int(k))         # envs a physics wave takes side by side (default: by the world's size)
     t, e = os.environ.get('MEGASTEP_RAY_GROUP_TAIL'), os.environ.get('MEGASTEP_RAY_GROUP_TAIL_ENVS')
     if t or e:                                           # the one-group waves at the end of a launch of wide ones: in rounds / in envs
         _lib.lib().ms_debug_ray_group_tail(float(t) if t else -1., int(e) if e else -1)

@@ -59,7 +59,8 @@ def test_lists_built_on_the_gpu_are_the_host_scans():
     assert np.mean(fractions) < .6
 
 
-@pytest.mark.parametrize('n_agents,res,fov,large', [(4, 64, 130., False), (1, 256, 130., True), (3, 128, 70., False), (2, 64, 160., False)])
+@pytest.mark.parametrize('n_agents,res,fov,large', [(4, 64, 130., False), (1, 256, 130., True), (3, 128, 70., False), (2, 64, 160., False),
+                                                    (12, 64, 130., False)])   # (twelve agents: hundreds of (wall, agent) pairs an env - physics culls, compacts, then tests)
 def test_kernels_with_lists_leave_the_bits_of_kernels_without(n_agents, res, fov, large):
     from megastep_amd import cuda
     worlds = [_world(96, n_agents, res, fov, seed=3, n_unique=12, large=large, grid=g)[0] for g in (True, False)]
