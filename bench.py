@@ -536,7 +536,7 @@ def other_shapes(dev, steps=20, warmup=5):
     c = world('C2', 4096, 1, 64, 130., n_unique=plan_count(4096, 1))
     out['c2_rgbd'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 2 (Explorer shape, one floorplan per env) with all five planes')
     out['c2_depth_only'] = shape_entry(dev, c, steps, warmup, fields=('distances',),
-                                       note="BASELINE config 2 as stated: depth-only - render_kernel<2,1,1,0>, no shading pass")
+                                       note="BASELINE config 2 as stated: depth-only - render_kernel<2,1,1,0,1>, no shading pass")
     del c
     torch.cuda.empty_cache()
     c = world('C3', 4096, 4, 128, 70., n_unique=plan_count(4096, 4))
@@ -713,7 +713,10 @@ def main(argv=None):
         'eager': {'value': n_total*args.steps/eager_s, 'ms_per_step': 1e3*eager_s/args.steps, 'timed_regions': int(len(eager_runs)),
                   'step_ms_hip_events': {'min': float(step_ms.min()), 'median': float(np.median(step_ms)), 'max': float(step_ms.max())}},
         'roofline': {
-            'kernel': 'ms_render = render_kernel<2,1,%s> (headings cached by ms_physics)' % ('1,0' if args.depth_only else '0,1'),
+            # (<IMPL, RW, OBS, SHADE, NG>; NG - 64-ray groups per wave - as ms_render picks it: four from 256 rays up on launches
+            # of two and a half rounds of such waves)
+            'kernel': 'ms_render = render_kernel<2,1,%s,%d> (headings cached by ms_physics)' % (
+                '1,0' if args.depth_only else '0,1', 4 if args.res >= 256 and 2*core.n_envs*core.n_agents*((args.res + 255)//256) >= 5*6144 else 1),
             'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
