@@ -6,7 +6,8 @@
 //
 // Eleven kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
 //
-//   physics_kernel<MOVE, EXTRA>   one wavefront per env: lane = agent for the state, the reach and the agent-agent
+//   physics_kernel<MOVE, EXTRA, PACK>   one wavefront per env (PACK = 1: per few consecutive envs, side by side - large
+//                   worlds of few agents per env): lane = agent for the state, the reach and the agent-agent
 //                   tests; the walls from the near lists of the agents' cells of the wall grid (rows of the dozen walls
 //                   within reach, dealt to the lanes one (wall, agent) pair each) - or, where no list applies, a sweep
 //                   over all the env's walls (buffer loads in flight, lane = wall, reach boxes in scalar registers,
@@ -14,7 +15,9 @@
 //                   agent's sin/cos for the renderer.  MOVE = 1 runs the movement modules' velocity update first,
 //                   EXTRA = 1 the envs' respawn / lifespan / IMU bookkeeping.
 //                                                            (reference: kernels.cu:179-230, modules.py:24-118,263-366)
-//   render_kernel<IMPL, RW, OBS>   one wavefront per (env, agent, 64-ray group).  The lines it meets: the other agents'
+//   render_kernel<IMPL, RW, OBS, SHADE, NG>   one wavefront per (env, agent, 64-ray group) - or, NG = 4, per four such groups
+//                   that share one list of lines, the launch's last envs left to one-group waves (256 rays and up on large
+//                   launches; SHADE = 0: no shading pass, for callers that want no colour).  The lines it meets: the other agents'
 //                   and the walls on the vis list of the agent's cell of the wall grid, less those whose view arc misses
 //                   the wave's rays.  Pass 1 (lane = line) turns every line into a conservative interval of the wave's
 //                   rays and compacts the visible ones into an LDS list; pass 2 deals the (line, ray) pairs of the list
