@@ -1,5 +1,7 @@
-"""render_kernel's NG - how many 64-ray groups one wave serves (1 up to 64 rays, 2 up to 128, 4 beyond; ms_render picks) -
-changes who does the work, never the result: every setting against the oracle and against the others, bit for bit."""
+"""render_kernel's NG - how many 64-ray groups one wave serves (1, 2 or 4; ms_render picks 1 or 4) - and the split of a launch
+into wide waves and the one-group waves it ends with change who does the work, never the result: every setting against the oracle and against the others, bit for bit."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,7 +104,8 @@ def test_stacks_of_coincident_walls_under_every_number_of_groups(groups):
         frames[g] = cuda.render(c.scenery, c.agents, telemetry=True)
         util.assert_render_matches(c, frames[g], want)
         _, folded_rays, lane_parallel_waves = frames[g]._telemetry[:3].tolist()
-        assert folded_rays > 1000 and lane_parallel_waves > 5, (g, folded_rays, lane_parallel_waves)
+        if not os.environ.get('MEGASTEP_RENDER_IMPL'):                  # (the product raycast's counters: an A/B run under an older one has none)
+            assert folded_rays > 1000 and lane_parallel_waves > 5, (g, folded_rays, lane_parallel_waves)
     _same(frames[2], frames[1], 2); _same(frames[4], frames[1], 4)
 
 
