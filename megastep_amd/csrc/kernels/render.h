@@ -300,6 +300,13 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #ifndef MS_VCAP
 #define MS_VCAP 128
 #endif
+// ... and of a wave of several ray groups (NG > 1), whose block is 30 bytes a line + 3072.  LDS is handed out in granules of
+// 1280 bytes on gfx950: 128 lines (6912 B) cost six granules - 21 waves a CU where the registers allow 24 - and so do 112;
+// 110 (6372 B) fit five.  Measured (tools/ab_groups.py, four groups a wave): 512 rays 147.5 -> 138.4 us at 96 lines (80: 138.9;
+// 112, 120: 148), C5's share 201.0 -> 193.4 (80: 198.9 - its 1000-wall plans overflow a short list more often).
+#ifndef MS_VCAP_WIDE
+#define MS_VCAP_WIDE 110
+#endif
 __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVES, MS_WAVES))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
@@ -317,8 +324,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     constexpr int NR = WAVE*NG;                  // rays per wave
     // (NG > 1: the list is shared by the wave's groups and must outlive their epilogues, whose scratch - the lighting's pair
     // list and shadow words, the RGB staging - therefore sits in the per-group region behind it, O_EPI, not on top of it)
-    constexpr int O_EPI = (IMPL == 2 && NG > 1) ? 24*MS_VCAP + 256 : 0;
-    constexpr int LDS_PER_WAVE = IMPL != 2 ? 4864 : NG == 1 ? 24*MS_VCAP + 3072 : O_EPI + 2816 + 6*MS_VCAP;
+    constexpr int VCAP = NG == 1 ? MS_VCAP : MS_VCAP_WIDE;
+    constexpr int O_EPI = (IMPL == 2 && NG > 1) ? 24*VCAP + 256 : 0;
+    constexpr int LDS_PER_WAVE = IMPL != 2 ? 4864 : NG == 1 ? 24*VCAP + 3072 : O_EPI + 2816 + 6*VCAP;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[RW][LDS_PER_WAVE];
 
     // (with one wave per workgroup the wave index is spelled out as 0: hipcc cannot tell that threadIdx.x >> 6 is, and
@@ -976,7 +984,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         // LDS per wave (V = V_CAP lines):  cand (V x 16 B) | info (V x 8 B: first ray - first pair, line) | ray (64 x 8 B: rx, ry)
         //               | near (64 x 4 B) | queue (128 x 2 B) | best, second, third (64 x 8 B each) | marks (4096 bits)
         // ------------------------------------------------------------------------------------------
-        constexpr int V_CAP = MS_VCAP, P_CAP = 4096 < 64*MS_VCAP ? 4096 : 64*MS_VCAP;
+        constexpr int V_CAP = VCAP, P_CAP = 4096 < 64*VCAP ? 4096 : 64*VCAP;
         // NG > 1 (several ray groups a wave, one after the other on ONE group's worth of per-ray state):
         //   cand (V x 16 B) | info (V x 8 B: first ray | rays << 16 of the line's interval among the span's rays, line) | queue
         //   | per group, O_EPI on: ray, near, best, second, third, marks as above | pinfo (V x 4 B: first ray - first pair of
