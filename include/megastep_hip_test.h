@@ -23,6 +23,15 @@ int ms_debug_ray_groups(int groups);
  * world's size, 1 = one, k = k where k x n_agents <= 64 and there is a wall grid, else one).  Process-wide; A/B runs and
  * tests - every setting produces the same bits. */
 int ms_debug_physics_pack(int envs);
+/* The launch geometry ms_render / ms_step_physics decide on the host, and the render kernel's own block -> rays mapping
+ * (render_block), for tests that walk whole launches on the CPU.  `slots`: the machine's wave slots for the render kernel (CUs x
+ * 4 SIMDs x 6 waves; 6144 on MI355X); pinned_groups / tail_rounds / tail_envs as the ms_debug_* hooks (0 / < 0 / < 0: the rules).
+ * ms_host_render_plan returns the number of one-wave blocks and the ray groups per wave; ms_host_render_block fills out4 =
+ * (env, agent, first ray, rays) for block `block` and returns 1, or 0 for a spare block, -1 outside the launch.
+ * ms_host_physics_pack: the envs a physics wave takes side by side. */
+long long ms_host_render_plan(int n_envs, int n_agents, int res, int slots, int pinned_groups, float tail_rounds, int tail_envs, int* groups);
+int ms_host_render_block(int n_envs, int n_agents, int res, int slots, int pinned_groups, float tail_rounds, int tail_envs, long long block, int* out4);
+int ms_host_physics_pack(int n_envs, int n_agents, int gridded, int pinned);
 /* A launch of waves of several groups ends with waves of one group for its last envs; their share, in rounds of the machine's
  * wave slots' worth of the wide waves' work (< 0: ms_render's own, half a round; 0: none; large: every env), or, if
  * envs >= 0, that many envs exactly.  Process-wide; A/B runs and tests - every setting produces the same bits. */

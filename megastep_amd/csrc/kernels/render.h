@@ -113,9 +113,50 @@ __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     const unsigned long long m = ((1ull << 32)*((1ull << s) - d))/d + 1ull;
     return Divisor{(unsigned)m, s < 1u ? s : 1u, s > 1u ? s - 1u : 0u};
 }
-__device__ inline int div_by(int n, const Divisor d) {     // n >= 0
-    const unsigned t = __umulhi(d.mul, (unsigned)n);
+__host__ __device__ inline int div_by(int n, const Divisor d) {     // n >= 0
+    const unsigned t = (unsigned)(((unsigned long long)d.mul*(unsigned)n) >> 32);     // (the high word: one v_mul_hi_u32 / s_mul_hi_u32)
     return (int)((t + (((unsigned)n - t) >> d.sh1)) >> d.sh2);
+}
+
+// Which rays of which agent the one-wave block `b` of a render launch of `n_blocks` casts: env n, agent a, rays r0 .. r0 + span - 1
+// (those below R).  False: a spare block (see below).  The kernel's own mapping - and, through ms_host_render_block, what
+// tests/test_launch_geometry.py walks over whole launches on the CPU.
+//   ng == 1: block = (env, agent, run of 64 rays), dealt so that hardware block b - which lands on XCD b % 8 - gives each XCD a
+//     contiguous run of them: the fans of one env (and its lines) stay behind one L2.  (XCDs 0 .. n_blocks % 8 - 1 get a block
+//     more; no branch: a branch ends the stretch of code hipcc gathers the kernel-argument loads of to its top.)
+//   ng > 1: XCD x takes blocks x, x + 8, ... and is given a contiguous run of ENVS - an eighth of them, the first N mod 8 XCDs one
+//     more - its blocks in two parts: waves of ng groups for its envs but the last rc.tail, and behind them waves of ONE group
+//     for those.  A wave of four groups lives four times as long, and a launch of a few rounds of those ends with the machine
+//     draining for most of one such life; the short waves are what the slots that come free take up then (render_plan sizes the
+//     second part: about half a round of the long ones' work).  Every XCD has as many blocks as the one with the most envs
+//     needs: one with an env fewer lets its last blocks go.
+__host__ __device__ inline bool render_block(const int b, const int n_blocks, const int A, const int R, const int ng, const RenderConsts& rc,
+                                             int& n, int& a, int& r0, int& span, int& fan) {
+    const int xcd = b & 7, ix = b >> 3;
+    fan = b;                                                             // (ng == 1: the run's number, env-major, that dynlight_kernel's queue holds)
+    if (ng == 1) {
+        const int q8 = n_blocks >> 3, r8 = n_blocks & 7;
+        fan = xcd*q8 + (xcd < r8 ? xcd : r8) + ix;
+        const int G = (R + WAVE - 1)/WAVE, F = A*G;   // g: which run of 64 rays of the agent's this wave casts
+        n = div_by(fan, rc.by_f); const int rem = fan - n*F; a = div_by(rem, rc.by_g); r0 = (rem - a*G)*WAVE; span = WAVE;
+        return true;
+    }
+    const int NR = ng*WAVE;
+    const int e_x = rc.envs_lo + (xcd < rc.envs_rem ? 1 : 0), first_x = xcd*rc.envs_lo + (xcd < rc.envs_rem ? xcd : rc.envs_rem);
+    const int t_x = rc.tail < e_x ? rc.tail : e_x;
+    const int Gw = (R + NR - 1)/NR, w_x = (e_x - t_x)*A*Gw;
+    const bool single = ix >= w_x;
+    const int f = single ? ix - w_x : ix;
+    const int G = single ? (R + WAVE - 1)/WAVE : Gw, F = A*G;
+    const Divisor df = Divisor{single ? rc.by_f1.mul : rc.by_f.mul, single ? rc.by_f1.sh1 : rc.by_f.sh1, single ? rc.by_f1.sh2 : rc.by_f.sh2};
+    const Divisor dg = Divisor{single ? rc.by_g1.mul : rc.by_g.mul, single ? rc.by_g1.sh1 : rc.by_g.sh1, single ? rc.by_g1.sh2 : rc.by_g.sh2};
+    const int nn = div_by(f, df), rem = f - nn*F;
+    if (nn >= (single ? t_x : e_x - t_x)) return false;
+    a = div_by(rem, dg);
+    n = first_x + (single ? e_x - t_x : 0) + nn;
+    span = single ? WAVE : NR;
+    r0 = (rem - a*G)*span;
+    return true;
 }
 
 __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
@@ -321,7 +362,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     // IMPL 2 lays its block out differently (see there): 6144 B
     PROBE_INIT
     static_assert(NG == 1 || (IMPL == 2 && RW == 1 && (NG == 2 || NG == 4)), "several ray groups per wave: the product raycast, one wave per workgroup");
-    constexpr int NR = WAVE*NG;                  // rays per wave
+    [[maybe_unused]] constexpr int NR = WAVE*NG;  // rays per wave
     // (NG > 1: the list is shared by the wave's groups and must outlive their epilogues, whose scratch - the lighting's pair
     // list and shadow words, the RGB staging - therefore sits in the per-group region behind it, O_EPI, not on top of it)
     constexpr int VCAP = NG == 1 ? MS_VCAP : MS_VCAP_WIDE;
@@ -340,51 +381,28 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     Cand* const s_cand_w = reinterpret_cast<Cand*>(&s_raw[wave][0]);
     float* const s_screen_w = reinterpret_cast<float*>(&s_raw[wave][IMPL == 2 ? O_EPI : 4096]);   // (IMPL 2: the raycast is over by then)
 
-    // XCD-aware block order: hardware block b lands on XCD b % 8; give each XCD a contiguous run of
-    // logical blocks so the fans of one env (and its lines) stay behind one L2.
-    // (With one wave per workgroup the grid is exactly the fans - ms_render launches it so: the count comes from the
-    // kernel's own arguments, not from the dispatch packet, and there is no early exit - either of which is a round trip
-    // of its own before the loads below may even be asked for.)
-    const int nb = RW == 1 ? n_fans : (int)gridDim.x, b = blockIdx.x;
-    const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
-    const int lb = xcd*q8 + min(xcd, r8) + ix;      // (XCDs 0..r8-1 get a block more; no branch: a branch ends the stretch of
-                                                    //  code hipcc gathers the kernel-argument loads of to its top)
-    const int fan = NG == 1 ? lb*RW + wave : b;       // (NG > 1: the blocks' own order, see below)
-    if constexpr (RW != 1) { if (fan >= n_fans) return; }                // waves are independent: no workgroup barriers below
+    // (With one wave per workgroup the grid is exactly the blocks render_block() deals - ms_render launches it so: the count
+    // comes from the kernel's own arguments, not from the dispatch packet, and at one group per wave there is no early exit -
+    // either of which is a round trip of its own before the loads below may even be asked for.)
+    const int b = blockIdx.x;
+    [[maybe_unused]] int fan = b;                                        // (what the probe and the ablation builds label a wave with)
+    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
+    int n, a, r0, span;
+    if constexpr (RW == 1) {
+        if (!render_block(b, n_fans, A, R, NG, rc, n, a, r0, span, fan)) return;
+    } else {                                                             // (the A/B builds' older raycasts: several waves a workgroup)
+        const int nb = (int)gridDim.x;
+        const int q8 = nb >> 3, r8 = nb & 7, xcd = b & 7, ix = b >> 3;
+        fan = (xcd*q8 + min(xcd, r8) + ix)*RW + wave;
+        if (fan >= n_fans) return;                                       // waves are independent: no workgroup barriers below
+        const int G = (R + WAVE - 1)/WAVE, F = A*G;
+        n = div_by(fan, rc.by_f); const int rem = fan - n*F; a = div_by(rem, rc.by_g); r0 = (rem - a*G)*WAVE; span = WAVE;
+    }
 #ifdef MS_PARK
     // (-DMS_PARK=<shader clocks>, an experiment: every render wave sits out that long before it starts, as it would at the
     // barrier of a single-launch step whose first wave does the env's physics - what do parked waves cost a launch?)
     { const long long t0_ = clock64(); while (clock64() - t0_ < MS_PARK) __builtin_amdgcn_s_sleep(8); }
 #endif
-    const int A = sc.n_agents, AF = sc.n_agents*sc.n_model;
-    // Which rays of which agent: NG == 1, fan = (env, agent, run of 64 rays).  NG > 1, an XCD's blocks are in two parts: waves
-    // of NG groups for its envs but the last rc.tail, and behind them waves of ONE group for those.  A wave of four groups
-    // lives four times as long, and a launch of a few rounds of those ends with the machine draining for most of one such
-    // life; the short waves are what the slots that come free take up then (ms_render sizes the second part: about half a
-    // round of the long ones' work).
-    int n, a, r0, span;
-    if constexpr (NG == 1) {
-        const int G = (R + WAVE - 1)/WAVE, F = A*G;   // g: which run of 64 rays of the agent's this wave casts
-        n = div_by(fan, rc.by_f); const int rem = fan - n*F; a = div_by(rem, rc.by_g); r0 = (rem - a*G)*WAVE; span = WAVE;
-    } else {
-        // (XCD x takes blocks x, x + 8, ...: it is given a contiguous run of envs - an eighth of them, the first N mod 8 XCDs one
-        // more - so that an env's waves and their lines stay behind one L2, its wide waves first and then the single ones of
-        // its last envs; an XCD with an env fewer than the others lets its last blocks go)
-        const int e_x = rc.envs_lo + (xcd < rc.envs_rem ? 1 : 0), first_x = xcd*rc.envs_lo + min(xcd, rc.envs_rem);
-        const int t_x = min(rc.tail, e_x);
-        const int Gw = (R + NR - 1)/NR, w_x = (e_x - t_x)*A*Gw;
-        const bool single = ix >= w_x;
-        const int f = single ? ix - w_x : ix;
-        const int G = single ? (R + WAVE - 1)/WAVE : Gw, F = A*G;
-        const Divisor df = Divisor{single ? rc.by_f1.mul : rc.by_f.mul, single ? rc.by_f1.sh1 : rc.by_f.sh1, single ? rc.by_f1.sh2 : rc.by_f.sh2};
-        const Divisor dg = Divisor{single ? rc.by_g1.mul : rc.by_g.mul, single ? rc.by_g1.sh1 : rc.by_g.sh1, single ? rc.by_g1.sh2 : rc.by_g.sh2};
-        const int nn = div_by(f, df), rem = f - nn*F;
-        if (nn >= (single ? t_x : e_x - t_x)) return;
-        a = div_by(rem, dg);
-        n = first_x + (single ? e_x - t_x : 0) + nn;
-        span = single ? WAVE : NR;
-        r0 = (rem - a*G)*span;
-    }
     const int r = r0 + lane;                       // (this lane's ray in the wave's first group)
     const int r_last = min(r0 + span - 1, R - 1);
     [[maybe_unused]] const int n_live = r_last - r0 + 1;

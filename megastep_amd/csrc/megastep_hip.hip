@@ -113,6 +113,60 @@ struct Probe {
 #include "kernels/wallgrid.h"
 
 // ------------------------------------------------------------------------------------------------
+// launch geometry (host): what ms_render / ms_step_physics decide before a launch - also behind ms_host_render_plan /
+// ms_host_physics_pack, so that tests walk whole launches on the CPU (tests/test_launch_geometry.py)
+// ------------------------------------------------------------------------------------------------
+// Ray groups per wave (render_kernel's NG): an agent's groups of 64 rays share the wave's list of walls instead of each wave
+// building its own.  Measured: four groups pay from 256 rays up - a quarter of the vector instructions saved
+// without colour, a sixth with - IF the launch has two and a half rounds of such waves to fill the machine with and every XCD's
+// last envs are left to waves of one group (render_block): 4096 x 4 x 512 rays 157.5 -> 139.0 us (colourless 127.4 -> 104.7),
+// C5's share 216.7 -> 196.7; with a round or less of them - 4096 x 1 x 256 rays - a quarter is LOST.  Two groups never pay.
+// `pinned`: ms_debug_ray_groups (1, 2, 4; else the rule above).  The one-group waves' share: `tail_rounds` rounds of the
+// machine's wave slots' worth of the wide waves' work (< 0: half a round), or `tail_envs` envs exactly if >= 0.
+struct RenderPlan { int ng; long long n_blocks; };
+RenderPlan render_plan(const int n_envs, const int n_agents, const int R, const int slots, const int pinned, const float tail_rounds,
+                       const int tail_envs_exact, RenderConsts& rc) {
+    int ng = 1;
+    if (R >= 4*WAVE && 2LL*n_envs*n_agents*((R + 4*WAVE - 1)/(4*WAVE)) >= 5LL*slots) ng = 4;   // (2.5 rounds, the one-group waves' half included)
+    if (pinned == 1 || pinned == 2 || pinned == 4) ng = pinned;
+    int tail = 0;
+    const int G1 = (R + WAVE - 1)/WAVE;
+    const int envs_lo = n_envs/8, envs_rem = n_envs % 8, envs_hi = envs_lo + (envs_rem ? 1 : 0);
+    if (ng > 1) {
+        const double rounds = tail_rounds >= 0.f ? (double)tail_rounds : 0.5;
+        const long long tail_envs = tail_envs_exact >= 0 ? tail_envs_exact : (long long)ceil(rounds*slots*ng/((double)n_agents*G1));
+        tail = (int)std::min<long long>((tail_envs + 7)/8, envs_hi);                        // per XCD
+        if (tail >= envs_hi && !(pinned > 1)) ng = 1;                 // nothing left for the wide waves: the plain kernel
+    }
+    const int G = (R + ng*WAVE - 1)/(ng*WAVE);
+    rc.by_f = divisor_of((unsigned)(n_agents*G));
+    rc.by_g = divisor_of((unsigned)G);
+    rc.by_f1 = divisor_of((unsigned)(n_agents*G1));
+    rc.by_g1 = divisor_of((unsigned)G1);
+    rc.envs_lo = envs_lo; rc.envs_rem = envs_rem; rc.tail = tail;
+    // (NG > 1: every XCD as many blocks as the one with the most envs needs)
+    const long long n_blocks = ng > 1 ? 8LL*((long long)(envs_hi - std::min(tail, envs_hi))*n_agents*G + (long long)std::min(tail, envs_hi)*n_agents*G1)
+                                      : (long long)n_envs*n_agents*G;
+    return RenderPlan{ng, n_blocks};
+}
+
+// Envs per wave (physics_kernel's PACK), with a wall grid (without one an env's walls are streamed, and there is nothing to put
+// side by side) and while a wave's agents stay within half its lanes: as many as bring the launch down to about 4096 waves -
+// 32768 envs of one agent are 5.3 rounds of waves with a lane or two at work each: 30.2 us; eight to a wave 9.7 (four 13.6,
+// sixteen 10.2); 16384 x 4 agents 22.2 -> 13.3 (eight: 17.8), 8192 x 4 13.4 -> 10.2 - and two even at 4096 envs, where one round
+// of short waves becomes half a round of waves twice as busy (8.7 -> 8.2 us; three 8.7, four 9.5; one agent per env 7.1 -> 6.4).
+// `pinned`: ms_debug_physics_pack (>= 1; else the rule).
+int physics_pack_of(const int n_envs, const int n_agents, const bool gridded, const int pinned) {
+    int pack = 1;
+    if (gridded && n_agents <= 16) {
+        pack = n_envs > 6144 ? std::min((n_envs + 4095)/4096, 16) : n_envs >= 3072 ? 2 : 1;
+        pack = std::max(std::min(pack, WAVE/2/n_agents), 1);
+    }
+    if (pinned >= 1) pack = (gridded && (long long)pinned*n_agents <= WAVE) ? pinned : 1;
+    return pack;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ------------------------------------------------------------------------------------------------
 int hip_fail(hipError_t e) { g_last_hip_error = (int)e; return MS_EHIP; }
@@ -171,6 +225,20 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
 
 int ms_debug_ray_groups(int groups) { g_ray_groups = groups; return MS_OK; }
 int ms_debug_physics_pack(int envs) { g_physics_pack = envs; return MS_OK; }
+int ms_host_physics_pack(int n_envs, int n_agents, int gridded, int pinned) { return physics_pack_of(n_envs, n_agents, gridded != 0, pinned); }
+long long ms_host_render_plan(int n_envs, int n_agents, int res, int slots, int pinned_groups, float tail_rounds, int tail_envs, int* groups) {
+    RenderConsts rc;
+    const RenderPlan plan = render_plan(n_envs, n_agents, res, slots, pinned_groups, tail_rounds, tail_envs, rc);
+    if (groups) *groups = plan.ng;
+    return plan.n_blocks;
+}
+int ms_host_render_block(int n_envs, int n_agents, int res, int slots, int pinned_groups, float tail_rounds, int tail_envs, long long block, int* out4) {
+    RenderConsts rc;
+    const RenderPlan plan = render_plan(n_envs, n_agents, res, slots, pinned_groups, tail_rounds, tail_envs, rc);
+    int fan = 0;
+    if (block < 0 || block >= plan.n_blocks) return -1;
+    return render_block((int)block, (int)plan.n_blocks, n_agents, res, plan.ng, rc, out4[0], out4[1], out4[2], out4[3], fan) ? 1 : 0;
+}
 int ms_debug_ray_group_tail(float rounds, int envs) { g_tail_rounds = rounds; g_tail_envs = envs; return MS_OK; }
 int ms_debug_pair_telemetry(int on) { g_pair_telemetry = on ? 1 : 0; return MS_OK; }
 
@@ -333,17 +401,7 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
         if (ex->lifespans && (!ex->max_lifespans || !ex->fresh_max)) return MS_EINVAL;
         if (ex->imu && !(ex->imu_ang_scale == ex->imu_ang_scale && ex->imu_speed_scale == ex->imu_speed_scale)) return MS_EINVAL;
     }
-    // Envs per wave (physics_kernel's PACK), with a wall grid (without one an env's walls are streamed, and there is nothing to
-    // put side by side) and while a wave's agents stay within half its lanes: as many as bring the launch down to about 4096
-    // waves - 32768 envs of one agent are 5.3 rounds of waves with a lane or two at work each: 30.2 us; eight to a wave 9.7
-    // (four 13.6, sixteen 10.2); 16384 x 4 agents 22.2 -> 13.3, 8192 x 4 13.4 -> 10.2 - and two even at 4096 envs, where one
-    // round of short waves becomes half a round of waves twice as busy (8.7 -> 8.2 us, one agent per env 7.1 -> 6.4; four: 6.7).
-    int pack = 1;
-    if (sc->wg_cells && sc->n_agents <= 16) {
-        pack = sc->n_envs > 6144 ? std::min((sc->n_envs + 4095)/4096, 16) : sc->n_envs >= 3072 ? 2 : 1;
-        pack = std::max(std::min(pack, WAVE/2/sc->n_agents), 1);
-    }
-    if (g_physics_pack >= 1) pack = (sc->wg_cells && g_physics_pack*sc->n_agents <= WAVE) ? g_physics_pack : 1;
+    const int pack = physics_pack_of(sc->n_envs, sc->n_agents, sc->wg_cells != nullptr, g_physics_pack);
     // per wave: 2 float4 + a float + an unsigned per agent, rounded up to whole float4s
     const size_t slice = ((sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents*pack + 15)/16;
     if (slice*16 > 56*1024) return MS_EUNSUPPORTED;
@@ -389,43 +447,22 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
-    // ray groups per wave (render_kernel's NG): an agent's groups of 64 rays share the wave's list of walls instead of each
-    // wave building its own.  (ms_debug_ray_groups: A/B runs and tests pin it.)
-    // Measured: four groups pay from 256 rays up - a quarter of the vector instructions saved without colour, a
-    // sixth with - IF the launch has two and a half rounds of such waves to fill the machine with and its last envs are left to
-    // waves of one group (below): 4096 x 4 x 512 rays 157.5 -> 146.7 us (colourless 127.4 -> 110.4), C5's share
-    // 216.7 -> 207.9 (152.8 -> 132.2); with a round or less of them - 4096 x 1 x 256 rays - a quarter is LOST.  Two groups
-    // never pay.
     static int slots = 0;                                                // the machine's wave slots for this kernel
     if (!slots) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         slots = cus*4*MS_WAVES;
     }
-    int ng = 1;
-    if (R >= 4*WAVE && 2LL*sc->n_envs*sc->n_agents*((R + 4*WAVE - 1)/(4*WAVE)) >= 5LL*slots) ng = 4;   // (2.5 rounds, the one-group waves' half included)
-    if (g_ray_groups == 1 || g_ray_groups == 2 || g_ray_groups == 4) ng = g_ray_groups;
+    bool wide_ok = true;
 #if MS_AB_IMPLS
-    if (getenv("MEGASTEP_RENDER_IMPL")) ng = 1;
+    if (getenv("MEGASTEP_RENDER_IMPL")) wide_ok = false;
 #endif
     // (without a light grid the rays that land on an agent are lit by dynlight_kernel, which takes them by groups of 64)
-    if (!(sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f) && sc->n_agents > 1 && (out->screen || out->obs_rgb)) ng = 1;
-    // (NG > 1: waves of ng groups for every XCD's envs but its last `tail`, waves of one group for those - render_kernel has
-    // why.  Their share: g_tail_rounds rounds of the machine's wave slots' worth of the wide waves' work, half a round unless
-    // ms_debug_ray_group_tail says otherwise.)
-    int tail = 0;
-    const int G1 = (R + WAVE - 1)/WAVE;
-    const int envs_lo = sc->n_envs/8, envs_rem = sc->n_envs % 8, envs_hi = envs_lo + (envs_rem ? 1 : 0);
-    if (ng > 1) {
-        const double rounds = g_tail_rounds >= 0.f ? (double)g_tail_rounds : 0.5;
-        const long long tail_envs = g_tail_envs >= 0 ? g_tail_envs : (long long)ceil(rounds*slots*ng/((double)sc->n_agents*G1));
-        tail = (int)std::min<long long>((tail_envs + 7)/8, envs_hi);                        // per XCD
-        if (tail >= envs_hi && !(g_ray_groups > 1)) ng = 1;           // nothing left for the wide waves: the plain kernel
-    }
-    const int G = (R + ng*WAVE - 1)/(ng*WAVE);
-    // (NG > 1: every XCD as many blocks as the one with the most envs needs)
-    const long long n_fans = ng > 1 ? 8LL*((long long)(envs_hi - std::min(tail, envs_hi))*sc->n_agents*G + (long long)std::min(tail, envs_hi)*sc->n_agents*G1)
-                                    : (long long)sc->n_envs*sc->n_agents*G;
+    if (!(sc->lg_vals && sc->lg_starts && sc->lg_geom && sc->lg_cell > 0.f) && sc->n_agents > 1 && (out->screen || out->obs_rgb)) wide_ok = false;
+    RenderConsts rc;
+    const RenderPlan plan = render_plan(sc->n_envs, sc->n_agents, R, slots, wide_ok ? g_ray_groups : 1, g_tail_rounds, g_tail_envs, rc);
+    const int ng = plan.ng;
+    const long long n_fans = plan.n_blocks;
     if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
     // kernels.cu:22
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
@@ -474,15 +511,9 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     if (colour && (!all_planes || pooled) && !(grid || sc->n_agents == 1)) return MS_EUNSUPPORTED;   // dynlight_kernel patches `screen` afterwards
     if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
     const bool obs = pooled || !all_planes;
-    RenderConsts rc;
     rc.x_clip = 0.5f*cfg->agent_radius/sqrtf(1.f + half_screen*half_screen);
     rc.c_b = 0.5f*(float)R/half_screen;
-    rc.by_f = divisor_of((unsigned)(sc->n_agents*G));
-    rc.by_g = divisor_of((unsigned)G);
     rc.by_m = divisor_of((unsigned)sc->n_model);
-    rc.by_f1 = divisor_of((unsigned)(sc->n_agents*G1));
-    rc.by_g1 = divisor_of((unsigned)G1);
-    rc.envs_lo = envs_lo; rc.envs_rem = envs_rem; rc.tail = tail;
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
     rc.inv_res = ((R & (R - 1)) == 0 && half_screen > 1e-3f) ? 1.f/(float)R : 0.f;
     rc.telemetry = g_pair_telemetry;
