@@ -99,3 +99,18 @@ def test_envs_per_physics_wave():
                 for pinned in (1, 2, 5, 64):
                     kp = pack(n, a, gridded, pinned)
                     assert kp == (pinned if gridded and pinned*a <= 64 else 1)
+
+
+def test_random_worlds_and_plans():
+    """The same walk over randomly drawn worlds, pinnings and tails (hypothesis)."""
+    from hypothesis import given, settings, strategies as st
+    h = _lib.lib()
+
+    @settings(max_examples=80, deadline=None)
+    @given(n_envs=st.integers(1, 200), n_agents=st.integers(1, 6), res=st.integers(1, 700), pinned=st.sampled_from([0, 1, 2, 4]),
+           tail_envs=st.integers(-1, 210), rounds=st.sampled_from([-1., 0., .25, .5, 3.]), slots=st.sampled_from([8, 64, 6144]))
+    def walk(n_envs, n_agents, res, pinned, tail_envs, rounds, slots):
+        groups, blocks = _launch(h, n_envs, n_agents, res, pinned, rounds, tail_envs, slots=slots)
+        assert groups in (1, 2, 4) and (pinned == 0 or groups == pinned)
+        _check(n_envs, n_agents, res, groups, blocks)
+    walk()
