@@ -17,7 +17,8 @@ With --gpus N>1 there is one rank per GPU: `python bench.py --gpus N` on its own
 that has already set WORLD_SIZE (the driver's torch.distributed.run command) it is one of them. The job holds N x
 --envs envs; every rank works out the same contiguous cuts (balanced by lines x agents x rays) from the floorplans on
 the host and builds and bakes ITS slice only - weak scaling, no collective on the data path: envs are independent; the
-ranks meet only in a gloo barrier around each timed region and a MAX over their times, so RCCL is never initialised.
+ranks meet only in a gloo barrier BEFORE each timed region and a MAX over their own times after it (each rank's clock runs
+from its own synchronize to its own synchronize: no rendezvous is inside what is timed), so RCCL is never initialised.
 Rank 0 prints one JSON line.
 
 Timing: a timed region is the W untimed warm-up steps from the spawn points and then exactly K steps between barrier +
@@ -459,9 +460,12 @@ def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields
         t0 = time.perf_counter()
         run()
         dev.sync()
-        own.append(time.perf_counter() - t0)                           # this rank's own time, before it waits for the others
-        barrier()
-        return sharding.max_over_ranks(time.perf_counter() - t0)       # the slowest rank sets the step rate
+        own.append(time.perf_counter() - t0)                           # this rank's own sync-to-sync time: the clock stops HERE
+        # The slowest rank's OWN K steps set the job's rate (N / max_g t_g after a start barrier). Nothing that
+        # the ranks do to meet again - the MAX below is itself a gloo round trip, a closing barrier would be another - is
+        # inside what is timed: at the driver's --steps 20 a region lasts under a millisecond, and round 4's closing
+        # barrier (half a millisecond of TCP on 2 ranks) would have read as a 5x ceiling on the 8-GPU line.
+        return sharding.max_over_ranks(own[-1])
 
     def repeated(run, floor_s=0.25, least=5, most=400):
         """`run` (exactly K steps) timed again and again - every region bracketed as above - until the regions add up to
@@ -619,6 +623,8 @@ def main(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
     ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
     ap.add_argument('--plan-workers', type=int, default=None, help='processes generating floorplans (0: in this process)')
+    ap.add_argument('--baseline-line', default=None, help="file holding the JSON line of the same command at --gpus 1: the line then "
+                                                          "carries scaling_efficiency = value / (N x that line's value)")
     args = ap.parse_args(argv)
     if args.plan_workers is not None:
         global PLAN_WORKERS
@@ -654,6 +660,12 @@ def main(argv=None):
         # gloo: the ranks only meet in a barrier and a MAX of one float - envs are independent, RCCL stays out of it
         dist.init_process_group('gloo')
         barrier = dist.barrier
+        if os.environ.get('BENCH_TEST_BARRIER_SLEEP_MS'):
+            # test hook (tests/test_bench_gloo.py): a slow rendezvous must not show in `value` - only what a rank does
+            # between its own two synchronize calls is timed
+            def barrier(_ms=float(os.environ['BENCH_TEST_BARRIER_SLEEP_MS'])):
+                time.sleep(_ms*1e-3)
+                dist.barrier()
     else:
         barrier = lambda: None
 
@@ -731,6 +743,20 @@ def main(argv=None):
                      'peak_fp32_vector_TFLOPs': FP32_VECTOR_PEAK_TFLOPS,
                      'frac_of_peak': flops/(render_ms*1e-3)/1e12/FP32_VECTOR_PEAK_TFLOPS}},
     }
+    if distributed:
+        # what the driver needs to read a 1 -> 8 curve: whose time `value` is, and what each rank's host side ran with
+        aff = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+        mine = {'rank': rank, 'device': str(device), 'omp_num_threads': os.environ.get('OMP_NUM_THREADS'),
+                'torch_threads': torch.get_num_threads(), 'cpus_allowed': len(aff)}
+        hosts = [None]*world
+        dist.all_gather_object(hosts, mine)
+        out['per_rank']['host'] = hosts
+        out['timing'] = ('value = all ranks\' envs x K / MAX over ranks of each rank\'s OWN synchronize-to-synchronize time for the K steps '
+                         '(start barrier before the clock starts; nothing collective inside it), median over the timed regions')
+    if args.baseline_line:
+        base = [json.loads(l) for l in open(args.baseline_line) if l.lstrip().startswith('{')][-1]
+        out['scaling_efficiency'] = {'vs': os.path.basename(args.baseline_line), 'n1_value': base['value'], 'n1_gpus': base.get('n_gpus', 1),
+                                     'efficiency': value/(world*base['value']/max(base.get('n_gpus', 1), 1))}
     if extras:
         if not args.no_cpu_baseline:
             out.update(cpu_baselines(core))

@@ -8,8 +8,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(nproc, extra=(), self_launch=False):
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
+def _run(nproc, extra=(), self_launch=False, environ=()):
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2', **dict(environ))
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT'):
         env.pop(k, None)
     args = ['--gpus', str(nproc), '--steps', '6', '--warmup', '2', '--envs', '24', '--agents', '2', '--res', '16',
@@ -48,6 +48,29 @@ def test_plain_command_starts_its_own_ranks():
     pr = out['per_rank']
     assert len(pr['envs']) == 2 and sum(pr['envs']) == 48 and len(pr['ms_per_step']) == 2
     assert all(0 < t <= out['ms_per_step']*1.5 + 1 for t in pr['ms_per_step'])
+
+
+def test_the_rendezvous_is_not_inside_what_is_timed(tmp_path):
+    """`value` is N x K over the slowest rank's OWN synchronize-to-synchronize time. A barrier that takes
+    50 ms (two orders of magnitude above a region of stub steps) must leave ms_per_step where the ranks' own times are -
+    round 4 read the clock after a closing barrier, which at the driver's --steps 20 would have capped the 8-GPU line."""
+    slow = _run(2, environ={'BENCH_TEST_BARRIER_SLEEP_MS': '50'})
+    own = slow['per_rank']['ms_per_step']
+    assert len(own) == 2 and 'OWN' in slow['timing']
+    # 50 ms of barrier over 6 steps would be 8.3 ms per step; a stub step is microseconds
+    assert slow['ms_per_step'] < 0.5, slow['ms_per_step']
+    # the median region's MAX over ranks against the ranks' median regions: the same quantity up to the noise of a
+    # microsecond-long CPU region (median of maxima vs maximum of medians)
+    assert slow['ms_per_step'] <= 1.05*max(own) + 0.02, (slow['ms_per_step'], own)
+    assert slow['timed_regions']['ms_per_step_min'] <= slow['ms_per_step'] <= slow['timed_regions']['ms_per_step_max']
+    assert [h['rank'] for h in slow['per_rank']['host']] == [0, 1] and slow['per_rank']['host'][0]['omp_num_threads'] == '2'
+    # scaling efficiency against an N = 1 line of the same command, when one is handed over
+    line = tmp_path/'n1.json'
+    one = _run(1)
+    line.write_text(json.dumps(one) + '\n')
+    two = _run(2, ('--baseline-line', str(line)))
+    eff = two['scaling_efficiency']
+    assert eff['n1_value'] == one['value'] and abs(eff['efficiency'] - two['value']/(2*one['value'])) < 1e-9
 
 
 def test_world_size_must_match_the_gpus_asked_for():
