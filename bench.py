@@ -437,7 +437,7 @@ def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields
     # One Agents view per step: positions/angles are the persistent state, velocity/angvelocity point at that
     # step's pre-generated inputs, already resident in HBM - the hot path reads its inputs in place, no copies.
     vel, angvel = vel0.clone(), angvel0.clone()                         # (ms_physics zeroes the stopped agents' in place)
-    views = [cuda.Agents(agents.angles, agents.positions, angvel[i], vel[i]) for i in range(total)]
+    views = [cuda.Agents(agents.angles, agents.positions, angvel[i], vel[i], config=core.config) for i in range(total)]
 
     def rewind():
         """Back to the spawn points, inputs pristine, then the W untimed warm-up steps: every timed region is the same K
@@ -502,6 +502,29 @@ def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields
     return m
 
 
+def ray_groups(dev, core):
+    """render_kernel's NG for this world as ms_render itself picks it: asked of the library's own launch plan
+    (ms_host_render_plan, the function ms_render calls), not re-derived here."""
+    import ctypes
+    from megastep_amd import _lib
+    ng = ctypes.c_int(0)
+    slots = 4*6*(torch.cuda.get_device_properties(dev.device).multi_processor_count if dev.device.type == 'cuda' else 256)
+    _lib.lib().ms_host_render_plan(core.n_envs, core.n_agents, core.res, slots, 0, -1., -1, ctypes.byref(ng))
+    return ng.value
+
+
+def grids(core):
+    """What bake() built around the floorplans (Scenery.grid_report()): bytes, cell sizes actually used, floorplans - a wall grid
+    that outgrew its budget coarsens itself, which costs the step 3-6 %: the line says so instead of leaving it to be guessed."""
+    rep = core.scenery.grid_report() if hasattr(core.scenery, 'grid_report') else {}
+    out = {}
+    for k in ('wall_grid', 'light_grid'):
+        r = rep.get(k)
+        if r:
+            out[k] = {kk: r[kk] for kk in ('bytes', 'cell', 'cells', 'floorplans', 'coarsened', 'candidate_rows', 'budget') if kk in r}
+    return out
+
+
 def shape_entry(dev, core, steps, warmup, fields=None, note=None):
     """One line of the `shapes` block: the hot path on another of BASELINE.json's shapes, timed like the headline (same
     protocol, shorter floors), with that shape's own algorithmic bytes against the HBM peak."""
@@ -518,7 +541,8 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None):
          'eager_ms_per_step': 1e3*float(np.median(m['eager_runs']))/steps,
          'render_launch_ms': render_ms, 'render_algorithmic_bytes': rb,
          'roofline_frac': rb/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
-         'step_achieved_GBps': (rb + pb)/(1e3*s/steps*1e-3)/1e9}
+         'step_achieved_GBps': (rb + pb)/(1e3*s/steps*1e-3)/1e9,
+         'ray_groups_per_wave': ray_groups(dev, core), **grids(core)}
     if note:
         e['note'] = note
     return e
@@ -715,7 +739,7 @@ def main(argv=None):
             'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
             'envs_per_gpu': args.envs, 'envs_this_rank': N, 'envs_total': n_total, 'agents': A, 'res': args.res,
             'lines_per_env': scenery.lines.vals.shape[0]/N, 'lights_per_env': scenery.lights.vals.shape[0]/N,
-            'distinct_floorplans_per_gpu': 460 if args.legacy_plans else n_unique,
+            'distinct_floorplans_per_gpu': 460 if args.legacy_plans else n_unique, **grids(core),
             'parallelism': f'env-sharded x{world} (contiguous slices balanced by lines x agents x rays), no collectives'},
         'agent_steps_per_sec': value*A,
         'per_rank': {'envs': [n for n, _ in per_rank], 'ms_per_step': [t for _, t in per_rank]},
@@ -728,7 +752,7 @@ def main(argv=None):
             # (<IMPL, RW, OBS, SHADE, NG>; NG - 64-ray groups per wave - as ms_render picks it: four from 256 rays up on launches
             # of two and a half rounds of such waves)
             'kernel': 'ms_render = render_kernel<2,1,%s,%d> (headings cached by ms_physics)' % (
-                '1,0' if args.depth_only else '0,1', 4 if args.res >= 256 and 2*core.n_envs*core.n_agents*((args.res + 255)//256) >= 5*6144 else 1),
+                '1,0' if args.depth_only else '0,1', ray_groups(dev, core)),
             'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,

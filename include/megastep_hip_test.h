@@ -17,10 +17,11 @@ void ms_host_ray_interval(const float* pose, const float* line, int res, float f
 void ms_host_ray_interval_wide(const float* pose, const float* line, int res, float fov, float agent_radius, int groups, int wave,
                                int* first, int* count);
 /* Pins the number of 64-ray groups a render wave serves (1, 2, 4; 0 = ms_render picks it from the request: DESIGN 3.6).
- * Process-wide; for A/B runs and tests - every setting produces the same bits. */
+ * Per calling THREAD (like every ms_debug_* switch: the library keeps no process-wide state - a thread that pins something
+ * changes its own calls only); for A/B runs and tests - every setting produces the same bits. */
 int ms_debug_ray_groups(int groups);
 /* Pins the number of envs a physics wave takes side by side (physics_kernel's PACK; 0 = ms_step_physics picks it from the
- * world's size, 1 = one, k = k where k x n_agents <= 64 and there is a wall grid, else one).  Process-wide; A/B runs and
+ * world's size, 1 = one, k = k where k x n_agents <= 64 and there is a wall grid, else one).  Per calling thread; A/B runs and
  * tests - every setting produces the same bits. */
 int ms_debug_physics_pack(int envs);
 /* The launch geometry ms_render / ms_step_physics decide on the host, and the render kernel's own block -> rays mapping
@@ -34,10 +35,10 @@ int ms_host_render_block(int n_envs, int n_agents, int res, int slots, int pinne
 int ms_host_physics_pack(int n_envs, int n_agents, int gridded, int pinned);
 /* A launch of waves of several groups ends with waves of one group for its last envs; their share, in rounds of the machine's
  * wave slots' worth of the wide waves' work (< 0: ms_render's own, half a round; 0: none; large: every env), or, if
- * envs >= 0, that many envs exactly.  Process-wide; A/B runs and tests - every setting produces the same bits. */
+ * envs >= 0, that many envs exactly.  Per calling thread; A/B runs and tests - every setting produces the same bits. */
 int ms_debug_ray_group_tail(float rounds, int envs);
 /* Has ms_render's waves add their (line, ray) pair and pair-window counts to workspace[3] and [4] (two atomics per wave on
- * one address: milliseconds at 10^5 waves - tools/pair_stats.py only).  Process-wide. */
+ * one address: milliseconds at 10^5 waves - tools/pair_stats.py only).  Per calling thread. */
 int ms_debug_pair_telemetry(int on);
 /* Host instantiation of the light grid's build (ms_bake; accelerates kernels.cu:238-268) for one cell c (row-major in a grid
  * of nx x ny cells of size `cell` from (ox, oy)), over n_walls walls (n_walls x 4 floats: ax, ay, bx, by) and n_lights

@@ -20,11 +20,11 @@ def gamma_decode(x):
     return x**2.2
 
 
-def _init_agents(n_envs, n_agents, device='cuda'):
+def _init_agents(n_envs, n_agents, device='cuda', config=None):
     """A zeroed :class:`~megastep_amd.cuda.Agents` (reference: core.py:24-31)."""
     zeros = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
     return cuda.Agents(angles=zeros(n_envs, n_agents), positions=zeros(n_envs, n_agents, 2),
-                       angvelocity=zeros(n_envs, n_agents), velocity=zeros(n_envs, n_agents, 2))
+                       angvelocity=zeros(n_envs, n_agents), velocity=zeros(n_envs, n_agents, 2), config=config)
 
 
 class Core:
@@ -48,9 +48,15 @@ class Core:
 
         assert fov < 180, 'FOV should be less than 180°'
 
+        # The reference keeps these four in process-global device constants (kernels.cu:12-27): one Core's res / fov per
+        # process. Here each Core keeps its own (`config`, passed by value with every launch) and hangs it on its agents,
+        # which is where cuda.physics / cuda.render look first - several Cores of different shapes step side by side.
+        # initialize() is still called, for callers of the drop-in two-argument cuda.render(scenery, agents) on Agents
+        # they built themselves.
+        self.config = cuda.config(self.agent_radius, self.res, self.fov, self.fps)
         cuda.initialize(self.agent_radius, self.res, self.fov, self.fps)
         self.scenery = scenery
-        self.agents = _init_agents(self.n_envs, self.n_agents, self.device)
+        self.agents = _init_agents(self.n_envs, self.n_agents, self.device, self.config)
         self.progress = torch.ones((self.n_envs, self.n_agents), device=self.device)
 
     def state(self, e):

@@ -79,7 +79,10 @@ __device__ inline Filt tex_filter(float x, int w) {
 // First launch of ms_render when a workspace is given: zeroes the queue counter and evaluates every agent's
 // sin/cos (binary64 inside, see sincospi_f) once, instead of once per wavefront of the raycast.
 // Workspace layout: [0] queue length, [1] rays that took the sequential fold, [2] wavefronts that took its lane-parallel
-// form (telemetry for tests) | [16, 16 + n_fans) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent).
+// form (telemetry for tests) | [16, 16 + N A ceil(R/64)) queued ray groups | (8-byte aligned) (sin, cos) per (env, agent), at
+// `headings_at` = 16 + that count rounded up to even - a place that depends on the shapes alone, as MS_RENDER_WORKSPACE_INTS
+// does, NOT on how many blocks the launch has: with several ray groups a wave every XCD gets as many blocks as the fullest
+// one needs, which can be more than N A ceil(R/64) (round 4 put the headings behind the block count: past the end then).
 // Launch-invariant values the host works out once per ms_render call instead of every wave doing so on the VALU:
 // culling constants, and exact unsigned division by F = A*G, G and M via multiply-high (Granlund & Montgomery).
 // sqrtf() for an argument known to be a normal number (not zero, denormal, infinite or NaN): the correctly rounded root
@@ -106,6 +109,7 @@ struct RenderConsts {
     int skip_own;                  // the agent's own model lines lie inside its near plane: no ray of its can hit them
     float inv_res;                 // 1/res where that is a power of two (x/res is then x*inv_res bit for bit), else 0
     int telemetry;                 // ms_debug_pair_telemetry: pair / window counts into workspace[3], [4]
+    int ws_headings;               // where in MsRender.workspace the (sin, cos) pairs of render_prep_kernel start, in 4-byte words
 };
 __host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
     unsigned s = 0;
@@ -160,13 +164,13 @@ __host__ __device__ inline bool render_block(const int b, const int n_blocks, co
 }
 
 __global__ __launch_bounds__(WG) void render_prep_kernel(const MsAgents ag, int* __restrict__ workspace,
-                                                         const int n_agents_total, const int n_fans) {
+                                                         const int n_agents_total, const int headings_at) {
     const int i = blockIdx.x*WG + threadIdx.x;
     if (i == 0) { workspace[0] = 0; workspace[1] = 0; workspace[2] = 0; workspace[3] = 0; workspace[4] = 0; }
     if (i < n_agents_total) {
         float s, c;
         sincospi_f(ag.angles[i]/180.f, s, c);
-        reinterpret_cast<float2*>(workspace + 16 + ((n_fans + 1) & ~1))[i] = make_float2(s, c);
+        reinterpret_cast<float2*>(workspace + headings_at)[i] = make_float2(s, c);
     }
 }
 
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         }
     } else if (lane < A) {
         if (out.workspace) {
-            const float2 sc_ = reinterpret_cast<const float2*>(out.workspace + 16 + ((n_fans + 1) & ~1))[n*A + lane];
+            const float2 sc_ = reinterpret_cast<const float2*>(out.workspace + rc.ws_headings)[n*A + lane];
             ag_s = sc_.x; ag_c = sc_.y;
         } else {
             const float2 sc_ = sincospi_called(ag.angles[n*A + lane]/180.f);

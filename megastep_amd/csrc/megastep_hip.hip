@@ -48,6 +48,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include "../../include/megastep_hip_test.h"
 
 namespace {
@@ -58,12 +59,16 @@ constexpr int WAVE = 64;
 constexpr int WG = 256;             // 4 waves per workgroup
 constexpr int WAVES = WG/WAVE;
 
+// The library keeps NO process-wide state: what the entry points need travels in their arguments (MsConfig by value).  What
+// follows is per THREAD - the last HIP error, and the test / A-B hooks of megastep_hip_test.h (ms_debug_*), which pin choices
+// ms_render / ms_step_physics otherwise make from the shapes: a thread that pins one changes its own calls only, every other
+// thread gets the product's behaviour.  (Round 4 had these as plain globals: a test hook changed the launches of the whole process.)
 thread_local int g_last_hip_error = 0;
-int g_pair_telemetry = 0;              // ms_debug_pair_telemetry
-int g_ray_groups = 0;                  // ms_debug_ray_groups: 0 = ms_render picks render_kernel's NG from the resolution
-int g_physics_pack = 0;                 // ms_debug_physics_pack: 0 = ms_step_physics picks the envs a physics wave takes side by side, k >= 1 = k
-float g_tail_rounds = -1.f;            // ms_debug_ray_group_tail: < 0 = ms_render's own share of one-group waves at the end of a launch of wide ones
-int g_tail_envs = -1;                  //   ... >= 0: that many envs exactly
+thread_local int g_pair_telemetry = 0;      // ms_debug_pair_telemetry
+thread_local int g_ray_groups = 0;          // ms_debug_ray_groups: 0 = ms_render picks render_kernel's NG from the resolution
+thread_local int g_physics_pack = 0;        // ms_debug_physics_pack: 0 = ms_step_physics picks the envs a physics wave takes side by side, k >= 1 = k
+thread_local float g_tail_rounds = -1.f;    // ms_debug_ray_group_tail: < 0 = ms_render's own share of one-group waves at the end of a launch of wide ones
+thread_local int g_tail_envs = -1;          //   ... >= 0: that many envs exactly
 
 // -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
 // time stamps (s_memtime at its start, at a few points where something it waited for has arrived, at its end) and of
@@ -170,6 +175,22 @@ int physics_pack_of(const int n_envs, const int n_agents, const bool gridded, co
 // host side of the C-ABI
 // ------------------------------------------------------------------------------------------------
 int hip_fail(hipError_t e) { g_last_hip_error = (int)e; return MS_EHIP; }
+
+// The wave slots render_kernel has on the CURRENT device (CUs x 4 SIMDs x the waves per SIMD its registers are held to): what
+// sizes a launch's choice of ray groups and its tail.  Looked up once per device (a process may drive several, of different
+// sizes: round 4 kept the first caller's); a benign race - every writer stores the same number.
+int wave_slots_here() {
+    constexpr int MAX_DEVICES = 64;
+    static std::atomic<int> slots_of[MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256*4*MS_WAVES;
+    if (dev >= 0 && dev < MAX_DEVICES) { const int known = slots_of[dev].load(std::memory_order_relaxed); if (known) return known; }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int slots = cus*4*MS_WAVES;
+    if (dev >= 0 && dev < MAX_DEVICES) slots_of[dev].store(slots, std::memory_order_relaxed);
+    return slots;
+}
 
 bool scenery_ok(const MsScenery* s) {
     return s && s->n_envs > 0 && s->n_agents > 0 && s->n_model > 0 && s->lines_vals && s->lines_widths &&
@@ -447,12 +468,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     }
     if (sc->n_lights_total > 0 && !sc->lights_vals) return MS_EINVAL;
     const int R = cfg->res;
-    static int slots = 0;                                                // the machine's wave slots for this kernel
-    if (!slots) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        slots = cus*4*MS_WAVES;
-    }
+    const int slots = wave_slots_here();                                 // the current device's wave slots for this kernel
     bool wide_ok = true;
 #if MS_AB_IMPLS
     if (getenv("MEGASTEP_RENDER_IMPL")) wide_ok = false;
@@ -463,7 +479,10 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     const RenderPlan plan = render_plan(sc->n_envs, sc->n_agents, R, slots, wide_ok ? g_ray_groups : 1, g_tail_rounds, g_tail_envs, rc);
     const int ng = plan.ng;
     const long long n_fans = plan.n_blocks;
-    if (n_fans > 0x7fffffffLL) return MS_EUNSUPPORTED;
+    // the workspace's layout (MS_RENDER_WORKSPACE_INTS): 16 counters, a queue of one entry per (env, agent, 64 rays), the headings
+    const long long ws_queue = (long long)sc->n_envs*sc->n_agents*((R + WAVE - 1)/WAVE);
+    if (n_fans > 0x7fffffffLL || ws_queue > 0x7fffff00LL) return MS_EUNSUPPORTED;
+    rc.ws_headings = 16 + (int)((ws_queue + 1) & ~1LL);
     // kernels.cu:22
     const float half_screen = tanf(3.14159265358979323846f/180.f*cfg->fov/2.);
 #if MS_AB_IMPLS
@@ -502,7 +521,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
             if ((uintptr_t)out->workspace % 8) return MS_EINVAL;
             const int na = sc->n_envs*sc->n_agents;
             hipLaunchKernelGGL(render_prep_kernel, dim3((na + WG - 1)/WG), dim3(WG), 0, (hipStream_t)stream,
-                               *ag, out->workspace, na, (int)n_fans);
+                               *ag, out->workspace, na, rc.ws_headings);
         }
     }
     // dynlight_kernel reads the per-ray outputs back: only the one-kernel path can do without some of them

@@ -33,21 +33,36 @@ def _ab_switches():
         _lib.lib().ms_debug_ray_group_tail(float(t) if t else -1., int(e) if e else -1)
 
 
-def initialize(agent_radius, res, fov, fps):
-    """Sets the constants used by :func:`bake`, :func:`physics` and :func:`render` (reference: wrappers.cpp:53).
-
-    As in the reference this is process-global; unlike it, the values travel by value with every launch, so nothing
-    device-side is mutated here and several devices can be driven from one process."""
-    global _config
+def config(agent_radius, res, fov, fps):
+    """The four constants of :func:`initialize` as a value (the C-ABI's ``MsConfig``, passed by value with every launch):
+    what a :class:`~megastep_amd.core.Core` keeps for itself and hangs on its ``Agents``, so that several Cores of
+    different resolutions, fields of view or frame rates live side by side in one process - on one device or several."""
     if not (0 < fov < 180):
         raise RuntimeError('fov must be in (0, 180) degrees')
     if res <= 0 or fps <= 0 or agent_radius <= 0:
         raise RuntimeError('agent_radius, res and fps must be positive')
-    _config = _lib.MsConfig(float(agent_radius), int(res), float(fov), float(fps))
+    return _lib.MsConfig(float(agent_radius), int(res), float(fov), float(fps))
+
+
+def initialize(agent_radius, res, fov, fps):
+    """Sets the constants used by :func:`physics` and :func:`render` for callers that hand them bare tensors' holders
+    (reference: wrappers.cpp:53) - the drop-in path. As in the reference this is process-global; unlike it, nothing
+    device-side is mutated (the values travel by value with every launch), and it is only the FALLBACK: a call that is
+    given ``config=``, or whose ``agents`` carry one (every ``Core``'s do), never looks at it."""
+    global _config
+    _config = config(agent_radius, res, fov, fps)
     _ab_switches()
 
 
-def _cfg():
+def _cfg(agents=None, explicit=None):
+    """The constants of one call: the ``config=`` argument, else the ones the agents' Core hung on them, else initialize()'s."""
+    if explicit is not None:
+        if not isinstance(explicit, _lib.MsConfig):
+            raise RuntimeError('config must come from megastep_amd.cuda.config(agent_radius, res, fov, fps)')
+        return explicit
+    own = getattr(agents, '_config', None)
+    if own is not None:
+        return own
     if _config is None:
         raise RuntimeError('megastep_amd.cuda.initialize(agent_radius, res, fov, fps) has not been called')
     return _config
@@ -162,7 +177,9 @@ class Agents:
     #: ``False`` sends ms_render through its own heading kernel instead of the cache ms_physics leaves (tests, A/B runs)
     HEADING_CACHE = True
 
-    def __init__(self, angles, positions, angvelocity, velocity):
+    def __init__(self, angles, positions, angvelocity, velocity, config=None):
+        #: the constants :func:`physics` / :func:`render` use for these agents (:func:`config`); None: initialize()'s
+        self._config = config
         self._angles = _check(angles, 'angles', torch.float32, 2)
         self._positions = _check(positions, 'positions', torch.float32, 3)
         self._angvelocity = _check(angvelocity, 'angvelocity', torch.float32, 2)
@@ -231,6 +248,7 @@ class Scenery:
         self._wg_sum = None         # checksum of the static walls the wall grid was built from
         self._wg_weights = None
         self._wg = None             # the wall grid's tensors (cells, starts, geom, cell, reach, near, pool); made by bake()
+        self._wg_report = self._lg_report = None      # what was built, at which cell size, in how many bytes (grid_report())
         self._dev = None
 
     n_agents = property(lambda self: self._n_agents)
@@ -252,34 +270,65 @@ class Scenery:
     #: light the grid cannot call - the rays whose waves a launch ends up waiting for; four times the cells.)
     LIGHT_GRID_CELL = float(os.environ.get('MEGASTEP_LIGHT_GRID_CELL', .125))     # (the environment switch is for A/B runs)
     LIGHT_GRID_POOL = 12        # pool words per cell (4 bytes each) for the candidate lists
+    #: what the light grid may take, bytes. A cell costs 16 B of verdicts + 8 B of list header + LIGHT_GRID_POOL x (4 B candidate
+    #: + 16 B of its wall's row) = 264 B: at 0.125 m cells 17 KB per square metre, 3-4 MB per benchmark floorplan, 14 MB per large
+    #: one - 1024 plans (the headline world) 3.4 GB, 4096 large ones 54 GB. Over budget the grid first goes without the
+    #: candidates' rows (72 B a cell: ms_render then fetches a candidate's wall one trip later, the round-3 behaviour), then
+    #: doubles its cells (a quarter of them, and more lights left UNKNOWN per cell: slower for the rays that land on an agent,
+    #: the same bits) until it fits. `Scenery.grid_report()` says what was built.
+    LIGHT_GRID_BYTES = int(float(os.environ.get('MEGASTEP_LIGHT_GRID_BYTES', 8 << 30)))
 
     def _light_grid(self):
         """Storage and geometry of the light grid (see include/megastep_hip.h): a uniform grid over each env's walls,
         half a metre of slack around them: per cell the lights' verdicts and a candidate list drawn from a shared pool.
         `bake` fills it in; zeros mean 'unknown, test every wall', which is always safe. Envs that share their
-        geometry (`geom`) share their representative's cells. 72 bytes per cell (16 verdicts + 8 list header + 48 pool):
-        about 1.2 KB per square metre of floorplan, i.e. tens of times the floorplan's own lines - hence the sharing,
-        and no grid at all for single-agent sceneries, whose rays never land on an agent."""
+        geometry (`geom`) share their representative's cells. 264 bytes per cell (16 verdicts + 8 list header + 12 pool
+        words of 4 + 16 each), i.e. hundreds of times the floorplan's own lines - hence the sharing, the byte budget
+        (LIGHT_GRID_BYTES) and no grid at all for single-agent sceneries, whose rays never land on an agent."""
         ln = self._lines
         dev = ln.vals.device
-        n_envs, cell = len(ln), self.LIGHT_GRID_CELL
+        n_envs = len(ln)
         lo, hi = self._wall_bounds()
         origin = torch.floor(lo) - .5
-        dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
-        # the grid holds 64 lights per env: an env with more gets no cells, and the renderer meets every wall for the
-        # rays that land on an agent there (the other envs keep their grids, and the launch stays one kernel)
-        dims = torch.where((self._lights.widths <= 64)[:, None], dims, torch.zeros_like(dims))
-        cells = (dims[:, 0]*dims[:, 1]).long()
         rep = torch.arange(n_envs, device=dev) if self._geom is None else self._geom.long()
-        own = cells*(rep == torch.arange(n_envs, device=dev))          # members own no cells
+        is_rep = rep == torch.arange(n_envs, device=dev)
+        cell, with_rows = float(self.LIGHT_GRID_CELL), True
+        while True:
+            dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
+            # the grid holds 64 lights per env: an env with more gets no cells, and the renderer meets every wall for the
+            # rays that land on an agent there (the other envs keep their grids, and the launch stays one kernel)
+            dims = torch.where((self._lights.widths <= 64)[:, None], dims, torch.zeros_like(dims))
+            cells = (dims[:, 0]*dims[:, 1]).long()
+            own = cells*is_rep                                             # members own no cells
+            total = int(own.sum())
+            words = min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1)
+            size = 24*(total + 1) + (20 if with_rows else 4)*words
+            if size <= self.LIGHT_GRID_BYTES or cell >= 8.:
+                break
+            if with_rows:
+                with_rows = False
+            else:
+                cell *= 2
         starts = (own.cumsum(0) - own)[rep].to(torch.int32)
         geom = torch.cat([origin, dims], 1).float()[rep].contiguous()
-        total = int(own.sum())
         vals = torch.zeros((total + 1, 4), dtype=torch.int32, device=dev)     # (+ a row for rays outside the last env's grid to read)
         lists = torch.zeros((total + 1, 2), dtype=torch.int32, device=dev)
-        pool = torch.zeros(min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1), dtype=torch.int32, device=dev)
-        rows = torch.zeros((pool.shape[0], 4), dtype=torch.float32, device=dev)      # the candidates' walls, next to their entries
+        pool = torch.zeros(words, dtype=torch.int32, device=dev)
+        # the candidates' walls, next to their entries (MsScenery.lg_pool_rows; optional)
+        rows = torch.zeros((words, 4), dtype=torch.float32, device=dev) if with_rows else None
+        self._lg_report = dict(bytes=size, cell=cell, cells=total, candidate_rows=with_rows, budget=self.LIGHT_GRID_BYTES,
+                               floorplans=int(is_rep.sum()))
+        if os.environ.get('MEGASTEP_VERBOSE'):
+            print(f'megastep_amd: light grid of {size/2**20:.0f} MiB: {total} cells of {cell:g} m over {int(is_rep.sum())} floorplans'
+                  + ('' if with_rows else ', without candidate rows') + (f' (asked for {self.LIGHT_GRID_CELL:g} m: over the '
+                  f'{self.LIGHT_GRID_BYTES/2**30:.1f} GiB budget)' if cell != self.LIGHT_GRID_CELL or not with_rows else ''), flush=True)
         return vals, starts.contiguous(), geom, cell, max(int(cells.max()), 1), lists, pool, rows
+
+    def grid_report(self):
+        """What bake() built around the floorplans, for logs and bench lines: {'wall_grid': {bytes, cell, floorplans, ...} or
+        None, 'light_grid': {bytes, cell, cells, candidate_rows, ...} or None} - the sizes actually allocated and the cell
+        sizes actually used (either grid coarsens itself to stay inside its byte budget)."""
+        return dict(wall_grid=self._wg_report, light_grid=self._lg_report)
 
     def _wall_bounds(self):
         """(n_envs, 2) lower and upper corner of each env's static walls (finite coordinates only; 0, 0 without any)."""
@@ -335,7 +384,7 @@ class Scenery:
     WALL_GRID_CELL = float(os.environ.get('MEGASTEP_WALL_GRID_CELL', .25))        # (the environment switch is for A/B runs)
     WALL_GRID_REACH = (.7, 1.3)
     WALL_GRID_NEAR = .12
-    WALL_GRID_BYTES = 8 << 30
+    WALL_GRID_BYTES = int(float(os.environ.get('MEGASTEP_WALL_GRID_BYTES', 8 << 30)))
     WALL_GRID_MAX_CELLS = 1 << 18       # per floorplan
     WALL_GRID_SCRATCH = 1 << 30         # bytes of bitmaps in flight while it is built
     WALL_GRID_COARSE = 4                # the parent level's cells, in cells (None: one level, every wall a candidate)
@@ -459,6 +508,7 @@ class Scenery:
         for cells WALL_GRID_COARSE times the size, whose lists are all that the cells proper then look at. Installs ``_wg``."""
         self._wg, self._struct = None, None
         self._wg_sum = None
+        self._wg_report = None
         if not self.WALL_GRID:
             return
         ln = self._lines
@@ -483,10 +533,21 @@ class Scenery:
                             float(self.WALL_GRID_NEAR), pool, near)
                 self._wg_sum = self._wall_checksum()
                 self._struct = None
-                if os.environ.get('MEGASTEP_VERBOSE'):
-                    size = sum(t.numel()*t.element_size() for t in (hdr, starts, geom, pool, near))
-                    print(f'megastep_amd: wall grid of {size/2**20:.0f} MiB for {int(usable.sum())} envs at {cell:g} m cells', flush=True)
+                size = sum(t.numel()*t.element_size() for t in (hdr, starts, geom, pool, near))
+                arange = torch.arange(len(ln), device=hdr.device)
+                reps = int((usable & ((self._geom.long() if self._geom is not None else arange) == arange)).sum())
+                self._wg_report = dict(bytes=size, cell=float(cell), cells=int(hdr.shape[0] - 1), envs=int(usable.sum()), floorplans=reps,
+                                       vis_entries=int(pool.numel() - 64), near_rows=int(near.shape[0] - 1), budget=self.WALL_GRID_BYTES,
+                                       coarsened=cell != self.WALL_GRID_CELL)
+                if os.environ.get('MEGASTEP_VERBOSE') or cell != self.WALL_GRID_CELL:
+                    # (a grid that had to coarsen costs the step 3-6 %: never silently)
+                    print(f'megastep_amd: wall grid of {size/2**20:.0f} MiB for {int(usable.sum())} envs ({reps} floorplans) at {cell:g} m cells'
+                          + (f' - {self.WALL_GRID_CELL:g} m cells would not fit WALL_GRID_BYTES = {self.WALL_GRID_BYTES/2**30:.1f} GiB'
+                             if cell != self.WALL_GRID_CELL else ''), flush=True)
                 return
+        self._wg_report = dict(bytes=0, cell=None, budget=self.WALL_GRID_BYTES, note='no env a grid could be built for, or none within the budget')
+        print(f'megastep_amd: no wall grid built (no env it could serve, or not even {4*self.WALL_GRID_CELL:g} m cells within WALL_GRID_BYTES = '
+              f'{self.WALL_GRID_BYTES/2**30:.1f} GiB): every ray and agent meets every wall of its env', flush=True)
 
     def _bake_plan(self):
         """Scratch for the two-phase bake (MsScenery.bake_vis): for each representative env, lights x ceil(texels/64)
@@ -601,7 +662,7 @@ def bake(scenery, scratch=True, wall_grid=True):
         scenery._build_wall_grid()
 
 
-def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None):
+def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None, config=None):
     """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
     returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230).
 
@@ -617,7 +678,8 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
       added to ``respawn['mask']`` (required with it), start over and take ``fresh`` as their new maximum;
     * ``imu=(out, ang_scale, speed_scale)``: the (N, A, 3) IMU observation of the state the step leaves behind.
 
-    ``out``: the :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating."""
+    ``out``: the :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating.
+    ``config``: the constants of this call (:func:`config`); default: the ones ``agents`` carry (a Core's do), else initialize()'s."""
     dev = scenery._device()
     _agents_on(agents, dev)
     shape = (len(scenery.lines), scenery.n_agents)
@@ -670,7 +732,7 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
     _check_grid(scenery, dev)
     with _on(dev):
         _lib.check(_lib.lib().ms_step_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
-                                              mv, ex, C.c_void_p(progress.data_ptr()), C.byref(_cfg()), _stream(dev)))
+                                              mv, ex, C.c_void_p(progress.data_ptr()), C.byref(_cfg(agents, config)), _stream(dev)))
     agents._cached = agents._use_cache
     agents._epoch += 1
     return Physics(progress) if out is None else out
@@ -683,11 +745,14 @@ CHECK_GRID = os.environ.get('MEGASTEP_CHECK_GRID', '0') not in ('', '0')
 
 
 def _check_grid(scenery, dev):
-    if CHECK_GRID and scenery._wg is not None and not torch.cuda.is_current_stream_capturing():
-        scenery.check_wall_grid()
+    if CHECK_GRID and scenery._wg is not None:
+        with _on(dev):                                                    # (the stream that matters is `dev`'s current one)
+            capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            scenery.check_wall_grid()
 
 
-def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None, seen=None):
+def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None, seen=None, config=None):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
 
@@ -713,7 +778,7 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
     n, a = agents.angles.shape
     if (n, a) != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery')
-    cfg = _cfg()
+    cfg = _cfg(agents, config)            # (``config=``: see physics)
     if seen is not None:
         stamp, epoch, count = seen
         if any(t.dtype != torch.int32 or not t.is_contiguous() for t in seen) or stamp.shape != (scenery.textures.vals.shape[0],) \

@@ -172,3 +172,29 @@ def test_wide_and_single_waves_share_a_launch_whatever_the_envs_per_xcd(groups, 
             _same(cuda.render(c.scenery, c.agents), want, (g, tail))
             d = cuda.render(c.scenery, c.agents, fields=('distances', 'indices'))
             assert np.array_equal(_bits(d.distances), _bits(wantd.distances)) and np.array_equal(_bits(d.indices), _bits(wantd.indices)), (g, tail)
+
+
+@pytest.mark.parametrize('n_envs,res,pinned', [(1, 256, 4), (100, 256, 2), (3, 512, 4), (9, 64, 1)])
+def test_the_workspace_is_never_written_past_its_declared_size(groups, n_envs, res, pinned):
+    """with several ray groups a wave every XCD gets as many blocks as the fullest one needs - more blocks than the
+    N A ceil(R/64) entries MS_RENDER_WORKSPACE_INTS provides a queue for (1 env x 4 agents x 256 rays pinned to four groups: 128
+    blocks, 16 entries) - and round 4 placed the agents' headings BEHIND the block count: past the end of the caller's buffer.
+    The self-contained path (no heading cache: render_prep_kernel fills the workspace) into a workspace of exactly the
+    declared size with a fence of sentinels behind it: the fence stands, and the frame is the cached path's bit for bit."""
+    from megastep_amd import cuda
+    c, _ = _world(n_envs, 4, res, 70, seed=5)
+    rng = np.random.RandomState(2)
+    util.random_velocities(c, rng)
+    cuda.physics(c.scenery, c.agents)
+    groups(pinned)
+    want = cuda.render(c.scenery, c.agents)                                  # headings from ms_physics' cache: no workspace in play
+    got = cuda.render(c.scenery, c.agents, telemetry=True)                   # allocates; we re-point its workspace below
+    N, A = c.n_envs, c.n_agents
+    words = 18 + N*A*((res + 63)//64) + 2*N*A                                # MS_RENDER_WORKSPACE_INTS(N, A, R)
+    fence = 4096
+    guarded = torch.full((words + fence,), 0x5a5a5a5a, dtype=torch.int32, device=c.device)
+    got._struct.workspace = guarded.data_ptr()
+    got = cuda.render(c.scenery, c.agents, telemetry=True, out=got)
+    torch.cuda.synchronize()
+    assert bool((guarded[words:] == 0x5a5a5a5a).all()), 'ms_render wrote past MS_RENDER_WORKSPACE_INTS words of workspace'
+    _same(got, want, (n_envs, res, pinned))

@@ -74,6 +74,27 @@ def test_scenery_and_agents_validation():
         cuda.initialize(.1, 64, 190, 10)
 
 
+def test_every_core_carries_its_own_constants():
+    """VERDICT r4 / SURVEY 5 "no globals => multi-device safe": the C-ABI takes MsConfig by value, and the Python side no longer
+    funnels it through one process-global either - a Core keeps its own and hangs it on its Agents; initialize()'s global is the
+    fallback for bare two-argument calls on hand-built Agents (the reference's only mode, kernels.cu:12-27)."""
+    from megastep_amd import core
+    s = scene.scenery([toys.box()], 1, device='cpu', bake=False)
+    a = core.Core(s, res=64, fov=130, fps=10)
+    b = core.Core(s, res=256, fov=70, fps=20)
+    assert (a.config.res, a.config.fov, a.config.fps) == (64, 130., 10.) and (b.config.res, b.config.fov) == (256, 70.)
+    assert cuda._cfg(a.agents) is a.config and cuda._cfg(b.agents) is b.config          # whichever Core came last
+    bare = cuda.Agents(a.agents.angles, a.agents.positions, a.agents.angvelocity, a.agents.velocity)
+    assert cuda._cfg(bare).res == 256                                                    # the fallback: the last initialize()
+    assert cuda._cfg(bare, a.config) is a.config and cuda._cfg(b.agents, a.config) is a.config   # config= wins
+    view = cuda.Agents(a.agents.angles, a.agents.positions, a.agents.angvelocity, a.agents.velocity, config=a.config)
+    assert cuda._cfg(view) is a.config
+    with pytest.raises(RuntimeError):
+        cuda._cfg(bare, (0.1, 64, 130., 10.))
+    with pytest.raises(RuntimeError):
+        cuda.config(.1, 64, 190, 10)
+
+
 def test_column_and_spaces():
     g = toys.column()
     np.testing.assert_allclose(sorted(g.lights.tolist()), [[2.5, 2.5], [2.5, 4.5], [4.5, 2.5], [4.5, 4.5]], atol=1e-12)
