@@ -68,6 +68,11 @@ PLAN_WORKERS = 0 if any('rocprof' in os.environ.get(k, '').lower() for k in ('LD
     else min(os.cpu_count() or 1, 32)
 
 
+# how those processes are started: 'fork' here (before the GPU is touched); tests that build benchmark worlds from inside a
+# process that has long been using its GPU set 'subprocess' (fresh numpy-only interpreters: megastep_amd.cubicasa.prefetch)
+PLAN_CONTEXT = 'fork'
+
+
 def log(msg):
     """Progress on stderr (stdout carries the one JSON line)."""
     if int(os.environ.get('RANK', 0)) == 0:
@@ -89,9 +94,9 @@ def world_geometries(n_envs, world, seed, n_unique=512, large=False, legacy=Fals
     from megastep_amd import cubicasa
     workers = PLAN_WORKERS
     if legacy:
-        pool = cubicasa.sample(min(512, n_envs), seed=seed + 1, n_unique=512, large=large, workers=workers)
+        pool = cubicasa.sample(min(512, n_envs), seed=seed + 1, n_unique=512, large=large, workers=workers, context=PLAN_CONTEXT)
     else:
-        pool = cubicasa.sample(n_unique, split='all', seed=seed + 1, n_unique=n_unique, large=large, workers=workers)
+        pool = cubicasa.sample(n_unique, split='all', seed=seed + 1, n_unique=n_unique, large=large, workers=workers, context=PLAN_CONTEXT)
     return [pool[i % len(pool)] for i in range(world*n_envs)]
 
 
@@ -548,6 +553,9 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None):
     return e
 
 
+C5_PLANS = 4096          # distinct large floorplans of C5's per-GPU share (the reference's pool: 4492)
+
+
 def other_shapes(dev, steps=20, warmup=5):
     """BASELINE.json's other single-GPU shapes, each timed with the headline's protocol at the driver's K / W: C2 (RGBD and
     depth-only), C3, the reference Deathmatch's own 512 rays, C5's per-GPU share, and the headline on rounds 1-3's
@@ -575,9 +583,15 @@ def other_shapes(dev, steps=20, warmup=5):
     out['r512'] = shape_entry(dev, c512, steps, warmup, note="the reference Deathmatch's own resolution (512 rays -> 128 px)")
     del c512
     torch.cuda.empty_cache()
-    c = world('C5 share', 32768, 1, 256, 130., n_unique=64, large=True, fast=True)
-    out['c5_per_gpu_share'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 5 / 8 GPUs: 32768 envs of 800-1200 walls, 64 distinct '
-                                          'plans tiled (one plan per env would be 32768 large plans: minutes of host-side generation)')
+    c = world('C5 share', 32768, 1, 256, 130., n_unique=C5_PLANS, large=True, fast=True)
+    out['c5_per_gpu_share'] = shape_entry(dev, c, steps, warmup, note=f'BASELINE config 5 / 8 GPUs: 32768 envs of 800-1200 walls on {C5_PLANS} distinct '
+                                          'plans tiled - the diversity of the reference, whose cubicasa.sample tiles 4492 geometries '
+                                          '(megastep/cubicasa.py:177-224); wall grid un-coarsened (see wall_grid)')
+    del c
+    torch.cuda.empty_cache()
+    c = world('C5 share, 64 plans', 32768, 1, 256, 130., n_unique=64, large=True, fast=True)
+    out['c5_per_gpu_share_64_plans'] = shape_entry(dev, c, steps, warmup, note="the same on rounds 3-4's 64 distinct plans (a 0.5 GB wall grid that "
+                                                   "lives in the caches): for continuity, not the figure of record")
     del c
     torch.cuda.empty_cache()
     c = world('headline, 460 plans', 4096, 4, 64, 130., legacy=True)
@@ -673,6 +687,7 @@ def main(argv=None):
     world_geometries(args.envs, 1, 1, n_unique, args.large, args.legacy_plans)
     if extras and not args.no_shapes:
         world_geometries(4096, 1, 1, 4096)
+        world_geometries(4096, 1, 1, C5_PLANS, large=True)
         world_geometries(4096, 1, 1, 64, large=True)
         world_geometries(4096, 1, 1, legacy=True)
     log('floorplans ready')

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 11
+#define MS_ABI_VERSION 12
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -118,10 +118,14 @@ typedef struct MsScenery {
      * the grid, or faster than wg_reach allows, meet every line as before.  Filled by ms_wallgrid_scan +
      * ms_wallgrid_fill (below) from the static walls as they are at that moment: the walls must not move afterwards
      * (or the grid must be rebuilt / dropped).  Envs that share their walls (env_geom) share their cells.
-     *   wg_cells  (sum cells + 1, 4) uint32: [first vis entry (in wg_pool), vis count, first near entry (in
+     *   wg_cells  (sum cells + 1, 4) uint32: [first vis entry (in wg_pool, from wg_pool_base[n]), vis count, first near entry (in
      *             wg_near_rows), near count within wg_reach_lo | near count in all << 16]
      *   wg_starts (N,) first cell of env n;   wg_geom (N, 4) float: grid origin x, y, cells along x, cells along y
      *             (0 cells: this env has no grid);   wg_cell: cell size in metres
+     *   wg_pool_base (N,) int64, required with wg_cells: where in wg_pool the vis lists of env n's floorplan start, in entries;
+     *             a cell's "first vis entry" counts from there.  (Round 5: a world of 4096 distinct 1000-wall floorplans - the
+     *             reference's cubicasa pool is 4492 - has 6 x 10^9 vis entries at 0.25 m cells, more than a 32-bit offset
+     *             reaches; per floorplan it is a few million.)  Envs that share their walls share the value.
      *   wg_pool   the vis lists, one uint32 per entry: wall index | first step << 16 | last step << 24 of the arc of
      *             directions the wall can be seen in from the cell (steps of 1/64 of a quarter turn-like unit, modulo 256:
      *             ms_render skips entries whose arc misses its rays'); at least 64 entries longer than the lists need
@@ -136,6 +140,7 @@ typedef struct MsScenery {
     float                 wg_reach_lo, wg_reach;
     float                 wg_near;
     const unsigned*       wg_pool;
+    const long long*      wg_pool_base;
     const float*          wg_near_rows;
     /* Optional: the largest distance of a point of `model` from the agent's origin, 0 = not known.  When it is below
      * the near plane (MsConfig.agent_radius, as in the reference: core.py:14, scene.py:25-33), no ray of an agent can
@@ -276,7 +281,8 @@ int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* 
  *                     max_groups: with a parent the most parent cells any listed env has, without ceil(most cells / 4).
  *   ms_wallgrid_fill  writes the lists: the set bits of each row, in order, from the cell's wg_cells offsets (which the
  *                     caller has filled in from the counts) - vis lists as entries of `vis_entries` (MsScenery.wg_pool's
- *                     format), near lists as rows into `near_rows`; or, for a parent level (both NULL), both lists as
+ *                     format) from the env's wg_pool_base on (which the scenery must carry then), near lists as rows into
+ *                     `near_rows`; or, for a parent level (both NULL; wg_pool_base is not looked at), both lists as
  *                     16-bit indices into `pool`.
  * An env with more than 65535 static walls must have a grid of 0 cells. */
 #define MS_WALLGRID_MAX_FOV 165.f

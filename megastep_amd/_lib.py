@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -36,7 +36,7 @@ class MsScenery(C.Structure):
         ('lg_max_cells', C.c_int), ('lg_list', C.c_void_p), ('lg_pool', C.c_void_p), ('lg_pool_size', C.c_int), ('lg_pool_rows', C.c_void_p),
         ('env_geom', C.c_void_p), ('bake_vis', C.c_void_p), ('bake_vis_starts', C.c_void_p), ('bake_vis_words', C.c_longlong),
         ('wg_cells', C.c_void_p), ('wg_starts', C.c_void_p), ('wg_geom', C.c_void_p), ('wg_cell', C.c_float),
-        ('wg_reach_lo', C.c_float), ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p), ('wg_near_rows', C.c_void_p),
+        ('wg_reach_lo', C.c_float), ('wg_reach', C.c_float), ('wg_near', C.c_float), ('wg_pool', C.c_void_p), ('wg_pool_base', C.c_void_p), ('wg_near_rows', C.c_void_p),
         ('model_radius', C.c_float)]
 
 

@@ -352,7 +352,11 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #ifndef MS_VCAP_WIDE
 #define MS_VCAP_WIDE 110
 #endif
-__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVES, MS_WAVES))) void render_kernel(
+// (MS_WAVES_WIDE: the same for the colour instantiations of several ray groups a wave - an A/B knob: at 5 they need no scratch)
+#ifndef MS_WAVES_WIDE
+#define MS_WAVES_WIDE MS_WAVES
+#endif
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1 && SHADE) ? MS_WAVES_WIDE : MS_WAVES, (NG > 1 && SHADE) ? MS_WAVES_WIDE : MS_WAVES))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
@@ -415,10 +419,11 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
     const int base = sc.lines_starts[n];
     // (the env's row of the wall grid is asked for here, with the env's other rows: where it is used - once the agent's
     // position is known - it would be one more round trip in the chain position -> cell -> list -> walls)
-    // (Unconditionally: ms_render points wg_geom / wg_starts at rows that exist when there is no grid, so that these two
+    // (Unconditionally: ms_render points wg_geom / wg_starts / wg_pool_base at rows that exist when there is no grid, so that these
     // are part of the one batch of loads and not the body of a branch with a round trip of its own.)
     const float4 wg_geom_n = reinterpret_cast<const float4*>(sc.wg_geom)[n];
     const int wg_start_n = sc.wg_starts[n];
+    const long long wg_pool_base_n = sc.wg_pool_base[n];                 // (its floorplan's vis lists: 64 bits - see MsScenery)
     float4* __restrict__ ln = reinterpret_cast<float4*>(sc.lines_vals) + base;
     const LineRows rows(ln, L);
     // --- every agent's heading and position, once per wave: lane i holds agent i (i < A <= 64; above that the
@@ -650,8 +655,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
                     reinterpret_cast<LightPair*>(&s_raw[wave][O_EPI]), reinterpret_cast<unsigned*>(&s_raw[wave][O_EPI + 2048]), light_telemetry);
 #endif
                 PROBE_VAL(2, light_telemetry)
-            } else if (out.workspace) {
-                if (lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
+            } else if constexpr (NG == 1) {      // (wide waves never come here: without a light grid ms_render launches NG = 1 -
+                // and `fan`, which nothing else needs, was one of the values the wide colour instantiations spilled)
+                if (out.workspace && lane == 0) out.workspace[16 + atomicAdd(&out.workspace[0], 1)] = fan;
             }
         }
         // the 2-tap filter, and the texels and baked light under it - again for every lane (a miss looks at texel 0 of the
@@ -1175,7 +1181,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(MS_WAVE
         const int own0 = a*sc.n_model, own = rc.skip_own ? sc.n_model : 0;
         const int AL = AF - own;                                             // agent lines among the items
         const __amdgpu_buffer_rsrc_t list_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned*>(sc.wg_pool + wg_first), 0, listed ? 4*n_raw : 0, 0x00020000);
+            const_cast<unsigned*>(sc.wg_pool + wg_pool_base_n + wg_first), 0, listed ? 4*n_raw : 0, 0x00020000);
         auto raw = [&](const int k0) {                                       // entries k0 + lane of the list (past its end: 0)
             return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(list_rsrc, 4*(k0 + lane), 0, 0);
         };

@@ -302,6 +302,8 @@ __global__ __launch_bounds__(WG) void wallgrid_fill_kernel(const MsScenery sc, c
     const int W32 = (n_walls + 31) >> 5;
     const uint4 hdr = reinterpret_cast<const uint4*>(sc.wg_cells)[(size_t)sc.wg_starts[n] + c];
     unsigned at = kind ? hdr.z : hdr.x;
+    // (the vis lists of the final level count from the floorplan's own place in the pool: MsScenery.wg_pool_base)
+    if (vis_entries) vis_entries += sc.wg_pool_base[n];
     for (int r = kind; r < (kind ? WG_ROWS : 1); r++) {
         const unsigned* __restrict__ row = bits + bits_starts[n] + (long long)(WG_ROWS*c + r)*W32;
         for (int w0 = 0; w0 < W32; w0 += WAVE) {                         // lane = word

@@ -399,7 +399,7 @@ int ms_wallgrid_fill(const MsScenery* sc, const int* reps, int n_reps, int max_c
                      const long long* bits_starts, const unsigned* bits, unsigned short* pool, unsigned* vis_entries, float* near_rows,
                      void* stream) {
     if (!scenery_ok(sc) || !wallgrid_ok(sc) || !sc->wg_cells || ((uintptr_t)sc->wg_cells % 16) || !reps || n_reps < 0 || max_cells < 0 ||
-        !bits_starts || !bits || ((vis_entries != nullptr) != (near_rows != nullptr)) || (!pool && !vis_entries) ||
+        !bits_starts || !bits || ((vis_entries != nullptr) != (near_rows != nullptr)) || (!pool && !vis_entries) || (vis_entries && !sc->wg_pool_base) ||
         ((uintptr_t)near_rows % 16) || ((uintptr_t)vis_entries % 4)) return MS_EINVAL;
     if (n_reps == 0 || max_cells == 0) return MS_OK;
     const long long blocks = (2LL*max_cells + WAVES - 1)/WAVES;
@@ -498,13 +498,14 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     if (!grid) scn.lg_vals = nullptr;
     // ... and so is the wall grid: its vis lists were built for near planes below wg_near and ray direction vectors no
     // longer than sqrt(WG_MAX_RU2) (wallgrid_scan_kernel); a call outside that meets every wall instead
-    const bool walls_listed = sc->wg_cells && sc->wg_starts && sc->wg_geom && sc->wg_pool && sc->wg_cell > 0.f &&
+    const bool walls_listed = sc->wg_cells && sc->wg_starts && sc->wg_geom && sc->wg_pool && sc->wg_pool_base && sc->wg_cell > 0.f &&
                               cfg->agent_radius*1.001f < sc->wg_near && 1.f + half_screen*half_screen <= WG_MAX_RU2;
     if (walls_listed && (((uintptr_t)sc->wg_cells % 16) || ((uintptr_t)sc->wg_geom % 16))) return MS_EINVAL;
     if (!walls_listed) {                                                 // (the kernel reads a row of each whatever happens: see there)
         scn.wg_cells = nullptr;
         scn.wg_geom = sc->lines_vals;                                    // at least 16 bytes per env: every env has its agents' lines
         scn.wg_starts = sc->lines_starts;
+        scn.wg_pool_base = reinterpret_cast<const long long*>(sc->lines_vals);   // (16 bytes of lines per env at least: 8 are there)
     }
     // Headings: from ms_physics' cache when the agents carry one and a single kernel does the whole job (then the
     // workspace is not needed at all); otherwise from render_prep_kernel, which also resets the workspace's counters.

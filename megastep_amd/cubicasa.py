@@ -137,17 +137,21 @@ def _make(keys):
     return [(key, floorplan(1000003*int(key[1]) + key[0], key[1])) for key in keys]
 
 
-def prefetch(indices, large=False, workers=None):
-    """Generates the plans ``indices`` that are not cached yet on ``workers`` forked processes (a plan takes ~7 ms of
-    numpy on one core; the benchmark's Explorer-style worlds want thousands of distinct ones). Fork only: call it before
-    the process has touched its GPU. Same plans as the lazy path - a plan is a function of its index alone."""
+def prefetch(indices, large=False, workers=None, context='fork'):
+    """Generates the plans ``indices`` that are not cached yet on ``workers`` worker processes (a plan takes ~7 ms of
+    numpy on one core, a large one 23; the benchmark's Explorer-style worlds want thousands of distinct ones). ``context``
+    'fork' (cheap; call it before the process has touched its GPU) or 'subprocess' (fresh numpy-only interpreters that
+    load this file and geometry.py on their own: safe at any time - from a test that has been using the GPU for a minute -
+    for a fraction of a second of start-up). Same plans as the lazy path - a plan is a function of its index alone."""
     import multiprocessing as mp
     import os
     todo = sorted({(int(i), bool(large)) for i in indices} - set(_cache))
     workers = min(workers or (os.cpu_count() or 1), 32, max(len(todo)//16, 1))
     if workers <= 1 or len(todo) < 64:
         return
-    with mp.get_context('fork').Pool(workers) as pool:
+    if context == 'subprocess':
+        return _prefetch_subprocess(todo, workers)
+    with mp.get_context(context).Pool(workers) as pool:
         chunks = [todo[i:i + 8] for i in range(0, len(todo), 8)]
         results = pool.imap_unordered(_make, chunks)
         try:
@@ -158,12 +162,51 @@ def prefetch(indices, large=False, workers=None):
             pool.terminate()
 
 
-def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0):
+_WORKER = """
+import importlib.util, pickle, sys, types
+here, todo_path, out_path = sys.argv[1:4]
+pkg = types.ModuleType('_ms_plans'); pkg.__path__ = [here]; sys.modules['_ms_plans'] = pkg
+stub = types.ModuleType('_ms_plans.arrdict'); stub.arrdict = dict; sys.modules['_ms_plans.arrdict'] = stub     # (no torch in here)
+for name in ('geometry', 'cubicasa'):
+    spec = importlib.util.spec_from_file_location('_ms_plans.' + name, here + '/' + name + '.py')
+    mod = importlib.util.module_from_spec(spec); sys.modules['_ms_plans.' + name] = mod; spec.loader.exec_module(mod)
+keys = pickle.load(open(todo_path, 'rb'))
+pickle.dump([(k, dict(mod.floorplan(1000003*int(k[1]) + k[0], k[1]))) for k in keys], open(out_path, 'wb'), protocol=4)
+"""
+
+
+def _prefetch_subprocess(todo, workers):
+    """The missing plans made by `workers` fresh interpreters (numpy only), exchanged through pickles in a temp dir."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for w in range(workers):
+            part = todo[w::workers]
+            if not part:
+                continue
+            src, dst = os.path.join(tmp, f'todo{w}.pkl'), os.path.join(tmp, f'plans{w}.pkl')
+            pickle.dump(part, open(src, 'wb'))
+            procs.append((subprocess.Popen([sys.executable, '-c', _WORKER, here, src, dst], env=dict(os.environ, OMP_NUM_THREADS='1')), dst))
+        for proc, dst in procs:
+            try:
+                if proc.wait(timeout=300) == 0:
+                    for key, plan in pickle.load(open(dst, 'rb')):
+                        _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if key[1] else "S"}{key[0]:04d}', **plan)
+            except subprocess.TimeoutExpired:                          # (the lazy path makes what is missing)
+                proc.kill()
+
+
+def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0, context='fork'):
     """A deterministic sample of ``n_geometries`` floorplans; same arguments, same sample (reference:
     cubicasa.py:177-224). ``split`` is 90/10 ``training``/``test`` or ``all`` over ``n_unique`` plans; plans are
     generated lazily and repeat cyclically when more are asked for than the split holds. ``large`` and ``n_unique`` are
     extensions for the big-map benchmark point and for cheap tests; ``workers`` > 1 generates the missing plans on that
-    many forked processes first (see :func:`prefetch`)."""
+    many worker processes first (see :func:`prefetch`; ``context``: how they are started)."""
     cutoff = int(.9*n_unique)
     order = np.random.RandomState(seed).permutation(n_unique)
     if split == 'training':
@@ -173,5 +216,5 @@ def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQU
     elif split != 'all':
         raise ValueError('Split must be train/test/all')
     if workers and workers > 1:
-        prefetch(order[:n_geometries], large, workers)
+        prefetch(order[:n_geometries], large, workers, context)
     return [_plan(order[i % len(order)], large) for i in range(n_geometries)]

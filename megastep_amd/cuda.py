@@ -11,6 +11,7 @@ reference: docs/faq.rst:23-26): calling bake/physics/render on non-GPU tensors r
 import ctypes as C
 import numbers
 import os
+import sys
 import torch
 from . import _lib
 
@@ -247,7 +248,7 @@ class Scenery:
         self._lg = None             # the light grid's tensors; made by _as_struct unless sharding carried one over
         self._wg_sum = None         # checksum of the static walls the wall grid was built from
         self._wg_weights = None
-        self._wg = None             # the wall grid's tensors (cells, starts, geom, cell, reach, near, pool); made by bake()
+        self._wg = None             # the wall grid's tensors (cells, starts, geom, cell, reaches, near plane, pool, near rows, pool bases); made by bake()
         self._wg_report = self._lg_report = None      # what was built, at which cell size, in how many bytes (grid_report())
         self._dev = None
 
@@ -372,9 +373,9 @@ class Scenery:
     def _wall_grid_fields(self):
         wg = self._wg
         if wg is None:
-            return (None, None, None, 0., 0., 0., 0., None, None)
-        cells, starts, geom, cell, reach_lo, reach, near, pool, rows = wg
-        return (cells.data_ptr(), starts.data_ptr(), geom.data_ptr(), cell, reach_lo, reach, near, pool.data_ptr(), rows.data_ptr())
+            return (None, None, None, 0., 0., 0., 0., None, None, None)
+        cells, starts, geom, cell, reach_lo, reach, near, pool, rows, pool_base = wg
+        return (cells.data_ptr(), starts.data_ptr(), geom.data_ptr(), cell, reach_lo, reach, near, pool.data_ptr(), pool_base.data_ptr(), rows.data_ptr())
 
     #: the wall grid (include/megastep_hip.h, MsScenery.wg_*): cell size in metres; the step lengths its collision lists
     #: cover (0.7 m: the momentum module at its defaults never reaches farther; 1.3 m: nor does the simple one at 10 fps);
@@ -384,10 +385,19 @@ class Scenery:
     WALL_GRID_CELL = float(os.environ.get('MEGASTEP_WALL_GRID_CELL', .25))        # (the environment switch is for A/B runs)
     WALL_GRID_REACH = (.7, 1.3)
     WALL_GRID_NEAR = .12
-    WALL_GRID_BYTES = int(float(os.environ.get('MEGASTEP_WALL_GRID_BYTES', 8 << 30)))
+    #: (bytes; None: a quarter of the device's memory - 72 GB of an MI355X's 288: the headline world's 1024 plans take 1.7 GB,
+    #: C2's 4096 plans 6.9 GB, 4096 large plans - C5's share on the reference's floorplan diversity - 35 GB at 0.25 m cells;
+    #: with rounds 3-4's flat 8 GiB that world fell back to 1 m cells and a step a third slower)
+    WALL_GRID_BYTES = int(float(os.environ['MEGASTEP_WALL_GRID_BYTES'])) if os.environ.get('MEGASTEP_WALL_GRID_BYTES') else None
     WALL_GRID_MAX_CELLS = 1 << 18       # per floorplan
     WALL_GRID_SCRATCH = 1 << 30         # bytes of bitmaps in flight while it is built
     WALL_GRID_COARSE = 4                # the parent level's cells, in cells (None: one level, every wall a candidate)
+
+    def _wall_grid_budget(self):
+        if self.WALL_GRID_BYTES is not None:
+            return int(self.WALL_GRID_BYTES)
+        dev = self._device()
+        return torch.cuda.get_device_properties(dev).total_memory//4
 
     def _scan_level(self, cell, parent, final, usable):
         """One level of the wall grid: cells of size `cell` over every representative floorplan, scanned (against the
@@ -431,7 +441,12 @@ class Scenery:
         group = torch.maximum((words.cumsum(0) - words)*4//self.WALL_GRID_SCRATCH, torch.arange(len(reps), device=dev)//60000)
         bounds = [0] + (torch.nonzero(group[1:] != group[:-1]).flatten() + 1).tolist() + [len(reps)]
         pools, nears = [], []
+        budget = self._wall_grid_budget()
         cell_rows = torch.zeros((total + 1, 4), dtype=torch.int64, device=dev)     # (+ the row agents outside the last grid read)
+        # where each floorplan's vis lists start in the pool (MsScenery.wg_pool_base; the final level's cells count their
+        # "first vis entry" from there: a world of thousands of large plans has more entries than 32 bits number)
+        pool_base = torch.zeros(n_envs, dtype=torch.int64, device=dev)
+        struct.wg_pool_base = pool_base.data_ptr()
         base_p = base_n = 0
         with _on(dev):
             for g0, g1 in zip(bounds[:-1], bounds[1:]):
@@ -450,15 +465,21 @@ class Scenery:
                 rows = torch.repeat_interleave(starts[r].long() - (span.cumsum(0) - span), span) + torch.arange(int(span.sum()), device=dev)
                 cnt = counts[rows].long()                              # (cells, 3): vis, near within the short reach, near beyond
                 n_vis, n_near = cnt[:, 0], cnt[:, 1] + cnt[:, 2]
-                if final:                                              # vis -> pool (indices), near -> rows
-                    off_v, off_n = n_vis.cumsum(0) - n_vis + base_p, n_near.cumsum(0) - n_near + base_n
+                if final:                                              # vis -> pool (entries), near -> rows
+                    off_v, off_n = n_vis.cumsum(0) - n_vis, n_near.cumsum(0) - n_near + base_n
                     add_p, add_n = int(n_vis.sum()), int(n_near.sum())
+                    # ... the vis lists numbered from their floorplan's own start
+                    first_cell = span.cumsum(0) - span                 # each representative's first cell among this group's
+                    rep_off = off_v[first_cell.clamp(max=len(off_v) - 1)]
+                    pool_base[r] = rep_off + base_p
+                    off_v = off_v - torch.repeat_interleave(rep_off, span)
                 else:                                                  # both lists as indices, back to back
                     both = torch.stack([n_vis, n_near], 1).flatten()
                     off = (both.cumsum(0) - both + base_p).view(-1, 2)
                     off_v, off_n = off[:, 0], off[:, 1]
                     add_p, add_n = int(both.sum()), 0
-                if (4 if final else 2)*(base_p + add_p) + 16*(base_n + add_n) > self.WALL_GRID_BYTES or base_p + add_p >= 2**32 - 64 \
+                if (4 if final else 2)*(base_p + add_p) + 16*(base_n + add_n) > budget \
+                        or (not final and base_p + add_p >= 2**32 - 64) or (final and int(off_v.max()) + int(n_vis.max()) >= 2**32 - 64) \
                         or base_n + add_n >= 2**32 \
                         or int(n_near.max()) > 65535:
                     return None
@@ -471,7 +492,7 @@ class Scenery:
                 # the fill kernel writes at the headers' offsets: hand it this group's pools displaced by what came before
                 _lib.check(h.ms_wallgrid_fill(C.byref(struct), r32.data_ptr(), len(r), mc, bits_starts.data_ptr(), bits.data_ptr(),
                                               None if final else C.c_void_p(pool.data_ptr() - 2*base_p),
-                                              C.c_void_p(pool.data_ptr() - 4*base_p) if final else None,
+                                              C.c_void_p(pool.data_ptr() - 4*base_p) if final else None,      # (+ wg_pool_base[n], in the kernel)
                                               C.c_void_p(near.data_ptr() - 16*base_n) if final else None, _stream(dev)))
                 torch.cuda.current_stream(dev).synchronize()           # (hdr / bits / pools of this group are done with)
                 pools.append(pool[:add_p])
@@ -480,7 +501,8 @@ class Scenery:
                 base_p, base_n = base_p + add_p, base_n + add_n
         pool = torch.cat(pools + [torch.zeros(64, dtype=pools[0].dtype, device=dev)])
         near = torch.cat(nears + [torch.zeros((1, 4), dtype=torch.float32, device=dev)]) if final else None
-        return _as_u32(cell_rows), starts, geom, pool, near, cells.to(torch.int32)
+        pool_base = pool_base[rep].contiguous()                       # (members: their representative's)
+        return _as_u32(cell_rows), starts, geom, pool, near, cells.to(torch.int32), pool_base
 
     def _wall_checksum(self):
         """A 64-bit checksum of the static walls' rows as they are now (their bits, position-weighted, summed modulo 2^64):
@@ -524,30 +546,30 @@ class Scenery:
             if self.WALL_GRID_COARSE:
                 level = self._scan_level(cell*self.WALL_GRID_COARSE, None, False, usable)
                 if level is not None:
-                    hdr, starts, geom, pool, _, cells = level
+                    hdr, starts, geom, pool, _, cells, _ = level
                     parent = (hdr, starts, geom, float(cell*self.WALL_GRID_COARSE), pool, cells)
             level = self._scan_level(cell, parent, True, usable)
             if level is not None:
-                hdr, starts, geom, pool, near, _ = level
+                hdr, starts, geom, pool, near, _, pool_base = level
                 self._wg = (hdr, starts, geom, float(cell), float(self.WALL_GRID_REACH[0]), float(self.WALL_GRID_REACH[1]),
-                            float(self.WALL_GRID_NEAR), pool, near)
+                            float(self.WALL_GRID_NEAR), pool, near, pool_base)
                 self._wg_sum = self._wall_checksum()
                 self._struct = None
-                size = sum(t.numel()*t.element_size() for t in (hdr, starts, geom, pool, near))
+                size = sum(t.numel()*t.element_size() for t in (hdr, starts, geom, pool, near, pool_base))
                 arange = torch.arange(len(ln), device=hdr.device)
                 reps = int((usable & ((self._geom.long() if self._geom is not None else arange) == arange)).sum())
                 self._wg_report = dict(bytes=size, cell=float(cell), cells=int(hdr.shape[0] - 1), envs=int(usable.sum()), floorplans=reps,
-                                       vis_entries=int(pool.numel() - 64), near_rows=int(near.shape[0] - 1), budget=self.WALL_GRID_BYTES,
+                                       vis_entries=int(pool.numel() - 64), near_rows=int(near.shape[0] - 1), budget=self._wall_grid_budget(),
                                        coarsened=cell != self.WALL_GRID_CELL)
                 if os.environ.get('MEGASTEP_VERBOSE') or cell != self.WALL_GRID_CELL:
                     # (a grid that had to coarsen costs the step 3-6 %: never silently)
                     print(f'megastep_amd: wall grid of {size/2**20:.0f} MiB for {int(usable.sum())} envs ({reps} floorplans) at {cell:g} m cells'
-                          + (f' - {self.WALL_GRID_CELL:g} m cells would not fit WALL_GRID_BYTES = {self.WALL_GRID_BYTES/2**30:.1f} GiB'
-                             if cell != self.WALL_GRID_CELL else ''), flush=True)
+                          + (f' - {self.WALL_GRID_CELL:g} m cells would not fit WALL_GRID_BYTES = {self._wall_grid_budget()/2**30:.1f} GiB'
+                             if cell != self.WALL_GRID_CELL else ''), file=sys.stderr, flush=True)
                 return
-        self._wg_report = dict(bytes=0, cell=None, budget=self.WALL_GRID_BYTES, note='no env a grid could be built for, or none within the budget')
+        self._wg_report = dict(bytes=0, cell=None, budget=self._wall_grid_budget(), note='no env a grid could be built for, or none within the budget')
         print(f'megastep_amd: no wall grid built (no env it could serve, or not even {4*self.WALL_GRID_CELL:g} m cells within WALL_GRID_BYTES = '
-              f'{self.WALL_GRID_BYTES/2**30:.1f} GiB): every ray and agent meets every wall of its env', flush=True)
+              f'{self._wall_grid_budget()/2**30:.1f} GiB): every ray and agent meets every wall of its env', file=sys.stderr, flush=True)
 
     def _bake_plan(self):
         """Scratch for the two-phase bake (MsScenery.bake_vis): for each representative env, lights x ceil(texels/64)

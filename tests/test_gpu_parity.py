@@ -161,11 +161,14 @@ def test_agent_wedged_between_coincident_walls():
 
 
 def test_full_benchmark_size_matches_oracle():
-    """BASELINE.json's metric shape - 4096 envs x 4 agents x 64 rays on synthetic cubicasa plans - against the
+    """BASELINE.json's metric shape - 4096 envs x 4 agents x 64 rays on synthetic cubicasa plans, the bench's own world: 1024
+    distinct plans tiled (SURVEY 8(d): N // 4), its wall grid and light grid the size the bench steps through - against the
     oracle (OpenMP over envs), two steps."""
     from megastep_amd import cuda
     import bench
-    c, geometries = bench.build_world(4096, 4, 64, 130., torch.device('cuda'), seed=1, n_unique=128)
+    bench.PLAN_CONTEXT = 'subprocess'                                      # (this process has been using its GPU for a while)
+    c, geometries = bench.build_world(4096, 4, 64, 130., torch.device('cuda'), seed=1, n_unique=bench.plan_count(4096, 4))
+    assert len({id(g) for g in geometries}) == 1024 and c.scenery.grid_report()['wall_grid']['floorplans'] == 1024
     ref = util.OracleWorld(c)
     ref.pull_baked(c)
     rng = np.random.RandomState(5)

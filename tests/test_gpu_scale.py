@@ -15,7 +15,8 @@ def _big_world(n_envs, n_agents, res, fov, n_distinct, large=False, fast=True, s
     from megastep_amd import core, cubicasa, modules, scene
     np.random.seed(seed)
     torch.manual_seed(seed)
-    pool = cubicasa.sample(n_distinct, n_unique=max(n_distinct, 16), seed=seed + 1, large=large)
+    # (thousands of plans: made by a few dozen fresh numpy-only interpreters - this process has a GPU context to keep out of a fork)
+    pool = cubicasa.sample(n_distinct, split='all', n_unique=max(n_distinct, 16), seed=seed + 1, large=large, workers=32, context='subprocess')
     geometries = [pool[i % len(pool)] for i in range(n_envs)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -53,20 +54,41 @@ def _check_sample(c, envs, steps=2, seed=3):
 
 
 def test_c2_explorer_shape_full_size():
-    """C2: 4096 envs x 1 agent x 64 rays (512 distinct floorplans: generating them is what takes time here)."""
-    c, _, t = _big_world(4096, 1, 64, 130, n_distinct=512, fast=True)
+    """C2: 4096 envs x 1 agent x 64 rays, one floorplan per env as Explorer builds it (explorer.py:11) and as the bench's C2
+    world is: 4096 distinct plans, a 7 GB wall grid."""
+    c, geoms, t = _big_world(4096, 1, 64, 130, n_distinct=4096, fast=True)
+    assert len({id(g) for g in geoms}) == 4096 and not c.scenery.grid_report()['wall_grid']['coarsened']
     exact = _check_sample(c, [0, 1, 1023, 1024, 2500, 4095])
     print('C2 timings (s):', t, 'baked bitwise-equal fraction:', exact)
 
 
 def test_c3_deathmatch_shape_full_size():
     """C3: 4096 envs x 4 agents x 128 rays, floorplans tiled n/4 as Deathmatch does (deathmatch.py:24)."""
-    c, geoms, t = _big_world(4096, 4, 128, 70, n_distinct=512, fast=True)
+    c, geoms, t = _big_world(4096, 4, 128, 70, n_distinct=1024, fast=True)
     n_distinct = len({id(g) for g in geoms})
-    assert 256 < n_distinct <= 512
+    assert n_distinct == 1024
     assert c.scenery.geom is not None and int((c.scenery.geom == torch.arange(4096, device='cuda')).sum()) == n_distinct
     exact = _check_sample(c, [0, 5, 512, 3000, 4095])
     print('C3 timings (s):', t, 'baked bitwise-equal fraction:', exact)
+
+
+def test_c5_per_gpu_shape_on_the_references_floorplan_diversity():
+    """C5's per-GPU share on what the reference tiles - 4492 distinct geometries (megastep/cubicasa.py:177-224); here 4096
+    distinct 800-1200-wall plans, 8 envs each: a wall grid of 35 GB and six billion vis entries at 0.25 m cells - more than a
+    32-bit offset numbers, hence MsScenery.wg_pool_base - built un-coarsened inside the default budget (a quarter of the
+    device's memory; rounds 3-4's flat 8 GiB sent this world to 1 m cells). A sample of envs from both ends of the pool against
+    the oracle: the entries past the 2^32nd are the ones the last envs' rays walk."""
+    from megastep_amd import cuda
+    c, geoms, t = _big_world(32768, 1, 256, 130, n_distinct=4096, large=True, fast=True)
+    rep = c.scenery.grid_report()['wall_grid']
+    print('C5 / 4096 plans timings (s):', t, 'wall grid:', rep)
+    assert len({id(g) for g in geoms}) == 4096 and rep['floorplans'] == 4096
+    assert rep['cell'] == cuda.Scenery.WALL_GRID_CELL and not rep['coarsened']
+    assert rep['vis_entries'] > 3*2**30                                 # (measured: 6.9 x 10^9)
+    if rep['vis_entries'] > 2**32:
+        assert int(c.scenery._wg[9].max()) > 2**32                      # pool bases beyond 32 bits are in play
+    exact = _check_sample(c, [0, 1, 4095, 4096, 20000, 28671, 32766, 32767], steps=2)
+    print('C5 / 4096 plans baked bitwise-equal fraction:', exact)
 
 
 def test_c5_per_gpu_shape_full_size():

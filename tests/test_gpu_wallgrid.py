@@ -28,10 +28,12 @@ def test_lists_built_on_the_gpu_are_the_host_scans():
     c, geometries = _world(12, 2, n_unique=5)
     sc = c.scenery
     assert sc._wg is not None
-    cells, starts, geom, cell, reach_lo, reach, near, pool, rows = sc._wg
+    cells, starts, geom, cell, reach_lo, reach, near, pool, rows, pool_base = sc._wg
     assert (reach_lo, reach, near) == tuple(np.float32([REACH_LO, REACH, NEAR]).astype(float)) or (reach_lo, reach, near) == (REACH_LO, REACH, NEAR)
     cells = cells.cpu().numpy().view(np.uint32)
     starts, geom, pool, rows = starts.cpu().numpy(), geom.cpu().numpy(), pool.cpu().numpy().view(np.uint32), rows.cpu().numpy()
+    pool_base = pool_base.cpu().numpy()                                 # (int64: where each env's floorplan's vis lists start)
+    assert pool_base[0] == pool_base[5] == pool_base[10] and len(set(pool_base[:5])) == 5 and pool_base.min() == 0
     AF = sc.n_agents*sc.model.shape[0]
     rng = np.random.RandomState(0)
     # envs of one floorplan share their cells
@@ -43,6 +45,7 @@ def test_lists_built_on_the_gpu_are_the_host_scans():
         for c_ in rng.choice(dims[0]*dims[1], 30, replace=False):
             vis, close = scan_cell(walls, origin, dims, c_, cell)
             v0, vn, n0, nn = cells[starts[n] + c_]
+            v0 = int(v0) + int(pool_base[n])                            # a cell's first vis entry counts from its floorplan's base
             n_lo, n_all = nn & 0xffff, nn >> 16
             # built through the coarse level: nothing the one-level scan lists may be missing, and next to nothing more
             # (an occluder the coarse cell's list lacks has a stand-in on it, which the thresholds may judge differently)
