@@ -150,6 +150,11 @@ def algorithmic_bytes(core, fields=None):
     physics = (16*(L - N*A*M) + 8*N        # wall segments + offsets read once per env
                + 48*N*A                    # agent state read + written
                + 4*N*A)                    # progress
+    rep = sc.grid_report().get('wall_grid') if hasattr(sc, 'grid_report') else None
+    if rep and rep.get('cells'):
+        # with a wall grid ms_physics does not stream the env's walls: an agent reads its cell's header and the rows of the
+        # walls near the cell (the mean list over the grid's cells) - THAT is what the step asks of the memory system
+        physics = N*A*(16 + 16*rep['near_rows']/rep['cells']) + 8*N + 52*N*A
     return render, physics
 
 
@@ -183,18 +188,8 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
             env.step(arrdict.arrdict(actions=acts[warmup + i]))
         torch.cuda.synchronize()
         eager = n*steps/(time.perf_counter() - t0)
-        # the same step captured once in a HIP graph and replayed (possible because nothing in it syncs with the host)
-        static = acts[0].clone()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            env.step(arrdict.arrdict(actions=static))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            static.copy_(acts[warmup + i])
-            graph.replay()
-        torch.cuda.synchronize()
-        return eager, n*steps/(time.perf_counter() - t0)
+        # the same steps as HIP graphs (possible because nothing in a step syncs with the host), actions taken by pointer
+        return eager, n*steps/replay_steps(lambda a: env.step(arrdict.arrdict(actions=a)), acts[warmup:warmup + steps])
 
     out = {}
     np.random.seed(0); torch.manual_seed(0)
@@ -221,20 +216,66 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     return out
 
 
-def measured_traffic(args):
-    """HBM bytes per ms_render launch from rocprofv3 PMC passes of this exact workload (profiles/rNN_traffic.json, collected
-    by tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950) and the file it was read from; the newest round that profiled the shape wins. (None, None) for a shape
-    nobody profiled: PMC counters cannot be collected from inside the benchmark process."""
+def replay_steps(step, actions):
+    """Seconds for len(actions) env steps replayed as HIP graphs: one graph per step, each captured on ITS OWN slice of the
+    pre-drawn actions - the step reads its actions where they lie, as it would read a policy's output buffer. (Round 4 replayed
+    one graph and copied every step's actions into its static input first: a 5 us copy kernel and a second launch per 45 us
+    step, standing in for a policy's write that is not the env's to pay for.) The graphs share one memory pool, so they all
+    write the same observation buffers; trajectories are the eager leg's, step for step."""
+    graphs = []
+    for a in actions:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=graphs[0].pool() if graphs else None):
+            step(a)
+        graphs.append(g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for g in graphs:
+        g.replay()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def traffic_entry(envs, agents, res, large=False, depth_only=False):
+    """The newest profiles/rNN_traffic.json entry for a workload (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate PMC
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; since round 5 also the vector ALUs' busy
+    fraction from the SQ pass of the same profile) and the file it was read from; (None, None) for a shape nobody profiled -
+    PMC counters cannot be collected from inside the benchmark process."""
     import glob
-    want = (args.envs, args.agents, args.res, bool(args.large), bool(args.depth_only))
+    want = (envs, agents, res, bool(large), bool(depth_only))
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_traffic.json')), reverse=True):
         t = json.load(open(path))
         for entry in t.get('shapes', [t]):                              # (one shape per file up to round 2, a list since)
             w = entry.get('workload', {})
             if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False)), bool(w.get('depth_only', False))) == want:
-                return entry['render_bytes_per_launch'], os.path.relpath(path, ROOT)
+                return entry, os.path.relpath(path, ROOT)
     return None, None
+
+
+def measured_traffic(args):
+    """HBM bytes per ms_render launch of this exact workload from the rocprofv3 PMC passes (see traffic_entry)."""
+    entry, path = traffic_entry(args.envs, args.agents, args.res, args.large, args.depth_only)
+    return (entry['render_bytes_per_launch'], path) if entry else (None, None)
+
+
+def measured_block(core, fields, render_ms, step_ms, large=False):
+    """What the counters say about a shape, next to its algorithmic-bytes roofline figure: the fabric traffic of the render
+    launch and of the step, what fraction of the HBM peak THAT is over the measured time, and how busy the vector ALUs are -
+    with the verdict on what bounds the shape. (The algorithmic formula of SURVEY 8(d) counts every line of an env once per
+    launch; the kernels walk per-cell lists instead and at the larger shapes move LESS than it says - a fraction of bytes that
+    were never moved is no utilisation, and round 4's C5 line read 8190 GB/s on an 8000 GB/s part that way.)"""
+    entry, path = traffic_entry(core.n_envs, core.n_agents, core.res, large, fields is not None and 'screen' not in fields)
+    if entry is None:
+        return {'traffic': None}
+    rt, pt = entry['render_bytes_per_launch'], entry.get('physics_bytes_per_launch', 0.)
+    out = {'traffic': rt, 'traffic_source': path, 'frac_measured': rt/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+           'step_traffic': rt + pt, 'step_measured_GBps': (rt + pt)/(step_ms*1e-3)/1e9}
+    busy = entry.get('valu_busy_frac', {}).get('render_kernel')
+    if busy is not None:
+        out['valu_busy'] = busy
+        out['bound_measured'] = ('vector ALU issue' if busy >= .85 else 'vector ALU issue, mostly' if busy >= .65 else
+                                 "the launch's coarse grain: dependent round trips at both ends of a wave and the drain of the last waves")
+    return out
 
 
 def _oracle_sample(core, max_envs):
@@ -545,8 +586,10 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None):
          'ms_per_step': 1e3*s/steps, 'env_steps_per_s': core.n_envs*steps/s, 'timed_regions': int(len(m['runs'])),
          'eager_ms_per_step': 1e3*float(np.median(m['eager_runs']))/steps,
          'render_launch_ms': render_ms, 'render_algorithmic_bytes': rb,
-         'roofline_frac': rb/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
-         'step_achieved_GBps': (rb + pb)/(1e3*s/steps*1e-3)/1e9,
+         'roofline_frac': rb/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS, 'physics_algorithmic_bytes': pb,
+         'roofline_frac_note': 'render_algorithmic_bytes (SURVEY 8(d): every line of an env once per launch, whether the kernel '
+                               'reads it or not) over the render launch against 8 TB/s; what was actually moved: traffic / frac_measured',
+         **measured_block(core, fields, render_ms, 1e3*s/steps, large=sc.lines.vals.shape[0]/core.n_envs > 600),
          'ray_groups_per_wave': ray_groups(dev, core), **grids(core)}
     if note:
         e['note'] = note
@@ -623,20 +666,11 @@ def headline_env_step(dev, core, steps=40, warmup=8):
         step(acts[warmup + i])
     dev.sync()
     eager = (time.perf_counter() - t0)/steps
-    static = acts[0].clone()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        step(static)
-    dev.sync()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        static.copy_(acts[warmup + i])
-        g.replay()
-    dev.sync()
-    graphed = (time.perf_counter() - t0)/steps
+    graphed = replay_steps(step, acts[warmup:warmup + steps])/steps
     return {'what': f'{N} envs x {A} agents x {core.res} rays: MomentumMovement + physics (+ IMU) in one launch, render with RGB + depth '
                     'observations written by the kernel, random actions',
-            'ms_per_step': 1e3*eager, 'env_steps_per_s': N/eager, 'ms_per_step_hip_graph': 1e3*graphed, 'env_steps_per_s_hip_graph': N/graphed}
+            'ms_per_step': 1e3*eager, 'env_steps_per_s': N/eager, 'ms_per_step_hip_graph': 1e3*graphed, 'env_steps_per_s_hip_graph': N/graphed,
+            'hip_graph': 'one graph per step, each reading its own slice of the pre-drawn actions in place (no copy into a static input)'}
 
 
 def main(argv=None):
@@ -661,6 +695,9 @@ def main(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
     ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
     ap.add_argument('--plan-workers', type=int, default=None, help='processes generating floorplans (0: in this process)')
+    ap.add_argument('--plan-cache', default=None, help='pickle of generated floorplans: loaded if it exists, written (and the run ended) with '
+                                                       '--plans-only - for profiled runs, which cannot fork plan workers')
+    ap.add_argument('--plans-only', action='store_true')
     ap.add_argument('--baseline-line', default=None, help="file holding the JSON line of the same command at --gpus 1: the line then "
                                                           "carries scaling_efficiency = value / (N x that line's value)")
     args = ap.parse_args(argv)
@@ -684,7 +721,14 @@ def main(argv=None):
     extras = rank == 0 and world == 1 and not args.dry_run_cpu
     # Floorplans first, on forked workers, before this process touches its GPU: the headline's pool (which the C3 / 512-ray
     # shapes share) and, if the `shapes` block is wanted, C2's one-plan-per-env pool and the large maps.
+    if args.plan_cache and os.path.exists(args.plan_cache):
+        from megastep_amd import cubicasa
+        cubicasa.load_cache(args.plan_cache)
     world_geometries(args.envs, 1, 1, n_unique, args.large, args.legacy_plans)
+    if args.plans_only:
+        from megastep_amd import cubicasa
+        cubicasa.save_cache(args.plan_cache)
+        return None
     if extras and not args.no_shapes:
         world_geometries(4096, 1, 1, 4096)
         world_geometries(4096, 1, 1, C5_PLANS, large=True)

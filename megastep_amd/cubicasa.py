@@ -201,6 +201,20 @@ def _prefetch_subprocess(todo, workers):
                 proc.kill()
 
 
+def save_cache(path):
+    """The plans generated so far, pickled (numpy arrays only): a profiled run, which must not fork workers, loads them."""
+    import pickle
+    with open(path, 'wb') as f:
+        pickle.dump({k: dict(v) for k, v in _cache.items()}, f, protocol=4)
+
+
+def load_cache(path):
+    import pickle
+    with open(path, 'rb') as f:
+        for k, v in pickle.load(f).items():
+            _cache.setdefault(k, arrdict.arrdict(**v))
+
+
 def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0, context='fork'):
     """A deterministic sample of ``n_geometries`` floorplans; same arguments, same sample (reference:
     cubicasa.py:177-224). ``split`` is 90/10 ``training``/``test`` or ``all`` over ``n_unique`` plans; plans are

@@ -7,7 +7,9 @@ tag=$1; shift
 shape="$@"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-lean="--no-cpu-baseline --no-env-fps --no-shapes --plan-workers 0"
+# (floorplans first, in a plain process that may fork its workers: the profiled runs load them - 4096 large plans are 90 s on one core)
+python bench.py --plan-cache /tmp/plans_$tag.pkl --plans-only $shape > /dev/null 2> $out/plans.log
+lean="--no-cpu-baseline --no-env-fps --no-shapes --plan-workers 0 --plan-cache /tmp/plans_$tag.pkl"
 rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python bench.py --steps 100 --warmup 10 $lean $shape > $out/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_write.log 2>&1
@@ -37,11 +39,12 @@ for c, f in [('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write')]:
 # calibrated here on physics_kernel's 16 B/lane wall stream in round 2), WRITE_SIZE (KB) as reported.
 rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) for k in ('render_kernel', 'render_prep_kernel', 'dynlight_kernel'))
 pb = 2*1024*res['FETCH_SIZE'].get('physics_kernel', 0) + 1024*res['WRITE_SIZE'].get('physics_kernel', 0)
-json.dump({'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large, 'depth_only': w.depth_only},
+traffic = {'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large, 'depth_only': w.depth_only}, 'shape': tag,
            'render_bytes_per_launch': rb, 'physics_bytes_per_launch': pb, 'raw_counters_KB': res,
+           'kernel_us': {r.Name.split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''): r.AverageNs/1e3
+                         for r in st.itertuples() if 'render_kernel' in r.Name or 'physics_kernel' in r.Name},
            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph ' + ' '.join(shape)
-                     + '; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'},
-          open(f'{out}/traffic.json', 'w'), indent=1)
+                     + '; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'}
 sq = pd.read_csv(f'{out}/sq/bench_counter_collection.csv')
 sq['k'] = sq.Kernel_Name.str.extract(KERNELS)
 g = sq[sq.k.notna()].groupby(['k', 'Counter_Name']).Counter_Value.mean().unstack()
@@ -63,6 +66,10 @@ if os.path.exists(f):
     a['cycles_per_valu_inst'] = 4*a.SQ_ACTIVE_INST_VALU/a.SQ_INSTS_VALU
     a['valu_busy_frac'] = 4*a.SQ_ACTIVE_INST_VALU/1024/(a.GRBM_GUI_ACTIVE/8)
     a.to_csv(f'{out}/valu_busy.csv'); print(a.round(3).to_string())
+    traffic['valu_busy_frac'] = a.valu_busy_frac.to_dict()
+traffic['per_wave'] = {k: {c: float(g.loc[k, c]) for c in ('VALU_per_wave', 'SALU_per_wave', 'LDS_per_wave', 'cycles_per_wave', 'parked_frac', 'issue_stall_frac')}
+                       for k in g.index}
+json.dump(traffic, open(f'{out}/traffic.json', 'w'), indent=1)
 PY
 tail -1 $out/bench_stats.log | cut -c1-400
 # (gpurun brings back at most 64 MiB: the raw traces stay on the box, the summaries above travel)
