@@ -183,11 +183,14 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
         for i in range(warmup):
             env.step(arrdict.arrdict(actions=acts[i]))
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            env.step(arrdict.arrdict(actions=acts[warmup + i]))
-        torch.cuda.synchronize()
-        eager = n*steps/(time.perf_counter() - t0)
+        times = []
+        for _ in range(5):                                               # (the median of a few passes, as for the graphs)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                env.step(arrdict.arrdict(actions=acts[warmup + i]))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        eager = n*steps/float(np.median(times))
         # the same steps as HIP graphs (possible because nothing in a step syncs with the host), actions taken by pointer
         return eager, n*steps/replay_steps(lambda a: env.step(arrdict.arrdict(actions=a)), acts[warmup:warmup + steps])
 
@@ -216,7 +219,7 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     return out
 
 
-def replay_steps(step, actions):
+def replay_steps(step, actions, repeats=5):
     """Seconds for len(actions) env steps replayed as HIP graphs: one graph per step, each captured on ITS OWN slice of the
     pre-drawn actions - the step reads its actions where they lie, as it would read a policy's output buffer. (Round 4 replayed
     one graph and copied every step's actions into its static input first: a 5 us copy kernel and a second launch per 45 us
@@ -229,11 +232,14 @@ def replay_steps(step, actions):
             step(a)
         graphs.append(g)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for g in graphs:
-        g.replay()
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0
+    times = []
+    for _ in range(repeats):                                             # (the median of a few passes: a pass is a few milliseconds)
+        t0 = time.perf_counter()
+        for g in graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    return float(np.median(times))
 
 
 def traffic_entry(envs, agents, res, large=False, depth_only=False):
@@ -661,11 +667,14 @@ def headline_env_step(dev, core, steps=40, warmup=8):
     for i in range(warmup):
         step(acts[i])
     dev.sync()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(acts[warmup + i])
-    dev.sync()
-    eager = (time.perf_counter() - t0)/steps
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(acts[warmup + i])
+        dev.sync()
+        times.append(time.perf_counter() - t0)
+    eager = float(np.median(times))/steps
     graphed = replay_steps(step, acts[warmup:warmup + steps])/steps
     return {'what': f'{N} envs x {A} agents x {core.res} rays: MomentumMovement + physics (+ IMU) in one launch, render with RGB + depth '
                     'observations written by the kernel, random actions',

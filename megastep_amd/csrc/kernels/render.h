@@ -337,7 +337,7 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #define MS_WAVES 6
 #endif
 #ifndef MS_ABLATE
-#define MS_ABLATE 0                          // (instruction-count experiments: 1 stops a wave after its set-up, 2 after pass 1 with
+#define MS_ABLATE 0                          // (instruction-count / time experiments: 4 ends a wave at once, 1 stops it after its set-up, 2 after pass 1 with
 #endif                                       //  pass 2 skipped, 3 after the raycast; the outputs are then garbage)
 #ifndef MS_AHEAD
 #define MS_AHEAD 3
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
         const int G = (R + WAVE - 1)/WAVE, F = A*G;
         n = div_by(fan, rc.by_f); const int rem = fan - n*F; a = div_by(rem, rc.by_g); r0 = (rem - a*G)*WAVE; span = WAVE;
     }
+    if constexpr (MS_ABLATE == 4) return;                                // (what does a launch of this many one-wave workgroups cost on its own?)
 #ifdef MS_PARK
     // (-DMS_PARK=<shader clocks>, an experiment: every render wave sits out that long before it starts, as it would at the
     // barrier of a single-launch step whose first wave does the env's physics - what do parked waves cost a launch?)

@@ -237,8 +237,9 @@ def test_light_grid_verdicts_hold_for_every_sampled_point():
     assert 0 < int(pool[0]) < len(pool)
 
 
-@pytest.mark.parametrize('res,fov,cell', [(64, 130, .25), (256, 70, 1.), (128, 100, .5), (64, 130, .125)])
-def test_crowded_rooms_exercise_dynamic_lighting(monkeypatch, res, fov, cell):
+@pytest.mark.parametrize('res,fov,cell,budget', [(64, 130, .25, None), (256, 70, 1., None), (128, 100, .5, None), (64, 130, .125, None),
+                                                 (64, 130, .125, 'no rows'), (128, 70, .125, 'coarser')])
+def test_crowded_rooms_exercise_dynamic_lighting(monkeypatch, res, fov, cell, budget):
     """Four agents packed into one room of each plan, looking at each other: many rays land on agents, under every
     mix of lit / shadowed / partly shadowed lights.  With coarser light-grid cells more lights stay open and the
     candidate lists grow past one LDS batch (64 pairs): several lists per wave, several batches per list, several rounds
@@ -246,7 +247,15 @@ def test_crowded_rooms_exercise_dynamic_lighting(monkeypatch, res, fov, cell):
     from megastep_amd import cuda
     monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_CELL', cell)
     monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_POOL', 12 if cell <= .25 else 200)
+    if budget is not None:
+        # LIGHT_GRID_BYTES: a grid over its budget goes without the candidates' rows (ms_render then fetches a
+        # candidate's wall from `lines`), then on cells twice, four times the size - the same picture either way
+        full = _world(24, 4, res, fov, seed=5)[0].scenery.grid_report()['light_grid']['bytes']
+        monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_BYTES', full - 1 if budget == 'no rows' else full//12)
     c, geometries = _world(24, 4, res, fov, seed=5)
+    if budget is not None:
+        rep = c.scenery.grid_report()['light_grid']
+        assert not rep['candidate_rows'] and c.scenery._lg[7] is None and (rep['cell'] == cell) == (budget == 'no rows')
     rng = np.random.RandomState(2)
     pos = np.zeros((24, 4, 2), np.float32)
     ang = np.zeros((24, 4), np.float32)

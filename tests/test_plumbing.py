@@ -95,6 +95,28 @@ def test_every_core_carries_its_own_constants():
         cuda.config(.1, 64, 190, 10)
 
 
+def test_the_light_grid_stays_inside_its_byte_budget(monkeypatch):
+    """at 0.125 m cells with the candidates' rows a cell costs 264 bytes - 13 GB for 4096 plans, 54 GB for large ones -
+    and there was no cap. Over LIGHT_GRID_BYTES the grid first drops the candidates' rows (ms_render handles NULL), then doubles
+    its cells until it fits; what was built is in grid_report()."""
+    g = cubicasa.sample(6, n_unique=16, seed=2)
+    s = scene.scenery(g, 2, device='cpu', bake=False)
+    full = s._light_grid()
+    rep = s.grid_report()['light_grid']
+    assert rep['cell'] == cuda.Scenery.LIGHT_GRID_CELL and rep['candidate_rows'] and full[7] is not None and rep['floorplans'] == 6
+    assert rep['bytes'] == 24*(rep['cells'] + 1) + 20*full[6].shape[0]                      # verdicts + headers, pool words + their rows
+    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_BYTES', rep['bytes'] - 1)
+    lean = s._light_grid()
+    r = s.grid_report()['light_grid']
+    assert lean[7] is None and not r['candidate_rows'] and r['cell'] == rep['cell'] and r['bytes'] < rep['bytes']//3
+    monkeypatch.setattr(cuda.Scenery, 'LIGHT_GRID_BYTES', rep['bytes']//20)
+    coarse = s._light_grid()
+    r = s.grid_report()['light_grid']
+    assert r['cell'] > rep['cell'] and r['bytes'] <= rep['bytes']//20 and coarse[3] == r['cell'] and coarse[0].shape[0] == r['cells'] + 1
+    # a shard carries the lean grid over like any other (no rows to repack)
+    assert s.grid_report()['wall_grid'] is None                                            # (never baked: no wall grid)
+
+
 def test_column_and_spaces():
     g = toys.column()
     np.testing.assert_allclose(sorted(g.lights.tolist()), [[2.5, 2.5], [2.5, 4.5], [4.5, 2.5], [4.5, 4.5]], atol=1e-12)

@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o bench --output-format
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace -d $out/sq -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_sq.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/active -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-graph $lean $shape > $out/bench_active.log 2>&1
 python - "$out" "$tag" $shape <<'PY'
-import json, os, sys
+import json, os, re, sys
 import pandas as pd
 out, tag, shape = sys.argv[1], sys.argv[2], sys.argv[3:]
 import argparse
@@ -41,8 +41,8 @@ rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) f
 pb = 2*1024*res['FETCH_SIZE'].get('physics_kernel', 0) + 1024*res['WRITE_SIZE'].get('physics_kernel', 0)
 traffic = {'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large, 'depth_only': w.depth_only}, 'shape': tag,
            'render_bytes_per_launch': rb, 'physics_bytes_per_launch': pb, 'raw_counters_KB': res,
-           'kernel_us': {r.Name.split('(')[0].replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', ''): r.AverageNs/1e3
-                         for r in st.itertuples() if 'render_kernel' in r.Name or 'physics_kernel' in r.Name},
+           'kernel_us': {re.search(r'((?:render|physics)_kernel<[^>]*>)', r.Name).group(1): r.AverageNs/1e3
+                         for r in st.itertuples() if re.search(r'(?:render|physics)_kernel<', r.Name)},
            'method': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --no-graph ' + ' '.join(shape)
                      + '; bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024'}
 sq = pd.read_csv(f'{out}/sq/bench_counter_collection.csv')
