@@ -19,7 +19,9 @@ __device__ inline bool light_blocked(P2 I, P2 U, float ax, float ay, float vx, f
     const float cs = cross(PQ, V);
     const float ns = bits_f(f_bits(cs) ^ sg);
     if (!((nt > 0.f) & (nt < ad) & (ns > 0.f))) return false;
-    return (cs/UxV) < .999f;
+    // (|UxV| >= 1e-3; a cs too small for div_inrange's range gives a quotient far below .999 either way, one too large an
+    // infinity or a NaN, which are not below it either: the comparison comes out as with the full division)
+    return div_inrange(cs, UxV) < .999f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -93,6 +95,13 @@ __device__ inline float grid_light_intensity(
     return __uint_as_float(st.x ^ lst.y) + Ii;                           // (ablation: the loads and the cell look-up only)
 #endif
     const bool shortcut = !MANY && __ballot((lane < ni) & !(Ii >= 0.f)) == 0ull;   // every contribution non-negative, finite
+    // every intensity zero or of an everyday size (uniform): a contribution 2 I / max(d^2, 1) is then a division in range
+    // (div_inrange: the same bits for 8 instructions instead of 11 - these loops are what the waves a launch waits for run)
+    // ... and every light and every hit point within 10^15 m of the origin: d^2 is then finite (uniform; NaNs fail the tests)
+    const bool light_ok = ((Ii == 0.f) || ((Ii >= 1.e-30f) && (Ii <= 1.e30f))) && (fabsf(Ix) <= 1.e15f) && (fabsf(Iy) <= 1.e15f);
+    const bool point_ok = (fabsf(cx_l) <= 1.e15f) && (fabsf(cy_l) <= 1.e15f);
+    const bool nice = MS_DIV_INRANGE && __ballot(((lane < ni) && !light_ok) || (dynamic && !point_ok)) == 0ull;
+    auto contribution = [&](const float num, const float den) { return nice ? div_inrange(num, den) : num/den; };
     // ---- the sum over the lights the grid proves unblocked, in light order.  Rays around one target mostly share
     // a cell, so: one pass per distinct verdict word set, scalar loop over its LIT bits (01 in the 2-bit fields)
     float part = AMBIENT;
@@ -107,7 +116,7 @@ __device__ inline float grid_light_intensity(
             for (unsigned lw = sw[k] & ~(sw[k] >> 1) & 0x55555555u; lw; lw &= lw - 1) {
                 const int i = 16*k + ((__ffs((int)lw) - 1) >> 1);
                 const float d2 = len2(p2(readlane_f(Ix, i), readlane_f(Iy, i)) - p2(cx_l, cy_l));
-                if (same) part += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+                if (same) part += contribution(LUMINANCE*readlane_f(Ii, i), ms_max(d2, 1.f));
             }
         }
     }
@@ -306,7 +315,7 @@ __device__ inline float grid_light_intensity(
             const bool unblocked = (s2 == 1u) | ((s2 == 0u) & !((shadow >> i) & 1ull));
             const P2 I = p2(readlane_f(Ix, i), readlane_f(Iy, i));
             const float d2 = len2(I - p2(cx_l, cy_l));
-            if (need & unblocked) acc += LUMINANCE*readlane_f(Ii, i)/ms_max(d2, 1.f);
+            if (need & unblocked) acc += contribution(LUMINANCE*readlane_f(Ii, i), ms_max(d2, 1.f));
         }
     }
     if (MANY) {

@@ -21,6 +21,37 @@ __host__ __device__ inline float dot(P2 v, P2 w) { return v.x*w.x + v.y*w.y; }
 __host__ __device__ inline float ms_min(float a, float b) { if (a != a) return b; return (b < a) ? b : a; }
 __host__ __device__ inline float ms_max(float a, float b) { if (a != a) return b; return (b > a) ? b : a; }
 
+// n / d where the quotient needs none of the range handling the compiler's expansion of a correctly rounded division carries:
+// that expansion is v_div_scale x 2 (which move operands near the ends of the exponent range towards the middle: a denormal
+// or > 2^126 divisor, a numerator below 2^-104, exponents more than 96 apart), v_rcp_f32, the Newton-Raphson steps below, and
+// v_div_fmas / v_div_fixup (which undo the scaling and patch zeros, infinities and NaNs in).  For operands in range the scaling
+// is the identity and the fix-up a move: the SAME steps on the SAME values, hence the same bits - the correctly rounded
+// quotient (Markstein's sequence) - for 8 instructions instead of 11, at ten divisions a wave (6 % of a render wave's vector
+// instructions with the shared reciprocal of tex_filter and the square root below).  In range by construction at every site
+// it is used: divisors are |cross(ray, wall)| >= 1e-3 of a hit, a ray's length in [1, 12], texel weights' sums >= 2e-3, a
+// wall's length + 1e-6; numerators of hits that can be taken are >= 1e-5.  Where the operands leave the range - a numerator that
+// is zero or below 2^-104, coordinates beyond 10^15 - the quotient is a float output within its 1e-5 tolerance (zero, or a few
+// ulps of something tiny) or the s of a hit inside the near plane that the comparison throws away either way; never a hit index.
+#ifndef MS_DIV_INRANGE
+#define MS_DIV_INRANGE 1               // (0: plain `/` everywhere - the A/B, and the same bits)
+#endif
+__device__ inline float rcp_refined(const float d) {                   // 1/d to within an ulp: the reciprocal the steps below share
+    const float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.f), r, r);
+}
+__device__ inline float div_by_refined(const float n, const float d, const float r) {   // n / d given r = rcp_refined(d)
+    float q = n*r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+__device__ inline float div_inrange(const float n, const float d) {
+#if MS_DIV_INRANGE
+    return div_by_refined(n, d, rcp_refined(d));
+#else
+    return n/d;
+#endif
+}
+
 // direction of (x, y) in [0, 4): 0 along +x, 1 along +y, 2 along -x, 3 along -y; NaN at the origin
 __host__ __device__ inline float pseudo_angle(float x, float y) {
     const float p = y/(fabsf(x) + fabsf(y));

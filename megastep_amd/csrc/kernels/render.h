@@ -71,8 +71,14 @@ __device__ inline Filt tex_filter(float x, int w) {
     f.r = (int)ms_min(y, (float)(w - 1));
     const float ld = fabsf(y - (f.l + 1)) + 1.e-3f;
     const float rd = fabsf(y - (f.r + 1)) + 1.e-3f;
+#if MS_DIV_INRANGE
+    const float den = ld + rd, r_den = rcp_refined(den);                // (in [2e-3, 2 w]: see div_inrange; one reciprocal for both)
+    f.lw = div_by_refined(rd, den, r_den);
+    f.rw = div_by_refined(ld, den, r_den);
+#else
     f.lw = rd/(ld + rd);
     f.rw = ld/(ld + rd);
+#endif
     return f;
 }
 
@@ -98,6 +104,19 @@ __device__ inline float sqrt_normal(const float x) {
     float r = (r_dn <= 0.f) ? dn : s;
     r = (r_up > 0.f) ? up : r;
     return r;
+}
+
+// sqrtf() where the argument may be anything: sqrt_normal for normal numbers (and zero: see there), the library's for the rest
+// (denormals, infinities, NaNs - a wall shorter than 10^-19 m) behind a branch no wave takes.
+__device__ __attribute__((noinline)) float sqrtf_called(const float x) { return sqrtf(x); }
+__device__ inline float sqrt_any(const float x) {
+#if MS_DIV_INRANGE
+    float r = sqrt_normal(x);
+    if (__builtin_expect(!(x >= 1.e-30f) && x != 0.f, 0) || __builtin_expect(!(x <= 1.e30f), 0)) r = sqrtf_called(x);
+    return r;
+#else
+    return sqrtf(x);
+#endif
 }
 
 struct Divisor { unsigned mul, sh1, sh2; };
@@ -539,10 +558,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
         // division by R only moves the exponent, and the product with 1/R is the correctly rounded quotient itself: one
         // multiply for the dozen instructions of a division.  The numerator is at least half_screen in size: no underflow.)
         const float num = (Rf - 2*(float)r_ - 1)*half_screen;
-        const float uy = rc.inv_res != 0.f ? num*rc.inv_res : num/Rf;
+        const float uy = rc.inv_res != 0.f ? num*rc.inv_res : div_inrange(num, Rf);
         rx_ = cs*1.f - sn*uy; ry_ = sn*1.f + cs*uy;
         rlen_ = ray_len(rx_, ry_);
-        near_ = agent_radius/rlen_;
+        near_ = div_inrange(agent_radius, rlen_);
     };
     float rx, ry, rlen, near;                                           // (the wave's first group's; the others' live in LDS)
     ray_of(r, rx, ry, rlen, near);
@@ -596,10 +615,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
             const float vx = hw.z - hw.x, vy = hw.w - hw.y;
             const float d = rx*vy - ry*vx;
             const float pqx = hw.x - pp.x, pqy = hw.y - pp.y;
-            loc = (pqx*ry - pqy*rx)/d;
+            loc = div_inrange(pqx*ry - pqy*rx, d);
             const float dtop = rx*vx + ry*vy;
-            const float dbot = rlen*sqrtf(vx*vx + vy*vy);
-            dt = dtop/(dbot + 1.e-6f);
+            const float dbot = rlen*sqrt_any(vx*vx + vy*vy);
+            dt = div_inrange(dtop, dbot + 1.e-6f);
         }
     }
     const size_t o = ((size_t)n*A + a)*R + r;
@@ -1111,7 +1130,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
                 // hit: 0 <= t <= 1 with t = nt/d  <=>  0 <= nt' <= |d| (exact, see light_blocked)
                 const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
                 if (hit) {
-                    const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
+                    const float sv = div_inrange(cd.pqx*cd.vy - cd.pqy*cd.vx, d);        // q.s = cross(PQ, V)/UxV
                     const bool beyond = s_near_w[rr] < sv;                          // beyond the near plane, kernels.cu:369
                     if (beyond) {
                         const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)info.y;
@@ -1333,7 +1352,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
                             bool valid = false;
                             float sv = 0.f;
                             if ((k0 + lane < list_n) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                                sv = cpv/d;
+                                sv = div_inrange(cpv, d);
                                 valid = jnear < sv;
                             }
                             unsigned long long m = __ballot(valid);
@@ -1364,7 +1383,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
                             const float ad = fabsf(d);
                             const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
                             if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                                const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                                const float sv = div_inrange(cd.pqx*cd.vy - cd.pqy*cd.vx, d);
                                 if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = line; }
                             }
                         }
@@ -1400,7 +1419,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
                             const float ad = fabsf(d);
                             const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
                             if ((ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                                const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;
+                                const float sv = div_inrange(cd.pqx*cd.vy - cd.pqy*cd.vx, d);
                                 if ((near < sv) & (sv < x - 1.e-4f)) { x = sv; xi = c0 + j; }
                             }
                         }
@@ -1430,7 +1449,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
                         bool valid = false;
                         float sv = 0.f;
                         if ((l < L) & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad)) {
-                            sv = (pqx*vy - pqy*vx)/d;
+                            sv = div_inrange(pqx*vy - pqy*vx, d);
                             valid = jnear < sv;
                         }
                         unsigned long long m = __ballot(valid);
@@ -1500,7 +1519,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1
                         const float ntp = bits_f(f_bits(nt) ^ (f_bits(d) & 0x80000000u));
                         const bool hit = valid & (ad >= 1.e-3f) & (ntp >= 0.f) & (ntp <= ad);
                         if (hit) {
-                            const float sv = (cd.pqx*cd.vy - cd.pqy*cd.vx)/d;        // q.s = cross(PQ, V)/UxV
+                            const float sv = div_inrange(cd.pqx*cd.vy - cd.pqy*cd.vx, d);        // q.s = cross(PQ, V)/UxV
                             const bool beyond = s_near_w[rr] < sv;                   // beyond the near plane, kernels.cu:369
                             if (beyond) {
                                 const unsigned long long key = ((unsigned long long)f_bits(sv) << 32) | (unsigned)line;
