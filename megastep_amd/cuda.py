@@ -277,7 +277,14 @@ class Scenery:
     #: candidates' rows (72 B a cell: ms_render then fetches a candidate's wall one trip later, the round-3 behaviour), then
     #: doubles its cells (a quarter of them, and more lights left UNKNOWN per cell: slower for the rays that land on an agent,
     #: the same bits) until it fits. `Scenery.grid_report()` says what was built.
-    LIGHT_GRID_BYTES = int(float(os.environ.get('MEGASTEP_LIGHT_GRID_BYTES', 8 << 30)))
+    #: None: an eighth of the device's memory (36 GB of an MI355X's 288; 8 GiB for tensors that are not on a GPU).
+    LIGHT_GRID_BYTES = int(float(os.environ['MEGASTEP_LIGHT_GRID_BYTES'])) if os.environ.get('MEGASTEP_LIGHT_GRID_BYTES') else None
+
+    def _light_grid_budget(self):
+        if self.LIGHT_GRID_BYTES is not None:
+            return int(self.LIGHT_GRID_BYTES)
+        dev = self._lines.vals.device
+        return torch.cuda.get_device_properties(dev).total_memory//8 if dev.type == 'cuda' else 8 << 30
 
     def _light_grid(self):
         """Storage and geometry of the light grid (see include/megastep_hip.h): a uniform grid over each env's walls,
@@ -294,6 +301,7 @@ class Scenery:
         rep = torch.arange(n_envs, device=dev) if self._geom is None else self._geom.long()
         is_rep = rep == torch.arange(n_envs, device=dev)
         cell, with_rows = float(self.LIGHT_GRID_CELL), True
+        budget = self._light_grid_budget()
         while True:
             dims = torch.ceil((hi + .5 - origin)/cell).clamp(1, 4096)
             # the grid holds 64 lights per env: an env with more gets no cells, and the renderer meets every wall for the
@@ -304,7 +312,7 @@ class Scenery:
             total = int(own.sum())
             words = min(1 + self.LIGHT_GRID_POOL*total, 2**31 - 1)
             size = 24*(total + 1) + (20 if with_rows else 4)*words
-            if size <= self.LIGHT_GRID_BYTES or cell >= 8.:
+            if size <= budget or cell >= 8.:
                 break
             if with_rows:
                 with_rows = False
@@ -317,12 +325,12 @@ class Scenery:
         pool = torch.zeros(words, dtype=torch.int32, device=dev)
         # the candidates' walls, next to their entries (MsScenery.lg_pool_rows; optional)
         rows = torch.zeros((words, 4), dtype=torch.float32, device=dev) if with_rows else None
-        self._lg_report = dict(bytes=size, cell=cell, cells=total, candidate_rows=with_rows, budget=self.LIGHT_GRID_BYTES,
+        self._lg_report = dict(bytes=size, cell=cell, cells=total, candidate_rows=with_rows, budget=budget,
                                floorplans=int(is_rep.sum()))
         if os.environ.get('MEGASTEP_VERBOSE'):
             print(f'megastep_amd: light grid of {size/2**20:.0f} MiB: {total} cells of {cell:g} m over {int(is_rep.sum())} floorplans'
                   + ('' if with_rows else ', without candidate rows') + (f' (asked for {self.LIGHT_GRID_CELL:g} m: over the '
-                  f'{self.LIGHT_GRID_BYTES/2**30:.1f} GiB budget)' if cell != self.LIGHT_GRID_CELL or not with_rows else ''), flush=True)
+                  f'{budget/2**30:.1f} GiB budget)' if cell != self.LIGHT_GRID_CELL or not with_rows else ''), flush=True)
         return vals, starts.contiguous(), geom, cell, max(int(cells.max()), 1), lists, pool, rows
 
     def grid_report(self):
