@@ -358,8 +358,16 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #ifndef MS_ABLATE
 #define MS_ABLATE 0                          // (instruction-count / time experiments: 4 ends a wave at once, 1 stops it after its set-up, 2 after pass 1 with
 #endif                                       //  pass 2 skipped, 3 after the raycast; the outputs are then garbage)
+// Chunks of 64 rows a walk has in flight per batch.  Three until round 5 - from before the wall grid, when a wave met every line
+// of its env, five or six chunks of them; with the vis lists a batch is the agents' lines and the 30-odd walls that pass the arc
+// cull: ONE chunk more often than not, and the other two slots' index arithmetic and (unconditional) row gathers were wasted
+// on it.  One chunk a batch (profiles/r05_ab_ahead.txt, us per render launch, same box): headline 33.8 -> 33.3, C3 51.0 -> 49.4,
+// 512 rays 141.0 -> 139.4, C5's share 190.0 -> 185.7, C2 11.8 -> 11.8; and 68 registers instead of 77.  (With them a seventh wave
+// a SIMD fits once the list is cut to 85 lines - 5112 B, four LDS granules; round 3's "seven waves" still had five granules and
+// never ran seven - and loses: 34.2 at the headline, 13.9 for 11.8 at C2, where a list of 85 lines overflows into second
+// drains and the all-lines fold; so does the shorter list alone at six waves.  Six waves, 128 lines stay.)
 #ifndef MS_AHEAD
-#define MS_AHEAD 3
+#define MS_AHEAD 1
 #endif
 #ifndef MS_VCAP
 #define MS_VCAP 128
@@ -371,11 +379,11 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #ifndef MS_VCAP_WIDE
 #define MS_VCAP_WIDE 110
 #endif
-// (MS_WAVES_WIDE: the same for the colour instantiations of several ray groups a wave - an A/B knob: at 5 they need no scratch)
+// (MS_WAVES_WIDE: the same for the instantiations of several ray groups a wave - an A/B knob: at 5 the colour ones need no scratch)
 #ifndef MS_WAVES_WIDE
-#define MS_WAVES_WIDE MS_WAVES
+#define MS_WAVES_WIDE 6
 #endif
-__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu((NG > 1 && SHADE) ? MS_WAVES_WIDE : MS_WAVES, (NG > 1 && SHADE) ? MS_WAVES_WIDE : MS_WAVES))) void render_kernel(
+__global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 ? MS_WAVES_WIDE : MS_WAVES, NG > 1 ? MS_WAVES_WIDE : MS_WAVES))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
         const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:

@@ -187,7 +187,7 @@ int wave_slots_here() {
     if (dev >= 0 && dev < MAX_DEVICES) { const int known = slots_of[dev].load(std::memory_order_relaxed); if (known) return known; }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    const int slots = cus*4*MS_WAVES;
+    const int slots = cus*4*MS_WAVES_WIDE;                             // (what sizes launches of wide waves: theirs)
     if (dev >= 0 && dev < MAX_DEVICES) slots_of[dev].store(slots, std::memory_order_relaxed);
     return slots;
 }
