@@ -52,12 +52,12 @@ def test_plain_command_starts_its_own_ranks():
 
 def test_the_rendezvous_is_not_inside_what_is_timed(tmp_path):
     """`value` is N x K over the slowest rank's OWN synchronize-to-synchronize time. A barrier that takes
-    50 ms (two orders of magnitude above a region of stub steps) must leave ms_per_step where the ranks' own times are -
+    10 ms (two orders of magnitude above a region of stub steps) must leave ms_per_step where the ranks' own times are -
     round 4 read the clock after a closing barrier, which at the driver's --steps 20 would have capped the 8-GPU line."""
-    slow = _run(2, environ={'BENCH_TEST_BARRIER_SLEEP_MS': '50'})
+    slow = _run(2, environ={'BENCH_TEST_BARRIER_SLEEP_MS': '10'})
     own = slow['per_rank']['ms_per_step']
     assert len(own) == 2 and 'OWN' in slow['timing']
-    # 50 ms of barrier over 6 steps would be 8.3 ms per step; a stub step is microseconds
+    # 10 ms of barrier over 6 steps would be 1.7 ms per step; a stub step is microseconds
     assert slow['ms_per_step'] < 0.5, slow['ms_per_step']
     # the median region's MAX over ranks against the ranks' median regions: the same quantity up to the noise of a
     # microsecond-long CPU region (median of maxima vs maximum of medians)
