@@ -573,7 +573,9 @@ def grids(core):
     for k in ('wall_grid', 'light_grid'):
         r = rep.get(k)
         if r:
-            out[k] = {kk: r[kk] for kk in ('bytes', 'cell', 'cells', 'floorplans', 'coarsened', 'candidate_rows', 'budget') if kk in r}
+            out[k] = {kk: r[kk] for kk in ('bytes', 'cell', 'cells', 'floorplans', 'coarsened', 'candidate_rows', 'budget', 'vis_entries', 'near_rows') if kk in r}
+    if rep.get('bake_seconds'):
+        out['bake_seconds'] = rep['bake_seconds']                        # (one-off: ms_bake with its light grid; the wall grid's levels)
     return out
 
 
@@ -596,7 +598,8 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None):
          'roofline_frac_note': 'render_algorithmic_bytes (SURVEY 8(d): every line of an env once per launch, whether the kernel '
                                'reads it or not) over the render launch against 8 TB/s; what was actually moved: traffic / frac_measured',
          **measured_block(core, fields, render_ms, 1e3*s/steps, large=sc.lines.vals.shape[0]/core.n_envs > 600),
-         'ray_groups_per_wave': ray_groups(dev, core), **grids(core)}
+         'ray_groups_per_wave': ray_groups(dev, core), **grids(core),
+         **({'world_build_seconds': core.build_seconds} if hasattr(core, 'build_seconds') else {})}
     if note:
         e['note'] = note
     return e
@@ -615,7 +618,8 @@ def other_shapes(dev, steps=20, warmup=5):
     def world(tag, *a, **kw):
         t0 = time.perf_counter()
         c, _ = build_world(*a, device=dev.device, seed=1, **kw)
-        log(f'{tag}: world built in {time.perf_counter() - t0:.1f}s')
+        c.build_seconds = time.perf_counter() - t0                       # (floorplans cached; scene assembly + bake + grids + spawns)
+        log(f'{tag}: world built in {c.build_seconds:.1f}s')
         return c
 
     c = world('C2', 4096, 1, 64, 130., n_unique=plan_count(4096, 1))

@@ -335,9 +335,10 @@ class Scenery:
 
     def grid_report(self):
         """What bake() built around the floorplans, for logs and bench lines: {'wall_grid': {bytes, cell, floorplans, ...} or
-        None, 'light_grid': {bytes, cell, cells, candidate_rows, ...} or None} - the sizes actually allocated and the cell
-        sizes actually used (either grid coarsens itself to stay inside its byte budget)."""
-        return dict(wall_grid=self._wg_report, light_grid=self._lg_report)
+        None, 'light_grid': {bytes, cell, cells, candidate_rows, ...} or None, 'bake_seconds': {lighting, wall_grid} of the last
+        cuda.bake()} - the sizes actually allocated and the cell sizes actually used (either grid coarsens itself to stay inside
+        its byte budget)."""
+        return dict(wall_grid=self._wg_report, light_grid=self._lg_report, bake_seconds=getattr(self, '_bake_s', None))
 
     def _wall_bounds(self):
         """(n_envs, 2) lower and upper corner of each env's static walls (finite coordinates only; 0, 0 without any)."""
@@ -686,10 +687,17 @@ def bake(scenery, scratch=True, wall_grid=True):
         vis, starts = scenery._bake_plan()
         struct = _lib.MsScenery.from_buffer_copy(struct)
         struct.bake_vis, struct.bake_vis_starts, struct.bake_vis_words = vis.data_ptr(), starts.data_ptr(), vis.shape[0]
+    import time
+    torch.cuda.synchronize(dev)                                          # (a one-off: what it cost goes into grid_report())
+    t0 = time.perf_counter()
     with _on(dev):
         _lib.check(_lib.lib().ms_bake(C.byref(struct), cfg, _stream(dev)))
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
     if wall_grid:
         scenery._build_wall_grid()
+        torch.cuda.synchronize(dev)
+    scenery._bake_s = dict(lighting=t1 - t0, wall_grid=time.perf_counter() - t1 if wall_grid else 0.)
 
 
 def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None, config=None):
