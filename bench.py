@@ -274,7 +274,8 @@ def measured_block(core, fields, render_ms, step_ms, large=False):
     if entry is None:
         return {'traffic': None}
     rt, pt = entry['render_bytes_per_launch'], entry.get('physics_bytes_per_launch', 0.)
-    out = {'traffic': rt, 'traffic_source': path, 'frac_measured': rt/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+    out = {'traffic': rt, 'traffic_source': path + f" (shape '{entry.get('shape', '?')}': profiled by envs x agents x rays, whatever the plan count)",
+           'frac_measured': rt/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
            'step_traffic': rt + pt, 'step_measured_GBps': (rt + pt)/(step_ms*1e-3)/1e9}
     busy = entry.get('valu_busy_frac', {}).get('render_kernel')
     if busy is not None:
