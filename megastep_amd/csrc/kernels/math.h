@@ -52,6 +52,20 @@ __device__ inline float div_inrange(const float n, const float d) {
 #endif
 }
 
+// Exact unsigned division by a divisor the host knows before the launch (agents per env, ray groups per agent, lines per agent):
+// multiply-high and two shifts (Granlund & Montgomery) - a run-time integer division costs a wave thirty vector instructions.
+struct Divisor { unsigned mul, sh1, sh2; };
+__host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
+    unsigned s = 0;
+    while ((1ull << s) < d) s++;
+    const unsigned long long m = ((1ull << 32)*((1ull << s) - d))/d + 1ull;
+    return Divisor{(unsigned)m, s < 1u ? s : 1u, s > 1u ? s - 1u : 0u};
+}
+__host__ __device__ inline int div_by(int n, const Divisor d) {     // n >= 0
+    const unsigned t = (unsigned)(((unsigned long long)d.mul*(unsigned)n) >> 32);     // (the high word: one v_mul_hi_u32 / s_mul_hi_u32)
+    return (int)((t + (((unsigned)n - t) >> d.sh1)) >> d.sh2);
+}
+
 // direction of (x, y) in [0, 4): 0 along +x, 1 along +y, 2 along -x, 3 along -y; NaN at the origin
 __host__ __device__ inline float pseudo_angle(float x, float y) {
     const float p = y/(fabsf(x) + fabsf(y));

@@ -31,7 +31,7 @@ constexpr int PHYS_PAIRS = (PHYS_FEW + 1)*WAVE;   // capacity of a wave's (wall,
 template <int MOVE, int EXTRA, int PACK = 0>
 __global__ __launch_bounds__(WAVE) void physics_kernel(
         const MsScenery sc, const MsAgents ag, float* __restrict__ progress,
-        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex, const int pack_envs) {
+        const float agent_radius, const float fps, const MsMovement mv, const MsStepExtras ex, const int pack_envs, const Divisor by_a) {
     PROBE_INIT
     extern __shared__ float4 s_dyn[];            // per agent: (p, v/fps) | reach box | reach^2 | progress bits
     __shared__ float4 s_wall[PHYS_PAIRS];        // walls near ...
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     const int E = PACK ? min(pack_envs, sc.n_envs - n) : 1;
     const int A = PACK ? A1*E : A1;                                      // the wave's agents: rows nA .. nA + A - 1 of every (N, A) array
     const int nA = n*A1;
-    [[maybe_unused]] const int lane_env = PACK ? min(lane/A1, E - 1) : 0;
+    // (by_a: division by the agents per env, worked out by the host - `lane / A1` sat in front of the wave's first loads)
+    [[maybe_unused]] const int lane_env = PACK ? min(div_by(lane, by_a), E - 1) : 0;
     float4* s_task = s_dyn;
     float4* s_box = s_task + A;
     float* s_reach2 = reinterpret_cast<float*>(s_box + A);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
     // (behind agents_apart(): agents of one env are mostly rooms apart, and then no lane of the wave goes into the test at
     // all - a fifth of a physics wave's instructions)
     for (int i = lane; i < A*A1; i += WAVE) {                            // (t, one of its env's agents)
-        const int t = i / A1, d1 = (PACK ? (t / A1)*A1 : 0) + i - t*A1;
+        const int t = div_by(i, by_a), d1 = (PACK ? div_by(t, by_a)*A1 : 0) + i - t*A1;
         if (d1 != t) {
             const float4 me = s_task[t], o = s_task[d1];
             if (!agents_apart(me, o, agent_radius)) {

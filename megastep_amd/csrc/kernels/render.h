@@ -119,7 +119,6 @@ __device__ inline float sqrt_any(const float x) {
 #endif
 }
 
-struct Divisor { unsigned mul, sh1, sh2; };
 struct RenderConsts {
     float x_clip, c_b;
     Divisor by_f, by_g, by_m;
@@ -130,17 +129,6 @@ struct RenderConsts {
     int telemetry;                 // ms_debug_pair_telemetry: pair / window counts into workspace[3], [4]
     int ws_headings;               // where in MsRender.workspace the (sin, cos) pairs of render_prep_kernel start, in 4-byte words
 };
-__host__ inline Divisor divisor_of(unsigned d) {           // d >= 1
-    unsigned s = 0;
-    while ((1ull << s) < d) s++;
-    const unsigned long long m = ((1ull << 32)*((1ull << s) - d))/d + 1ull;
-    return Divisor{(unsigned)m, s < 1u ? s : 1u, s > 1u ? s - 1u : 0u};
-}
-__host__ __device__ inline int div_by(int n, const Divisor d) {     // n >= 0
-    const unsigned t = (unsigned)(((unsigned long long)d.mul*(unsigned)n) >> 32);     // (the high word: one v_mul_hi_u32 / s_mul_hi_u32)
-    return (int)((t + (((unsigned)n - t) >> d.sh1)) >> d.sh2);
-}
-
 // Which rays of which agent the one-wave block `b` of a render launch of `n_blocks` casts: env n, agent a, rays r0 .. r0 + span - 1
 // (those below R).  False: a spare block (see below).  The kernel's own mapping - and, through ms_host_render_block, what
 // tests/test_launch_geometry.py walks over whole launches on the CPU.
@@ -726,8 +714,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             if (__ballot(fresh_last) && lane == 0) atomicAdd(&late->out.seen_count[last_env], 1);
         }
         if (late->out.obs_centre) {                                // deathmatch.py:74-80: who is in the crosshair
-            const int sub = late->out.obs_subsample, W = R/sub;
-            const int r1 = (W/2 - 1)*sub + sub/2, r2 = (W/2)*sub + sub/2;
+            // (obs_subsample is a power of two - ms_render checks: shifts, not the thirty-instruction integer divisions a runtime
+            // divisor costs here)
+            const int sub = late->out.obs_subsample, sh = __builtin_ctz((unsigned)sub), W = R >> sh;
+            const int r1 = (((W >> 1) - 1) << sh) + (sub >> 1), r2 = ((W >> 1) << sh) + (sub >> 1);
             if ((r == r1) | (r == r2)) {
                 int seen = -1;
                 if ((nearest_idx >= 0) & (nearest_idx < AF)) seen = div_by(nearest_idx, rc.by_m);
@@ -766,7 +756,22 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         const int sub = late->out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
         float p0 = s0, p1 = s1, p2 = s2;
         float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
-        for (int o2 = 1; o2 < sub; o2 <<= 1) {
+        // (the first two rounds - lanes 1 and 2 apart: all of them at the demo envs' four rays a pixel - stay inside quads of lanes:
+        // DPP quad permutes, which ride on the add itself, instead of ds_bpermute's round trips through the LDS crossbar)
+        auto quad_xor = [](const float v, auto ctrl) {
+            return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), decltype(ctrl)::value, 0xf, 0xf, true));
+        };
+        constexpr std::integral_constant<int, 0xB1> XOR1{};      // quad_perm [1, 0, 3, 2]
+        constexpr std::integral_constant<int, 0x4E> XOR2{};      // quad_perm [2, 3, 0, 1]
+        if (sub > 1) {
+            if constexpr (COLOUR) { p0 += quad_xor(p0, XOR1); p1 += quad_xor(p1, XOR1); p2 += quad_xor(p2, XOR1); }
+            pd += quad_xor(pd, XOR1);
+        }
+        if (sub > 2) {
+            if constexpr (COLOUR) { p0 += quad_xor(p0, XOR2); p1 += quad_xor(p1, XOR2); p2 += quad_xor(p2, XOR2); }
+            pd += quad_xor(pd, XOR2);
+        }
+        for (int o2 = 4; o2 < sub; o2 <<= 1) {
             if constexpr (COLOUR) {
                 p0 += __shfl_xor(p0, o2, WAVE); p1 += __shfl_xor(p1, o2, WAVE); p2 += __shfl_xor(p2, o2, WAVE);
             }
@@ -775,8 +780,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         if (((lane & (sub - 1)) == 0) & (r < R)) {
             // (the mean: a sum over a power-of-two count - the host checks - divided by it, which only moves the exponent;
             // times the exact reciprocal is the same number for a twelfth of the instructions)
-            const float inv = 1.f/(float)sub;
-            const int W = R/sub, px = r/sub;
+            // (... and sub, which divides R, a power of two as well: 1/sub is 2^-sh exactly, R/sub and r/sub are shifts - as
+            // divisions by a run-time divisor these three were a hundred vector instructions per group of 64 rays, a seventh of
+            // everything such a wave does: the pooled instantiation at 512 rays took 160.8 us where the plain one takes 138.7)
+            const int sh = __builtin_ctz((unsigned)sub);
+            const float inv = bits_f((uint32_t)(127 - sh) << 23);
+            const int W = R >> sh, px = r >> sh;
             const size_t na = (size_t)n*A + a;
             if (COLOUR && late->out.obs_rgb) {
                 late->out.obs_rgb[(na*3 + 0)*W + px] = p0*inv;

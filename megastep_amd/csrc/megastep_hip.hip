@@ -433,9 +433,10 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
     MsScenery scn = *sc;
     if (!sc->wg_cells) { scn.wg_geom = sc->lines_vals; scn.wg_starts = sc->lines_starts; }   // (rows the kernel may read: see there)
     const hipStream_t hs = (hipStream_t)stream;
+    const Divisor by_a = divisor_of((unsigned)sc->n_agents);
     // one wavefront per env (several envs per wave, one AFTER the other: 2 -> +25 %, 4 -> +85 % at 4096 envs; side by side: PACK)
 #define MS_LAUNCH_PHYSICS_P(M, E, P) \
-    hipLaunchKernelGGL((physics_kernel<M, E, P>), dim3((sc->n_envs + pack - 1)/pack), dim3(WAVE), slice*16, hs, scn, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, pack)
+    hipLaunchKernelGGL((physics_kernel<M, E, P>), dim3((sc->n_envs + pack - 1)/pack), dim3(WAVE), slice*16, hs, scn, *ag, progress, cfg->agent_radius, cfg->fps, mvv, exv, pack, by_a)
 #define MS_LAUNCH_PHYSICS(M, E) { if (pack > 1) MS_LAUNCH_PHYSICS_P(M, E, 1); else MS_LAUNCH_PHYSICS_P(M, E, 0); }
     if (mv && ex) MS_LAUNCH_PHYSICS(1, 1)
     else if (ex) MS_LAUNCH_PHYSICS(0, 1)

@@ -20,10 +20,13 @@ ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--envs', type=int, default=4096)
 ap.add_argument('--agents', type=int, default=4)
 ap.add_argument('--res', type=int, default=64)
+ap.add_argument('--fov', type=float, default=130.)
+ap.add_argument('--sub', type=int, default=1, help='rays per observation pixel of the pooled variants')
+ap.add_argument('--centre', action='store_true', help='pooled variants also write the crosshair ids')
 args = ap.parse_args()
 bench.PLAN_WORKERS = 0
 dev = bench._Gpu(0)
-core, _ = bench.build_world(args.envs, args.agents, args.res, 130., dev.device, seed=1, n_unique=bench.plan_count(args.envs, args.agents))
+core, _ = bench.build_world(args.envs, args.agents, args.res, args.fov, dev.device, seed=1, n_unique=bench.plan_count(args.envs, args.agents))
 N, A, K = core.n_envs, core.n_agents, args.steps
 sc, ag = core.scenery, core.agents
 mover, imu = modules.MomentumMovement(core), modules.IMU(core)
@@ -47,9 +50,11 @@ def render_variant(kind, state):
     if kind == 'planes':
         state['r'] = cuda.render(sc, ag, out=state.get('r'))
     elif kind == 'obs':
-        state['r'] = cuda.render(sc, ag, fields=(), pooled=dict(subsample=1, max_depth=10., rgb=True, depth=True), out=state.get('r'))
+        state['r'] = cuda.render(sc, ag, fields=(), pooled=dict(subsample=args.sub, max_depth=10., rgb=True, depth=True, centre=args.centre), out=state.get('r'))
     elif kind == 'obs+planes':
-        state['r'] = cuda.render(sc, ag, pooled=dict(subsample=1, max_depth=10., rgb=True, depth=True), out=state.get('r'))
+        state['r'] = cuda.render(sc, ag, pooled=dict(subsample=args.sub, max_depth=10., rgb=True, depth=True, centre=args.centre), out=state.get('r'))
+    elif kind == 'obs-depth':
+        state['r'] = cuda.render(sc, ag, fields=(), pooled=dict(subsample=args.sub, max_depth=10., rgb=False, depth=True), out=state.get('r'))
     elif kind == 'depth':
         state['r'] = cuda.render(sc, ag, fields=('distances',), out=state.get('r'))
 
@@ -81,5 +86,5 @@ def timed(pk, rk, reps=60):
 
 
 for pk, rk in (('plain', 'planes'), ('move', 'planes'), ('move+imu', 'planes'), ('plain', 'obs'), ('plain', 'obs+planes'), ('plain', 'depth'),
-               ('move+imu', 'obs')):
+               ('move+imu', 'obs'), ('plain', 'obs-depth')):
     print(f'physics {pk:9s} render {rk:11s}: {timed(pk, rk):7.2f} us per step', flush=True)
