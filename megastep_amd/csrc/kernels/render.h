@@ -128,12 +128,15 @@ struct RenderConsts {
     float inv_res;                 // 1/res where that is a power of two (x/res is then x*inv_res bit for bit), else 0
     int telemetry;                 // ms_debug_pair_telemetry: pair / window counts into workspace[3], [4]
     int ws_headings;               // where in MsRender.workspace the (sin, cos) pairs of render_prep_kernel start, in 4-byte words
-    // Which of MsRender's optional outputs are there (OUT_* bits), worked out by the host: the OBS instantiations ask THIS - a
-    // scalar register the wave has had since its first instruction - whether an output is wanted, and only fetch a pointer
-    // from the kernel-argument segment when it is; asked of the pointers themselves every check was a scalar load and a wait
-    // of its own, per group of rays, for outputs nobody wanted.
-    int out_mask;
 };
+// Which of MsRender's optional outputs are there, as bits - for the COLOURLESS instantiations, which ask a scalar register the
+// wave has had since its first instruction whether an output is wanted and only fetch a pointer from the kernel-argument segment
+// when it is: asked of the pointers themselves every check was a scalar load and a wait of its own, per group of rays, for
+// outputs nobody wanted (512 rays, pooled depth alone: 121.8 -> 114.6 us, against 113.9 for bare distances).  ms_render hands
+// the bits over in the upper half of MsRender.obs_subsample of the copy it launches with - NOT as a field of RenderConsts, and
+// not to the colour instantiations: a 4-byte field more in the kernel's arguments, used or not, cost the colour kernels of four
+// ray groups a wave 5 % (512 rays: 144.9 -> 152.0 us, same box, same sources otherwise - they sit at 80 registers and 150
+// spilled scalars, and anything that moves their allocation moves their time; profiles/r05_ab_out_mask.txt).
 enum { OUT_INDICES = 1, OUT_LOCATIONS = 2, OUT_DOTS = 4, OUT_DISTANCES = 8, OUT_SCREEN = 16, OUT_RGB = 32, OUT_DEPTH = 64, OUT_CENTRE = 128,
        OUT_SEEN = 256 };
 // Which rays of which agent the one-wave block `b` of a render launch of `n_blocks` casts: env n, agent a, rays r0 .. r0 + span - 1
@@ -585,13 +588,16 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     // it; they are CALLED at the wave's end, and it is there that they read their kernel arguments: see RenderArgs.)
     constexpr bool COLOUR = SHADE != 0;
     static_assert(COLOUR || OBS == 1, "without colour `screen` is NULL: the OBS instantiation");
+    // (is an optional output wanted?  colourless: a bit of the mask ms_render left in obs_subsample's upper half; else the pointer)
+    [[maybe_unused]] const int out_mask_ = COLOUR ? 0 : (out.obs_subsample >> 8);
+#define MS_WANTED(BIT, PTR) (COLOUR ? ((PTR) != nullptr) : ((out_mask_ & (BIT)) != 0))
     // what depends on the winner's number alone: its row, its texel count and first texel
     // (plain scalars in and out: as a struct by value this cost every wave 32 bytes of scratch memory)
     auto winner_of = [&](const int nearest_idx, float4& hw_mem, int& tex_w, int& tstart) {
         const LateArgs late = late_args();       // (see RenderArgs: read where it is used, at the wave's end)
         // (uniform; constant-folded away in the colour instantiations)
-        const bool want_texel_row = COLOUR || (OBS && (rc.out_mask & OUT_SEEN));
-        const bool want_line = want_texel_row || !OBS || (rc.out_mask & (OUT_LOCATIONS | OUT_DOTS));
+        const bool want_texel_row = COLOUR || (OBS && MS_WANTED(OUT_SEEN, late->out.seen_stamp));
+        const bool want_line = want_texel_row || MS_WANTED(OUT_LOCATIONS, late->out.locations) || MS_WANTED(OUT_DOTS, late->out.dots);
         const int row = min(max(nearest_idx, 0), max(L - 1, 0));
         hw_mem = make_float4(0.f, 0.f, 0.f, 0.f); tex_w = 1; tstart = 0;
         if (want_line) hw_mem = rows.row(row);
@@ -606,8 +612,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
                             const float nearest_s, const int nearest_idx, const float4 hw_mem, const int tex_w, const int tstart) {
     const LateArgs late = late_args();       // (see RenderArgs: read where it is used, at the wave's end)
     // (uniform; constant-folded away in the colour instantiations)
-    const bool want_texel_row = COLOUR || (OBS && (rc.out_mask & OUT_SEEN));
-    const bool want_line = want_texel_row || !OBS || (rc.out_mask & (OUT_LOCATIONS | OUT_DOTS));
+    const bool want_texel_row = COLOUR || (OBS && MS_WANTED(OUT_SEEN, late->out.seen_stamp));
+    const bool want_line = want_texel_row || MS_WANTED(OUT_LOCATIONS, late->out.locations) || MS_WANTED(OUT_DOTS, late->out.dots);
     float loc = NAN, dt = NAN;
     float4 hw = make_float4(0.f, 0.f, 0.f, 0.f);
     if (want_line) {
@@ -627,16 +633,16 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     const size_t o = ((size_t)n*A + a)*R + r;
     const float dist = nearest_s*rlen;
     {
-        if (!OBS || (rc.out_mask & (OUT_INDICES | OUT_LOCATIONS | OUT_DOTS | OUT_DISTANCES))) {      // (uniform)
+        if (COLOUR || (out_mask_ & (OUT_INDICES | OUT_LOCATIONS | OUT_DOTS | OUT_DISTANCES))) {      // (uniform)
             int* const o_indices = late->out.indices;
             float* const o_locations = late->out.locations;
             float* const o_dots = late->out.dots;
             float* const o_distances = late->out.distances;
             if (r < R) {
-                if (!OBS || (rc.out_mask & OUT_INDICES)) MS_OUT_STORE(nearest_idx, &o_indices[o]);
-                if (!OBS || (rc.out_mask & OUT_LOCATIONS)) MS_OUT_STORE(loc, &o_locations[o]);
-                if (!OBS || (rc.out_mask & OUT_DOTS)) MS_OUT_STORE(dt, &o_dots[o]);
-                if (!OBS || (rc.out_mask & OUT_DISTANCES)) MS_OUT_STORE(dist, &o_distances[o]);
+                if (!OBS || MS_WANTED(OUT_INDICES, o_indices)) MS_OUT_STORE(nearest_idx, &o_indices[o]);
+                if (!OBS || MS_WANTED(OUT_LOCATIONS, o_locations)) MS_OUT_STORE(loc, &o_locations[o]);
+                if (!OBS || MS_WANTED(OUT_DOTS, o_dots)) MS_OUT_STORE(dt, &o_dots[o]);
+                if (!OBS || MS_WANTED(OUT_DISTANCES, o_distances)) MS_OUT_STORE(dist, &o_distances[o]);
             }
         }
     }
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
     }
     if constexpr (OBS == 1) {
-        if (rc.out_mask & OUT_SEEN) {                              // explorer.py:34-58: which texels are seen for the first time
+        if (MS_WANTED(OUT_SEEN, late->out.seen_stamp)) {           // explorer.py:34-58: which texels are seen for the first time
             bool fresh = false, fresh_last = false;
             const int last_env = sc.n_envs - 1;
             if (is_hit) {
@@ -722,10 +728,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             if (fm && lane == 0) atomicAdd(&late->out.seen_count[n], __popcll(fm));
             if (__ballot(fresh_last) && lane == 0) atomicAdd(&late->out.seen_count[last_env], 1);
         }
-        if (rc.out_mask & OUT_CENTRE) {                            // deathmatch.py:74-80: who is in the crosshair
+        if (MS_WANTED(OUT_CENTRE, late->out.obs_centre)) {         // deathmatch.py:74-80: who is in the crosshair
             // (obs_subsample is a power of two - ms_render checks: shifts, not the thirty-instruction integer divisions a runtime
             // divisor costs here)
-            const int sub = late->out.obs_subsample, sh = __builtin_ctz((unsigned)sub), W = R >> sh;
+            const int sub = COLOUR ? late->out.obs_subsample : (late->out.obs_subsample & 0xff), sh = __builtin_ctz((unsigned)sub), W = R >> sh;
             const int r1 = (((W >> 1) - 1) << sh) + (sub >> 1), r2 = ((W >> 1) << sh) + (sub >> 1);
             if ((r == r1) | (r == r2)) {
                 int seen = -1;
@@ -743,8 +749,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
             s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
         }
-        if (!OBS || (rc.out_mask & OUT_SCREEN)) {
-            float* const o_screen = late->out.screen;
+        float* const o_screen = late->out.screen;
+        if (!OBS || o_screen) {
             // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
             s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -761,8 +767,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     }
     // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
     // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
-    if (OBS && (rc.out_mask & ((COLOUR ? OUT_RGB : 0) | OUT_DEPTH))) {
-        const int sub = late->out.obs_subsample;                       // power of two, divides 64 and R (checked by the host)
+    if (OBS && ((COLOUR && late->out.obs_rgb) || MS_WANTED(OUT_DEPTH, late->out.obs_depth))) {
+        const int sub = COLOUR ? late->out.obs_subsample : (late->out.obs_subsample & 0xff);   // power of two, divides 64 and R (checked by the host)
         float p0 = s0, p1 = s1, p2 = s2;
         float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
         // (the first two rounds - lanes 1 and 2 apart: all of them at the demo envs' four rays a pixel - stay inside quads of lanes:
@@ -796,12 +802,12 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             const float inv = bits_f((uint32_t)(127 - sh) << 23);
             const int W = R >> sh, px = r >> sh;
             const size_t na = (size_t)n*A + a;
-            if (COLOUR && (rc.out_mask & OUT_RGB)) {
+            if (COLOUR && late->out.obs_rgb) {
                 late->out.obs_rgb[(na*3 + 0)*W + px] = p0*inv;
                 late->out.obs_rgb[(na*3 + 1)*W + px] = p1*inv;
                 late->out.obs_rgb[(na*3 + 2)*W + px] = p2*inv;
             }
-            if (rc.out_mask & OUT_DEPTH) late->out.obs_depth[na*W + px] = pd*inv;
+            if (MS_WANTED(OUT_DEPTH, late->out.obs_depth)) late->out.obs_depth[na*W + px] = pd*inv;
         }
     }
     };
@@ -1787,6 +1793,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         finish_group(0, r, rx, ry, rlen, nearest_s, nearest_idx, hw_mem, tex_w, tstart);
     }
     PROBE_DONE(fan)
+#undef MS_WANTED
 }
 
 // ------------------------------------------------------------------------------------------------

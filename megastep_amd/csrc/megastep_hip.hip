@@ -538,9 +538,14 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     rc.skip_own = (sc->model_radius > 0.f && sc->model_radius*1.01f < cfg->agent_radius) ? 1 : 0;
     rc.inv_res = ((R & (R - 1)) == 0 && half_screen > 1e-3f) ? 1.f/(float)R : 0.f;
     rc.telemetry = g_pair_telemetry;
-    rc.out_mask = (out->indices ? OUT_INDICES : 0) | (out->locations ? OUT_LOCATIONS : 0) | (out->dots ? OUT_DOTS : 0) |
-                  (out->distances ? OUT_DISTANCES : 0) | (out->screen ? OUT_SCREEN : 0) | (out->obs_rgb ? OUT_RGB : 0) |
-                  (out->obs_depth ? OUT_DEPTH : 0) | (out->obs_centre ? OUT_CENTRE : 0) | (out->seen_stamp ? OUT_SEEN : 0);
+    bool older_raycast = false;
+#if MS_AB_IMPLS
+    older_raycast = seq || pairs1;                                       // (their instantiations are the colour ones, whatever is asked for)
+#endif
+    if (!colour && !older_raycast)   // (the colourless instantiations read which optional outputs are wanted from here: see OUT_* in render.h)
+        outn.obs_subsample = (out->obs_subsample & 0xff) | (((out->indices ? OUT_INDICES : 0) | (out->locations ? OUT_LOCATIONS : 0) |
+                              (out->dots ? OUT_DOTS : 0) | (out->distances ? OUT_DISTANCES : 0) | (out->obs_depth ? OUT_DEPTH : 0) |
+                              (out->obs_centre ? OUT_CENTRE : 0) | (out->seen_stamp ? OUT_SEEN : 0)) << 8);
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
