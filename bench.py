@@ -445,7 +445,7 @@ def launch_ranks(args, argv):
     import subprocess
     if not args.dry_run_cpu:
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < args.gpus and not (args.share_gpu and have >= 1):
             raise SystemExit(f'bench.py: --gpus {args.gpus} asked for, but this node shows {have} GPU(s)')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -709,6 +709,8 @@ def main(argv=None):
     ap.add_argument('--no-graph', action='store_true', help='value = the eager leg (no HIP graph)')
     ap.add_argument('--dry-run-cpu', action='store_true', help='no GPU: stub kernels, real plumbing (tests)')
     ap.add_argument('--plan-workers', type=int, default=None, help='processes generating floorplans (0: in this process)')
+    ap.add_argument('--share-gpu', action='store_true', help='plumbing check on a box with fewer GPUs than ranks: rank r runs on device '
+                                                          'r mod the devices there are (the rates mean nothing then, and the line says so)')
     ap.add_argument('--plan-cache', default=None, help='pickle of generated floorplans: loaded if it exists, written (and the run ended) with '
                                                        '--plans-only - for profiled runs, which cannot fork plan workers')
     ap.add_argument('--plans-only', action='store_true')
@@ -749,7 +751,7 @@ def main(argv=None):
         world_geometries(4096, 1, 1, 64, large=True)
         world_geometries(4096, 1, 1, legacy=True)
     log('floorplans ready')
-    dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank)
+    dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank % max(torch.cuda.device_count(), 1) if args.share_gpu else local_rank)
     device = dev.device
     if distributed:
         import torch.distributed as dist
@@ -850,6 +852,8 @@ def main(argv=None):
         out['per_rank']['host'] = hosts
         out['timing'] = ('value = all ranks\' envs x K / MAX over ranks of each rank\'s OWN synchronize-to-synchronize time for the K steps '
                          '(start barrier before the clock starts; nothing collective inside it), median over the timed regions')
+    if args.share_gpu and distributed:
+        out['data'] = 'synthetic; RANKS SHARE A GPU (--share-gpu: a plumbing check, not a measurement)'
     if args.baseline_line:
         base = [json.loads(l) for l in open(args.baseline_line) if l.lstrip().startswith('{')][-1]
         out['scaling_efficiency'] = {'vs': os.path.basename(args.baseline_line), 'n1_value': base['value'], 'n1_gpus': base.get('n_gpus', 1),
