@@ -40,6 +40,13 @@ int ms_debug_ray_group_tail(float rounds, int envs);
 /* Has ms_render's waves add their (line, ray) pair and pair-window counts to workspace[3] and [4] (two atomics per wave on
  * one address: milliseconds at 10^5 waves - tools/pair_stats.py only).  Per calling thread. */
 int ms_debug_pair_telemetry(int on);
+/* The kernels' arithmetic shortcuts against what they stand for, element by element on the device (DEVICE pointers, `count`
+ * elements each): q_inrange[i] = div_inrange(n[i], d[i]) - the division without range scaling the render kernel uses where its
+ * operands are in range by construction (kernels/math.h) - next to q_ieee[i] = n[i] / d[i] as the compiler expands a correctly
+ * rounded division; r_any[i] = sqrt_any(x[i]) next to r_ieee[i] = sqrtf(x[i]).  tests/test_gpu_numerics.py holds them against
+ * each other bit for bit over the ranges the call sites guarantee.  Any output pointer may be NULL. */
+int ms_test_arithmetic(const float* n, const float* d, float* q_inrange, float* q_ieee, const float* x, float* r_any, float* r_ieee,
+                       long long count, void* hip_stream);
 /* Host instantiation of the light grid's build (ms_bake; accelerates kernels.cu:238-268) for one cell c (row-major in a grid
  * of nx x ny cells of size `cell` from (ox, oy)), over n_walls walls (n_walls x 4 floats: ax, ay, bx, by) and n_lights
  * lights (n_lights x 3: x, y, intensity), HOST memory: words[4] = the lights' 2-bit verdicts as in lg_vals (0 unknown, 1 lit,

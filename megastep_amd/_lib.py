@@ -68,7 +68,7 @@ class MsRender(C.Structure):
 
 
 #: every symbol include/megastep_hip.h (the boundary) and include/megastep_hip_test.h (test hooks) declare
-SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
+SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
            'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
@@ -183,6 +183,8 @@ def lib():
         handle.ms_debug_ray_group_tail.restype = C.c_int
         handle.ms_debug_pair_telemetry.argtypes = [C.c_int]
         handle.ms_debug_pair_telemetry.restype = C.c_int
+        handle.ms_test_arithmetic.argtypes = [C.c_void_p]*7 + [C.c_longlong, C.c_void_p]
+        handle.ms_test_arithmetic.restype = C.c_int
         handle.ms_host_fold_hits.argtypes = [_f32p, _i32p, C.c_int, _i32p, _f32p, _i32p]
         handle.ms_host_fold_hits.restype = C.c_int
         handle.ms_host_lightgrid_cell.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float,

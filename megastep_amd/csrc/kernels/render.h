@@ -139,6 +139,18 @@ struct RenderConsts {
 // spilled scalars, and anything that moves their allocation moves their time; profiles/r05_ab_out_mask.txt).
 enum { OUT_INDICES = 1, OUT_LOCATIONS = 2, OUT_DOTS = 4, OUT_DISTANCES = 8, OUT_SCREEN = 16, OUT_RGB = 32, OUT_DEPTH = 64, OUT_CENTRE = 128,
        OUT_SEEN = 256 };
+// (test hook, ms_test_arithmetic: the shortcuts above next to the operations they stand for)
+__global__ __launch_bounds__(WG) void arithmetic_test_kernel(const float* __restrict__ n, const float* __restrict__ d, float* __restrict__ q_inrange,
+                                                             float* __restrict__ q_ieee, const float* __restrict__ x, float* __restrict__ r_any,
+                                                             float* __restrict__ r_ieee, const long long count) {
+    const long long i = (long long)blockIdx.x*WG + threadIdx.x;
+    if (i >= count) return;
+    if (q_inrange) q_inrange[i] = div_by_refined(n[i], d[i], rcp_refined(d[i]));
+    if (q_ieee) q_ieee[i] = n[i]/d[i];
+    if (r_any) r_any[i] = sqrt_any(x[i]);
+    if (r_ieee) r_ieee[i] = sqrtf(x[i]);
+}
+
 // Which rays of which agent the one-wave block `b` of a render launch of `n_blocks` casts: env n, agent a, rays r0 .. r0 + span - 1
 // (those below R).  False: a spare block (see below).  The kernel's own mapping - and, through ms_host_render_block, what
 // tests/test_launch_geometry.py walks over whole launches on the CPU.

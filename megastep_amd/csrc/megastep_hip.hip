@@ -263,6 +263,17 @@ int ms_host_render_block(int n_envs, int n_agents, int res, int slots, int pinne
 int ms_debug_ray_group_tail(float rounds, int envs) { g_tail_rounds = rounds; g_tail_envs = envs; return MS_OK; }
 int ms_debug_pair_telemetry(int on) { g_pair_telemetry = on ? 1 : 0; return MS_OK; }
 
+int ms_test_arithmetic(const float* n, const float* d, float* q_inrange, float* q_ieee, const float* x, float* r_any, float* r_ieee,
+                       long long count, void* stream) {
+    if (count < 0 || ((q_inrange || q_ieee) && !(n && d)) || ((r_any || r_ieee) && !x)) return MS_EINVAL;
+    if (count == 0) return MS_OK;
+    const long long blocks = (count + WG - 1)/WG;
+    if (blocks > 0x7fffffffLL) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(arithmetic_test_kernel, dim3((unsigned)blocks), dim3(WG), 0, (hipStream_t)stream, n, d, q_inrange, q_ieee, x, r_any, r_ieee, count);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
 void ms_host_ray_interval_wide(const float* pose, const float* line, int res, float fov, float agent_radius, int groups, int wave,
                                int* first, int* count) {
     // (the launch-invariant values as ms_render works them out, the per-wave ones as render_kernel does)
