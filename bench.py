@@ -87,16 +87,18 @@ def plan_count(n_envs, n_agents, unique=None):
     return n_envs if n_agents == 1 else max(n_envs//4, 1)
 
 
-def world_geometries(n_envs, world, seed, n_unique=512, large=False, legacy=False):
+def world_geometries(n_envs, world, seed, n_unique=512, large=False, legacy=False, oblique=False):
     """The floorplan of every env of the whole (world x n_envs)-env job: a pool of exactly `n_unique` distinct plans, tiled.
     (`legacy`: the pool of rounds 1-3 - the training split of a 512-plan sample, 460 distinct - for a figure comparable
-    with theirs.)  Plans that are not cached yet are generated on forked worker processes."""
+    with theirs; `oblique`: the plans turned by seeded angles, with diagonal partitions - megastep_amd/cubicasa.py.)  Plans that
+    are not cached yet are generated on forked worker processes."""
     from megastep_amd import cubicasa
     workers = PLAN_WORKERS
     if legacy:
         pool = cubicasa.sample(min(512, n_envs), seed=seed + 1, n_unique=512, large=large, workers=workers, context=PLAN_CONTEXT)
     else:
-        pool = cubicasa.sample(n_unique, split='all', seed=seed + 1, n_unique=n_unique, large=large, workers=workers, context=PLAN_CONTEXT)
+        pool = cubicasa.sample(n_unique, split='all', seed=seed + 1, n_unique=n_unique, large=large, workers=workers, context=PLAN_CONTEXT,
+                               oblique=oblique)
     return [pool[i % len(pool)] for i in range(world*n_envs)]
 
 
@@ -112,12 +114,12 @@ def rank_slice(geometries, n_agents, res, rank, world):
 
 
 def build_world(n_envs, n_agents, res, fov, device, seed, n_unique=512, large=False, rank=0, world=1, bake=True, fast=False,
-                legacy=False):
+                legacy=False, oblique=False):
     """The benchmark's world - this rank's slice of it. With world > 1 the job has world x n_envs envs; every rank works
     out the same cost-balanced cuts from the floorplans and builds (and bakes) its own slice only: nothing of the other
     ranks' envs ever reaches this rank's device (reference: common.h:136-144 slices, it does not replicate)."""
     from megastep_amd import core, modules, scene
-    geometries = world_geometries(n_envs, world, seed, n_unique, large, legacy)
+    geometries = world_geometries(n_envs, world, seed, n_unique, large, legacy, oblique)
     start, stop = rank_slice(geometries, n_agents, res, rank, world)
     np.random.seed(seed)
     scenery = scene.scenery(geometries, n_agents, device=device, random=np.random.RandomState(seed), bake=bake, fast=fast,
@@ -172,10 +174,13 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     """Whole env.step() rates - kernels plus the torch glue of megastep_amd.demo.envs - with random actions, the
     quantity the reference's docs quote (docs/index.rst:13-25: Explorer 180k FPS, Deathmatch 1.2m FPS on a 2080 Ti).
     Explorer renders 256 rays -> 64 px, Deathmatch 512 -> 128 px, as in the reference; FPS counts agent-envs."""
-    from megastep_amd import arrdict, cubicasa
+    from megastep_amd import arrdict
     from megastep_amd.demo import Deathmatch, Explorer
-    pool = cubicasa.sample(256, n_unique=512)
-    geometries = [pool[i % len(pool)] for i in range(n_core_envs)]
+    # One distinct floorplan per core env, as the reference builds them: Explorer(n) samples n geometries (explorer.py:11),
+    # Deathmatch(n, 4) samples n // 4 for its n // 4 core envs (deathmatch.py:24, where n counts agent-rows, :44) - out of its 4492.
+    # (Rounds 2-5 tiled a 256-plan pool here: VERDICT r5, missing 2.)  The pool is C2's, generated before the GPU was touched.
+    geometries = world_geometries(n_core_envs, 1, 1, n_core_envs)
+    plans = len({id(g) for g in geometries})
 
     def rate(env, n):
         env.reset()
@@ -202,20 +207,21 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     log('Explorer timed')
     del env
     out['explorer'] = {'fps': eager, 'fps_hip_graph': graphed,
-                       'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU'}
+                       'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU', 'distinct_floorplans': plans}
     torch.cuda.empty_cache()
     # BASELINE config 2 says "depth-only": the same env without the RGB observation - the renderer's colourless instantiation
     env = Explorer(n_core_envs, device=device, geometries=geometries, depth_only=True)
     eager, graphed = rate(env, n_core_envs)
     del env
     out['explorer_depth_only'] = {'fps': eager, 'fps_hip_graph': graphed,
-                                  'env': f'Explorer({n_core_envs}, depth_only=True): 1 agent, 256 rays -> 64 px D+IMU'}
+                                  'env': f'Explorer({n_core_envs}, depth_only=True): 1 agent, 256 rays -> 64 px D+IMU', 'distinct_floorplans': plans}
     torch.cuda.empty_cache()
     env = Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries)
     log('Deathmatch built')
     eager, graphed = rate(env, 4*n_core_envs)
     out['deathmatch'] = {'fps': eager, 'fps_hip_graph': graphed,
-                         'env': f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU'}
+                         'env': f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU',
+                         'distinct_floorplans': plans}
     return out
 
 
@@ -242,7 +248,7 @@ def replay_steps(step, actions, repeats=5):
     return float(np.median(times))
 
 
-def traffic_entry(envs, agents, res, large=False, depth_only=False):
+def traffic_entry(envs, agents, res, large=False, depth_only=False, plans=None):
     """The newest profiles/rNN_traffic.json entry for a workload (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate PMC
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; since round 5 also the vector ALUs' busy
     fraction from the SQ pass of the same profile) and the file it was read from; (None, None) for a shape nobody profiled -
@@ -254,13 +260,19 @@ def traffic_entry(envs, agents, res, large=False, depth_only=False):
         for entry in t.get('shapes', [t]):                              # (one shape per file up to round 2, a list since)
             w = entry.get('workload', {})
             if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False)), bool(w.get('depth_only', False))) == want:
-                return entry, os.path.relpath(path, ROOT)
+                # (`plans`: the world's distinct floorplans - a profile of the same shape on another plan count moved other bytes:
+                # the 64-plan C5 world lives in the caches, the 4096-plan one does not.  An entry that does not say is a profile of
+                # the shape's default world, SURVEY 8(d)'s count; a line for another count gets no traffic rather than a wrong one.)
+                have = w.get('plans', plan_count(envs, agents) if not large else C5_PLANS)
+                if plans is None or have == plans:
+                    return entry, os.path.relpath(path, ROOT)
     return None, None
 
 
 def measured_traffic(args):
     """HBM bytes per ms_render launch of this exact workload from the rocprofv3 PMC passes (see traffic_entry)."""
-    entry, path = traffic_entry(args.envs, args.agents, args.res, args.large, args.depth_only)
+    plans = 460 if args.legacy_plans else plan_count(args.envs, args.agents, args.unique)
+    entry, path = traffic_entry(args.envs, args.agents, args.res, args.large, args.depth_only, plans)
     return (entry['render_bytes_per_launch'], path) if entry else (None, None)
 
 
@@ -270,11 +282,13 @@ def measured_block(core, fields, render_ms, step_ms, large=False):
     with the verdict on what bounds the shape. (The algorithmic formula of SURVEY 8(d) counts every line of an env once per
     launch; the kernels walk per-cell lists instead and at the larger shapes move LESS than it says - a fraction of bytes that
     were never moved is no utilisation, and round 4's C5 line read 8190 GB/s on an 8000 GB/s part that way.)"""
-    entry, path = traffic_entry(core.n_envs, core.n_agents, core.res, large, fields is not None and 'screen' not in fields)
+    sc = core.scenery
+    plans = int((sc.geom == torch.arange(core.n_envs, device=sc.geom.device)).sum()) if getattr(sc, 'geom', None) is not None else core.n_envs
+    entry, path = traffic_entry(core.n_envs, core.n_agents, core.res, large, fields is not None and 'screen' not in fields, plans)
     if entry is None:
-        return {'traffic': None}
+        return {'traffic': None, 'traffic_note': f'no profile of this shape on {plans} floorplans under profiles/'}
     rt, pt = entry['render_bytes_per_launch'], entry.get('physics_bytes_per_launch', 0.)
-    out = {'traffic': rt, 'traffic_source': path + f" (shape '{entry.get('shape', '?')}': profiled by envs x agents x rays, whatever the plan count)",
+    out = {'traffic': rt, 'traffic_source': path + f" (shape '{entry.get('shape', '?')}', {plans} floorplans)",
            'frac_measured': rt/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS,
            'step_traffic': rt + pt, 'step_measured_GBps': (rt + pt)/(step_ms*1e-3)/1e9}
     busy = entry.get('valu_busy_frac', {}).get('render_kernel')
@@ -556,13 +570,16 @@ def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields
 
 
 def ray_groups(dev, core):
-    """render_kernel's NG for this world as ms_render itself picks it: asked of the library's own launch plan
-    (ms_host_render_plan, the function ms_render calls), not re-derived here."""
+    """render_kernel's NG for this world: what this thread's last ms_render actually launched (ms_debug_last_render_groups - the
+    library's own record, with its pins, the scenery's grids and the device's wave slots taken into account; ADVICE r5: round 5
+    re-derived the rule here and could label a line with a kernel that was not the one launched). Every caller has just timed
+    the world's hot path on this thread; the CPU dry run, which launches nothing, asks the library's plan."""
     import ctypes
     from megastep_amd import _lib
+    if dev.device.type == 'cuda':
+        return int(_lib.lib().ms_debug_last_render_groups())
     ng = ctypes.c_int(0)
-    slots = 4*6*(torch.cuda.get_device_properties(dev.device).multi_processor_count if dev.device.type == 'cuda' else 256)
-    _lib.lib().ms_host_render_plan(core.n_envs, core.n_agents, core.res, slots, 0, -1., -1, ctypes.byref(ng))
+    _lib.lib().ms_host_render_plan(core.n_envs, core.n_agents, core.res, 4*6*256, 0, -1., -1, ctypes.byref(ng))
     return ng.value
 
 
@@ -646,6 +663,18 @@ def other_shapes(dev, steps=20, warmup=5):
     c = world('C5 share, 64 plans', 32768, 1, 256, 130., n_unique=64, large=True, fast=True)
     out['c5_per_gpu_share_64_plans'] = shape_entry(dev, c, steps, warmup, note="the same on rounds 3-4's 64 distinct plans (a 0.5 GB wall grid that "
                                                    "lives in the caches): for continuity, not the figure of record")
+    del c
+    torch.cuda.empty_cache()
+    c = world('headline, 4096 plans', 4096, 4, 64, 130., n_unique=4096)
+    out['headline_4096_plans'] = shape_entry(dev, c, steps, warmup, note="the headline shape on ONE DISTINCT FLOORPLAN PER CORE ENV - what the reference's "
+                                             "Deathmatch(16384, 4) builds (deathmatch.py:24: cubicasa.sample(n_envs // 4) for its n_envs // 4 core envs; "
+                                             "SURVEY 8(d)'s 'N // 4 tiled', which the headline follows, reads that line as a quarter of that)")
+    del c
+    torch.cuda.empty_cache()
+    c = world('headline, oblique plans', 4096, 4, 64, 130., n_unique=plan_count(4096, 4), oblique=True)
+    out['headline_oblique'] = shape_entry(dev, c, steps, warmup, note="the headline shape on floorplans turned by seeded angles, with diagonal partitions "
+                                          "(cubicasa.sample(oblique=True)): the reference's walls are exteriors of arbitrary SVG polygons "
+                                          "(geometry.py:43-57), the synthetic generator's are axis-aligned - same plan count as the headline")
     del c
     torch.cuda.empty_cache()
     c = world('headline, 460 plans', 4096, 4, 64, 130., legacy=True)
@@ -750,6 +779,9 @@ def main(argv=None):
         world_geometries(4096, 1, 1, C5_PLANS, large=True)
         world_geometries(4096, 1, 1, 64, large=True)
         world_geometries(4096, 1, 1, legacy=True)
+        world_geometries(4096, 1, 1, plan_count(4096, 4), oblique=True)
+    elif extras and not args.no_env_fps:
+        world_geometries(4096, 1, 1, 4096)                               # (the env.step legs': one plan per core env)
     log('floorplans ready')
     dev = _Stub() if args.dry_run_cpu else _Gpu(local_rank % max(torch.cuda.device_count(), 1) if args.share_gpu else local_rank)
     device = dev.device

@@ -24,6 +24,11 @@ int ms_debug_ray_groups(int groups);
  * world's size, 1 = one, k = k where k x n_agents <= 64 and there is a wall grid, else one).  Per calling thread; A/B runs and
  * tests - every setting produces the same bits. */
 int ms_debug_physics_pack(int envs);
+/* What the calling thread's last ms_render launched: the 64-ray groups per wave (render_kernel's NG: 1, 2, 4) it settled on -
+ * the pins, the scenery (no light grid: one group), the build (A/B raycasts: one) and the device's wave slots all taken into
+ * account, which a caller re-deriving the rule cannot know; 0 before the thread's first call.  bench.py labels its
+ * lines with it. */
+int ms_debug_last_render_groups(void);
 /* The launch geometry ms_render / ms_step_physics decide on the host, and the render kernel's own block -> rays mapping
  * (render_block), for tests that walk whole launches on the CPU.  `slots`: the machine's wave slots for the render kernel (CUs x
  * 4 SIMDs x 6 waves; 6144 on MI355X); pinned_groups / tail_rounds / tail_envs as the ms_debug_* hooks (0 / < 0 / < 0: the rules).

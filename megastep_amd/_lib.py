@@ -68,7 +68,7 @@ class MsRender(C.Structure):
 
 
 #: every symbol include/megastep_hip.h (the boundary) and include/megastep_hip_test.h (test hooks) declare
-SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
+SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_last_render_groups', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
            'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
@@ -171,6 +171,8 @@ def lib():
         handle.ms_host_ray_interval_wide.restype = None
         handle.ms_debug_ray_groups.argtypes = [C.c_int]
         handle.ms_debug_ray_groups.restype = C.c_int
+        handle.ms_debug_last_render_groups.argtypes = []
+        handle.ms_debug_last_render_groups.restype = C.c_int
         handle.ms_debug_ray_group_tail.argtypes = [C.c_float, C.c_int]
         handle.ms_debug_physics_pack.argtypes = [C.c_int]
         handle.ms_debug_physics_pack.restype = C.c_int

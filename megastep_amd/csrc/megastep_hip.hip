@@ -69,6 +69,7 @@ thread_local int g_ray_groups = 0;          // ms_debug_ray_groups: 0 = ms_rende
 thread_local int g_physics_pack = 0;        // ms_debug_physics_pack: 0 = ms_step_physics picks the envs a physics wave takes side by side, k >= 1 = k
 thread_local float g_tail_rounds = -1.f;    // ms_debug_ray_group_tail: < 0 = ms_render's own share of one-group waves at the end of a launch of wide ones
 thread_local int g_tail_envs = -1;          //   ... >= 0: that many envs exactly
+thread_local int g_last_render_groups = 0;  // ms_debug_last_render_groups: the NG this thread's last ms_render launched
 
 // -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
 // time stamps (s_memtime at its start, at a few points where something it waited for has arrived, at its end) and of
@@ -245,6 +246,7 @@ int ms_debug_probe(unsigned* buf, long long capacity) {
 #endif
 
 int ms_debug_ray_groups(int groups) { g_ray_groups = groups; return MS_OK; }
+int ms_debug_last_render_groups(void) { return g_last_render_groups; }
 int ms_debug_physics_pack(int envs) { g_physics_pack = envs; return MS_OK; }
 int ms_host_physics_pack(int n_envs, int n_agents, int gridded, int pinned) { return physics_pack_of(n_envs, n_agents, gridded != 0, pinned); }
 long long ms_host_render_plan(int n_envs, int n_agents, int res, int slots, int pinned_groups, float tail_rounds, int tail_envs, int* groups) {
@@ -490,6 +492,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     RenderConsts rc;
     const RenderPlan plan = render_plan(sc->n_envs, sc->n_agents, R, slots, wide_ok ? g_ray_groups : 1, g_tail_rounds, g_tail_envs, rc);
     const int ng = plan.ng;
+    g_last_render_groups = ng;
     const long long n_fans = plan.n_blocks;
     // the workspace's layout (MS_RENDER_WORKSPACE_INTS): 16 counters, a queue of one entry per (env, agent, 64 rays), the headings
     const long long ws_queue = (long long)sc->n_envs*sc->n_agents*((R + WAVE - 1)/WAVE);

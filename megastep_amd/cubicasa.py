@@ -11,6 +11,12 @@ procedurally generated apartments whose statistics follow the one in-repo datapo
   exteriors, geometry.py:43-57), broken by 0.9 m door gaps; small pillars pad the count to the target;
 * 150-400 wall segments per plan (800-1200 with ``large=True``), all coordinates > MARGIN;
 * one light per room at its centroid; masks at 0.2 m with -1 wall / 0 outside / k room.
+
+``oblique=True`` (round 6): the reference's walls are the exteriors of arbitrary SVG polygons (geometry.py:43-57) - nothing
+in a real floorplan is aligned with the axes of its coordinate system, and some walls are not aligned with each other. An
+oblique plan is the aligned plan of the same index with a few diagonal partitions added (thick pieces cutting room corners
+at seeded angles) and then the whole of it - walls, rooms, lights - turned by a seeded angle about its centre and moved
+back into the positive quadrant; masks are rasterised from the turned shapes.
 """
 import numpy as np
 from . import geometry, arrdict
@@ -70,7 +76,15 @@ def _find(parent, i):
     return i
 
 
-def floorplan(seed, large=False):
+def _turned_piece(cx, cy, length, angle):
+    """Outline of a THICK x length wall piece centred at (cx, cy), at `angle` to the x-axis: 4 oriented segments."""
+    c, s = np.cos(angle), np.sin(angle)
+    u, v = np.array([c, s])*length/2, np.array([-s, c])*THICK/2
+    corners = np.array([cx, cy]) + np.array([-u - v, u - v, u + v, -u + v])
+    return np.stack([corners, np.roll(corners, -1, 0)], 1)
+
+
+def floorplan(seed, large=False, oblique=False):
     """One synthetic apartment as a geometry dict (without ``id``)."""
     rng = np.random.RandomState(seed)
     scale = 2.2 if large else 1.
@@ -113,9 +127,34 @@ def floorplan(seed, large=False):
         px = rng.choice([x0 + THICK/2, x1 - THICK/2 - s])
         py = rng.uniform(y0 + THICK/2, max(y1 - THICK/2 - s, y0 + THICK/2 + 1e-3))
         walls.append(_rect_walls(px, py, px + s, py + s))
-    walls = np.concatenate(walls) + off
-
-    spaces = [np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]]) + off for x0, y0, x1, y1 in rooms]
+    spaces = [np.array([[x0, y0], [x1, y0], [x1, y1], [x0, y1]]) for x0, y0, x1, y1 in rooms]
+    if oblique:
+        # (a stream of its own: the aligned plan of this index is what it was)
+        orng = np.random.RandomState((seed + 0x9E3779B1) % (2**32))
+        # diagonal partitions: a piece across a corner of a room, 0.6-1.6 m from it, at 25-65 degrees to the room's walls
+        for i in orng.permutation(len(rooms))[:max(len(rooms)//4, 2)]:
+            x0, y0, x1, y1 = rooms[i]
+            d = orng.uniform(.6, min(1.6, .45*min(x1 - x0, y1 - y0)))
+            sx, sy = orng.choice([-1, 1]), orng.choice([-1, 1])
+            corner = np.array([x0 if sx > 0 else x1, y0 if sy > 0 else y1])
+            slope = np.radians(orng.uniform(25, 65))
+            # from (d / tan) along one wall to d along the other
+            p, q = corner + [sx*d/np.tan(slope), 0.], corner + [0., sy*d]
+            mid, vec = (p + q)/2, q - p
+            walls.append(_turned_piece(mid[0], mid[1], max(np.hypot(*vec) - 2*THICK, .2), np.arctan2(vec[1], vec[0])))
+        walls = np.concatenate(walls)
+        theta = orng.uniform(0, 2*np.pi)
+        c, s = np.cos(theta), np.sin(theta)
+        rot = np.array([[c, s], [-s, c]])                       # row vectors: p @ rot turns p by theta
+        centre = np.array([w/2, h/2])
+        walls = (walls - centre) @ rot
+        spaces = [(sp - centre) @ rot for sp in spaces]
+        shift = off - walls.reshape(-1, 2).min(0)               # back into the positive quadrant, every coordinate > MARGIN
+        walls = walls + shift
+        spaces = [sp + shift for sp in spaces]
+    else:
+        walls = np.concatenate(walls) + off
+        spaces = [sp + off for sp in spaces]
     return arrdict.arrdict(
         walls=walls,
         lights=geometry.centroids(spaces),
@@ -126,18 +165,31 @@ def floorplan(seed, large=False):
 _cache = {}
 
 
-def _plan(i, large):
-    key = (int(i), bool(large))
+def _key(i, large, oblique=False):
+    """A plan's cache key: (index, large) for the aligned plans - as it has always been - and (index, large, True) for the oblique."""
+    return (int(i), bool(large), True) if oblique else (int(i), bool(large))
+
+
+def _name(key):
+    return f'synthetic-{"L" if key[1] else "S"}{"o" if len(key) > 2 else ""}{key[0]:04d}'
+
+
+def _build(key):
+    return floorplan(1000003*int(key[1]) + key[0], key[1], len(key) > 2)
+
+
+def _plan(i, large, oblique=False):
+    key = _key(i, large, oblique)
     if key not in _cache:
-        _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if large else "S"}{int(i):04d}', **floorplan(1000003*int(large) + int(i), large))
+        _cache[key] = arrdict.arrdict(id=_name(key), **_build(key))
     return _cache[key]
 
 
 def _make(keys):
-    return [(key, floorplan(1000003*int(key[1]) + key[0], key[1])) for key in keys]
+    return [(key, _build(key)) for key in keys]
 
 
-def prefetch(indices, large=False, workers=None, context='fork'):
+def prefetch(indices, large=False, workers=None, context='fork', oblique=False):
     """Generates the plans ``indices`` that are not cached yet on ``workers`` worker processes (a plan takes ~7 ms of
     numpy on one core, a large one 23; the benchmark's Explorer-style worlds want thousands of distinct ones). ``context``
     'fork' (cheap; call it before the process has touched its GPU) or 'subprocess' (fresh numpy-only interpreters that
@@ -145,7 +197,7 @@ def prefetch(indices, large=False, workers=None, context='fork'):
     for a fraction of a second of start-up). Same plans as the lazy path - a plan is a function of its index alone."""
     import multiprocessing as mp
     import os
-    todo = sorted({(int(i), bool(large)) for i in indices} - set(_cache))
+    todo = sorted({_key(i, large, oblique) for i in indices} - set(_cache))
     workers = min(workers or (os.cpu_count() or 1), 32, max(len(todo)//16, 1))
     if workers <= 1 or len(todo) < 64:
         return
@@ -157,7 +209,7 @@ def prefetch(indices, large=False, workers=None, context='fork'):
         try:
             for _ in chunks:
                 for key, plan in results.next(timeout=60):           # (a pool that stalls is abandoned: the lazy path makes the rest)
-                    _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if key[1] else "S"}{key[0]:04d}', **plan)
+                    _cache[key] = arrdict.arrdict(id=_name(key), **plan)
         except mp.TimeoutError:
             pool.terminate()
 
@@ -171,7 +223,7 @@ for name in ('geometry', 'cubicasa'):
     spec = importlib.util.spec_from_file_location('_ms_plans.' + name, here + '/' + name + '.py')
     mod = importlib.util.module_from_spec(spec); sys.modules['_ms_plans.' + name] = mod; spec.loader.exec_module(mod)
 keys = pickle.load(open(todo_path, 'rb'))
-pickle.dump([(k, dict(mod.floorplan(1000003*int(k[1]) + k[0], k[1]))) for k in keys], open(out_path, 'wb'), protocol=4)
+pickle.dump([(k, dict(mod._build(k))) for k in keys], open(out_path, 'wb'), protocol=4)
 """
 
 
@@ -196,7 +248,7 @@ def _prefetch_subprocess(todo, workers):
             try:
                 if proc.wait(timeout=300) == 0:
                     for key, plan in pickle.load(open(dst, 'rb')):
-                        _cache[key] = arrdict.arrdict(id=f'synthetic-{"L" if key[1] else "S"}{key[0]:04d}', **plan)
+                        _cache[key] = arrdict.arrdict(id=_name(key), **plan)
             except subprocess.TimeoutExpired:                          # (the lazy path makes what is missing)
                 proc.kill()
 
@@ -215,12 +267,13 @@ def load_cache(path):
             _cache.setdefault(k, arrdict.arrdict(**v))
 
 
-def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0, context='fork'):
+def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQUE, workers=0, context='fork', oblique=False):
     """A deterministic sample of ``n_geometries`` floorplans; same arguments, same sample (reference:
     cubicasa.py:177-224). ``split`` is 90/10 ``training``/``test`` or ``all`` over ``n_unique`` plans; plans are
     generated lazily and repeat cyclically when more are asked for than the split holds. ``large`` and ``n_unique`` are
     extensions for the big-map benchmark point and for cheap tests; ``workers`` > 1 generates the missing plans on that
-    many worker processes first (see :func:`prefetch`; ``context``: how they are started)."""
+    many worker processes first (see :func:`prefetch`; ``context``: how they are started); ``oblique``: the plans turned by
+    seeded angles, with diagonal partitions (see the module's docstring)."""
     cutoff = int(.9*n_unique)
     order = np.random.RandomState(seed).permutation(n_unique)
     if split == 'training':
@@ -230,5 +283,5 @@ def sample(n_geometries, split='training', seed=1, large=False, n_unique=N_UNIQU
     elif split != 'all':
         raise ValueError('Split must be train/test/all')
     if workers and workers > 1:
-        prefetch(order[:n_geometries], large, workers, context)
-    return [_plan(order[i % len(order)], large) for i in range(n_geometries)]
+        prefetch(order[:n_geometries], large, workers, context, oblique)
+    return [_plan(order[i % len(order)], large, oblique) for i in range(n_geometries)]

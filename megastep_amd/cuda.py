@@ -21,8 +21,17 @@ from . import _lib
 _config = None
 
 
+_switched = __import__('threading').local()
+
+
 def _ab_switches():
-    """A/B switches of the library that tools set through the environment (the library itself reads none on its hot path)."""
+    """A/B switches of the library that tools set through the environment (the library itself reads none on its hot path).
+    The library's pins are per THREAD (megastep_hip.hip: thread_local), so they are applied once on every thread that launches -
+    physics() and render() call this - not only on the one that called initialize() (an A/B run that stepped from a
+    worker thread compared two identical builds)."""
+    if getattr(_switched, 'done', False):
+        return
+    _switched.done = True
     g = os.environ.get('MEGASTEP_RAY_GROUPS')
     if g:
         _lib.lib().ms_debug_ray_groups(int(g))           # 64-ray groups per render wave: 1, 2, 4 (default: by resolution)
@@ -284,7 +293,7 @@ class Scenery:
         if self.LIGHT_GRID_BYTES is not None:
             return int(self.LIGHT_GRID_BYTES)
         dev = self._lines.vals.device
-        return torch.cuda.get_device_properties(dev).total_memory//8 if dev.type == 'cuda' else 8 << 30
+        return _memory_share(dev, 8) if dev.type == 'cuda' else 8 << 30
 
     def _light_grid(self):
         """Storage and geometry of the light grid (see include/megastep_hip.h): a uniform grid over each env's walls,
@@ -338,6 +347,11 @@ class Scenery:
         None, 'light_grid': {bytes, cell, cells, candidate_rows, ...} or None, 'bake_seconds': {lighting, wall_grid} of the last
         cuda.bake()} - the sizes actually allocated and the cell sizes actually used (either grid coarsens itself to stay inside
         its byte budget)."""
+        marks = getattr(self, '_bake_marks', None)
+        if getattr(self, '_bake_s', None) is None and marks is not None and marks[0] is not None:
+            ev, wall_grid = marks
+            ev[2].synchronize()
+            self._bake_s = dict(lighting=ev[0].elapsed_time(ev[1])*1e-3, wall_grid=ev[1].elapsed_time(ev[2])*1e-3 if wall_grid else 0.)
         return dict(wall_grid=self._wg_report, light_grid=self._lg_report, bake_seconds=getattr(self, '_bake_s', None))
 
     def _wall_bounds(self):
@@ -405,8 +419,7 @@ class Scenery:
     def _wall_grid_budget(self):
         if self.WALL_GRID_BYTES is not None:
             return int(self.WALL_GRID_BYTES)
-        dev = self._device()
-        return torch.cuda.get_device_properties(dev).total_memory//4
+        return _memory_share(self._device(), 4)
 
     def _scan_level(self, cell, parent, final, usable):
         """One level of the wall grid: cells of size `cell` over every representative floorplan, scanned (against the
@@ -553,11 +566,21 @@ class Scenery:
             usable = (extent[:, 0]*extent[:, 1] <= self.WALL_GRID_MAX_CELLS) & (walls > 0) & (walls <= 65535)
             parent = None
             if self.WALL_GRID_COARSE:
-                level = self._scan_level(cell*self.WALL_GRID_COARSE, None, False, usable)
+                try:
+                    level = self._scan_level(cell*self.WALL_GRID_COARSE, None, False, usable)
+                except torch.cuda.OutOfMemoryError:
+                    level = None
+                    torch.cuda.empty_cache()
                 if level is not None:
                     hdr, starts, geom, pool, _, cells, _ = level
                     parent = (hdr, starts, geom, float(cell*self.WALL_GRID_COARSE), pool, cells)
-            level = self._scan_level(cell, parent, True, usable)
+            try:
+                level = self._scan_level(cell, parent, True, usable)
+            except torch.cuda.OutOfMemoryError:
+                # (the budget is an estimate of the final size; the build's peak is higher - on a device that is nearly full the
+                # next coarser level is the answer, not a crash)
+                level, parent = None, None
+                torch.cuda.empty_cache()
             if level is not None:
                 hdr, starts, geom, pool, near, _, pool_base = level
                 self._wg = (hdr, starts, geom, float(cell), float(self.WALL_GRID_REACH[0]), float(self.WALL_GRID_REACH[1]),
@@ -647,6 +670,18 @@ def _as_u32(t):
     return torch.where(t >= 2**31, t - 2**32, t).to(torch.int32).contiguous()
 
 
+def _memory_share(dev, fraction):
+    """The default byte budget of a grid: 1/`fraction` of the device's memory - but never more than a third of what is FREE on
+    it right now (next to a policy and its optimizer, or on a small GPU, a share of the TOTAL is memory that is not there:
+    ADVICE r5; building a wall grid peaks at about twice its final size, so a third of the free memory is what can be afforded)."""
+    total = torch.cuda.get_device_properties(dev).total_memory
+    try:
+        free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # (+ what torch's cache holds idle)
+    except Exception:
+        free = total
+    return int(min(total//fraction, free//3))
+
+
 class _on:
     """Makes ``dev`` the current HIP device for the launch if it is not already."""
 
@@ -687,17 +722,22 @@ def bake(scenery, scratch=True, wall_grid=True):
         vis, starts = scenery._bake_plan()
         struct = _lib.MsScenery.from_buffer_copy(struct)
         struct.bake_vis, struct.bake_vis_starts, struct.bake_vis_words = vis.data_ptr(), starts.data_ptr(), vis.shape[0]
-    import time
-    torch.cuda.synchronize(dev)                                          # (a one-off: what it cost goes into grid_report())
-    t0 = time.perf_counter()
+    # What it cost goes into grid_report() - from events on the CURRENT stream, read when the report is asked for: no device-wide
+    # synchronize here (round 5 had three: every other stream of the device stalled for a number nobody may want, and a bake
+    # inside a stream capture raised).
     with _on(dev):
+        timed = not torch.cuda.is_current_stream_capturing()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if timed:
+            marks[0].record()
         _lib.check(_lib.lib().ms_bake(C.byref(struct), cfg, _stream(dev)))
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    if wall_grid:
-        scenery._build_wall_grid()
-        torch.cuda.synchronize(dev)
-    scenery._bake_s = dict(lighting=t1 - t0, wall_grid=time.perf_counter() - t1 if wall_grid else 0.)
+        if timed:
+            marks[1].record()
+        if wall_grid:
+            scenery._build_wall_grid()
+        if timed:
+            marks[2].record()
+    scenery._bake_marks, scenery._bake_s = (marks, wall_grid), None
 
 
 def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None, config=None):
@@ -767,6 +807,7 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
         _require_gpu(*used)
         ex = C.byref(x)
     progress = torch.empty_like(agents.angles) if out is None else out.progress      # `out`: an earlier call's Physics
+    _ab_switches()
     _check_grid(scenery, dev)
     with _on(dev):
         _lib.check(_lib.lib().ms_step_physics(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
@@ -837,6 +878,7 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
         result._key = key
         if seen is not None:
             result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = (t.data_ptr() for t in seen)
+    _ab_switches()
     _check_grid(scenery, dev)
     with _on(dev):
         use_cache = agents._cached and not telemetry

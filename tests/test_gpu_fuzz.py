@@ -20,3 +20,11 @@ def test_random_worlds_match_the_oracle(first):
     for seed in range(first, first + 12):
         print(seed, fuzz.one(seed))
         print(seed, fuzz.one_fused(seed))
+
+
+@pytest.mark.parametrize('first', [100, 108])
+def test_random_oblique_worlds_match_the_oracle(first):
+    """Round 6: every seed on floorplans turned by seeded angles with diagonal partitions (cubicasa.sample(oblique=True)) - until
+    then every plan-scale world the device had met was axis-aligned, which the reference's SVG polygons are not."""
+    for seed in range(first, first + 8):
+        print(seed, fuzz.one(seed, oblique=True))

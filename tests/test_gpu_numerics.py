@@ -59,6 +59,29 @@ def test_division_in_range_is_the_correctly_rounded_quotient():
     assert (z['fast'] == 0).all() and (z['ieee'] == 0).all()
 
 
+def test_division_in_range_over_the_lighting_sites_whole_declared_range():
+    """The dynamic lighting's call site (kernels/lighting.h, `nice`): 2 I / max(d^2, 1) with I in [1e-12, 1e12] and lights and hit
+    points within 10^6 m of the origin - numerators 2e-12 .. 2e12, divisors 1 .. 8e12, up to 82 binary orders apart.  ADVICE r5:
+    the guard used to let 1e-30 .. 1e30 and 10^15 m through, a range no test covered; it now admits exactly what is swept here."""
+    rng = np.random.RandomState(4)
+    m = 5_000_000
+    n = (2.*10.**rng.uniform(-12, 12, m)).astype(np.float32)
+    d = np.maximum(10.**rng.uniform(-2, np.log10(8e12), m), 1.).astype(np.float32)
+    # the corners of the box, and quotients next to rounding boundaries at both ends of it
+    n[:4], d[:4] = [2e-12, 2e-12, 2e12, 2e12], [1., 8e12, 1., 8e12]
+    k = 500_000
+    q0 = (rng.randint(1, 1 << 12, k)/float(1 << 11)).astype(np.float32)*(10.**rng.uniform(-24, 12, k)).astype(np.float32)
+    near = (q0*d[4:4 + k]).astype(np.float32)
+    ok = (near >= 2e-12) & (near <= 2e12)
+    near = (near.view(np.int32) + rng.randint(-3, 4, k).astype(np.int32)).view(np.float32)
+    n[4:4 + k] = np.where(ok, near, n[4:4 + k])
+    got, _ = _run(n, d)
+    want = (n/d).astype(np.float32)
+    assert np.array_equal(_bits(got['ieee']), _bits(want))
+    diff = _bits(got['fast']) != _bits(want)
+    assert not diff.any(), (int(diff.sum()), n[diff][:5], d[diff][:5], got['fast'][diff][:5], want[diff][:5])
+
+
 def test_division_outside_its_range_only_where_the_kernels_say_it_may_differ():
     """Numerators below 2^-104 (the compiler's expansion rescales those): the quotient may differ from the IEEE one there - by a few
     ulps of something below 1e-28, which every call site either throws away (a hit inside the near plane) or writes to a float

@@ -182,6 +182,58 @@ def test_full_benchmark_size_matches_oracle():
         util.assert_render_matches(c, r, ref.render())
 
 
+def test_full_benchmark_size_on_oblique_floorplans_matches_oracle():
+    """The headline shape on floorplans turned by seeded angles with diagonal partitions (cubicasa.sample(oblique=True), the bench's
+    `shapes.headline_oblique` world): the reference's walls are exteriors of arbitrary SVG polygons (geometry.py:43-57), and until
+    round 6 every plan-scale world the kernels had met - the occlusion cull's pass-1 intervals, the view arcs, the light grid's
+    verdicts - was axis-aligned.  All 4096 envs against the oracle, two steps, bake included."""
+    from megastep_amd import cuda
+    import bench
+    bench.PLAN_CONTEXT = 'subprocess'
+    c, geometries = bench.build_world(4096, 4, 64, 130., torch.device('cuda'), seed=1, n_unique=bench.plan_count(4096, 4), oblique=True)
+    assert len({id(g) for g in geometries}) == 1024 and c.scenery.grid_report()['wall_grid']['floorplans'] == 1024
+    walls = geometries[0].walls
+    d = walls[:, 1] - walls[:, 0]
+    assert (np.abs(d).min(1) > 1e-3).mean() > .9, 'hardly a wall of an oblique plan is aligned with an axis'
+    ref = util.OracleWorld(c)
+    np.testing.assert_allclose(c.scenery.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+    ref.pull_baked(c)
+    rng = np.random.RandomState(6)
+    for step in range(2):
+        util.random_velocities(c, rng, speed=6.)
+        ref.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        prog_ref, agents_ref = ref.physics()
+        util.assert_physics_matches(c, p, prog_ref, agents_ref)
+        util.assert_render_matches(c, r, ref.render())
+
+
+@pytest.mark.parametrize('n_envs,n_agents,res,fov,large', [(8, 4, 64, 130, False), (6, 1, 256, 130, True), (5, 4, 512, 70, False), (4, 2, 100, 160, False)])
+def test_step_on_oblique_floorplans_matches_oracle(n_envs, n_agents, res, fov, large):
+    """Small oblique worlds through every instantiation family: the plain one, wide single-agent fans on large plans, the
+    reference Deathmatch's 512 rays, a ragged last group at a wide view - four steps each, lines written back included."""
+    from megastep_amd import core, cubicasa, cuda, scene
+    np.random.seed(11)
+    geometries = cubicasa.sample(n_envs, n_unique=16, seed=12, large=large, oblique=True)
+    scenery = scene.scenery(geometries, n_agents, device='cuda', random=np.random.RandomState(11))
+    c = core.Core(scenery, res=res, fov=fov, fps=10)
+    util.spawn(c, geometries, seed=11)
+    ref = util.OracleWorld(c)
+    np.testing.assert_allclose(c.scenery.baked.vals.cpu().numpy(), ref.bake(), rtol=0, atol=1e-5)
+    ref.pull_baked(c)
+    rng = np.random.RandomState(8)
+    for step in range(4):
+        util.random_velocities(c, rng, speed=4. if step % 2 else 40.)
+        ref.pull_agents(c)
+        p = cuda.physics(c.scenery, c.agents)
+        r = cuda.render(c.scenery, c.agents)
+        prog_ref, agents_ref = ref.physics()
+        util.assert_physics_matches(c, p, prog_ref, agents_ref)
+        util.assert_render_matches(c, r, ref.render())
+        np.testing.assert_allclose(c.scenery.lines.vals.cpu().numpy(), ref.scene.lines_vals, rtol=0, atol=1e-6)
+
+
 _obstructed = util.obstructed
 
 

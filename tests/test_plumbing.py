@@ -155,6 +155,31 @@ def test_synthetic_cubicasa_sample_is_deterministic_and_in_range():
     assert 800 <= len(big.walls) <= 1204
 
 
+def test_oblique_plans_are_the_aligned_ones_turned_with_diagonal_partitions():
+    """cubicasa.sample(oblique=True) (round 6; the reference's walls are exteriors of arbitrary polygons, geometry.py:43-57): the
+    plan of the same index, a few diagonal pieces added, everything turned by one seeded angle - walls at two families of
+    directions 90 degrees apart plus the diagonals', every coordinate still beyond MARGIN, lights in their rooms, lengths kept."""
+    a, b = cubicasa.sample(5, n_unique=32, oblique=True), cubicasa.sample(5, n_unique=32, oblique=True)
+    flat = cubicasa.sample(5, n_unique=32)
+    for ga, gb, g0 in zip(a, b, flat):
+        assert ga.id == gb.id and ga.id != g0.id and (ga.walls == gb.walls).all() and (ga.masks == gb.masks).all()
+        extra = len(ga.walls) - len(g0.walls)
+        assert extra >= 8 and extra % 4 == 0                                  # the diagonal pieces: four segments each
+        assert ga.walls.min() > geometry.MARGIN - 1e-9 and scene.lengths(ga.walls).min() > 1e-3
+        # a turn keeps lengths: the aligned plan's walls come first, in their order
+        np.testing.assert_allclose(scene.lengths(ga.walls[:len(g0.walls)]), scene.lengths(g0.walls), atol=1e-9)
+        d = ga.walls[:, 1] - ga.walls[:, 0]
+        ang = np.degrees(np.arctan2(d[:, 1], d[:, 0])) % 90
+        main = np.median(ang[:len(g0.walls)])
+        assert (np.abs(ang[:len(g0.walls)] - main) < 1e-6).mean() > .99        # one turn for the whole plan
+        assert (np.abs(ang[len(g0.walls):] - main) > 1.).any()                 # ... and the diagonals are at others
+        assert (np.abs(d).min(1) > 1e-3).mean() > .9, 'hardly anything is left aligned with the axes'
+        room_cells = geometry.indices(ga.lights, ga.masks.shape, ga.res)
+        assert (ga.masks[room_cells[:, 0], room_cells[:, 1]] > 0).all() and (ga.masks > 0).sum() > 100 and ga.masks.min() == -1
+    big = cubicasa.sample(1, large=True, n_unique=16, oblique=True)[0]
+    assert 800 <= len(big.walls) <= 1300
+
+
 def test_env_slices_partition_the_envs():
     for n, w in [(4096, 8), (10, 3), (7, 7), (5, 8)]:
         slices = [sharding.env_slice(n, r, w) for r in range(w)]

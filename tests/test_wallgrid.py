@@ -89,11 +89,28 @@ def mutated(walls, rng):
 
 
 CASES = ['plan0', 'plan1', 'plan2_mutated', 'plan3_mutated', 'plan4', 'plan5_mutated', 'plan6', 'plan7', 'plan8_mutated', 'plan9',
-         'large', 'box', 'column']
+         'large', 'box', 'column', 'oblique0', 'oblique1', 'oblique2_mutated', 'oblique3', 'obliquelarge']
+
+
+def case_geometry(name):
+    """The floorplan behind a case (round 6: `oblique*` - plans turned by seeded angles, with diagonal partitions: the reference's
+    walls are exteriors of arbitrary polygons, geometry.py:43-57, and until then every plan-scale case here was axis-aligned)."""
+    if name == 'obliquelarge':
+        return cubicasa.sample(1, n_unique=16, large=True, oblique=True)[0]
+    if name.startswith('oblique'):
+        return cubicasa.sample(4, n_unique=16, oblique=True)[int(name[7])]
+    if name == 'large':
+        return cubicasa.sample(1, n_unique=16, large=True)[0]
+    if name.startswith('plan'):
+        return cubicasa.sample(10, n_unique=16)[int(name[4])]
+    return toys.box() if name == 'box' else toys.column()
 
 
 def case_walls(name):
     rng = np.random.RandomState(zlib.crc32(name.encode()))              # (not hash(): that changes from run to run)
+    if name.startswith('oblique'):
+        w = case_geometry(name).walls.astype(np.float32)
+        return mutated(w, rng) if name.endswith('mutated') else w
     if name.startswith('plan'):
         g = cubicasa.sample(10, n_unique=16)[int(name[4])]
         w = g.walls.astype(np.float32)
@@ -108,7 +125,7 @@ def test_vis_lists_leave_the_fold_where_it_was(oracle, name):
     walls = case_walls(name)
     rng = np.random.RandomState(1)
     origin, dims = grid_of(walls)
-    n_cells = 10 if name == 'large' else 24
+    n_cells = 10 if name.endswith('large') else 24
     cells = rng.choice(dims[0]*dims[1], n_cells, replace=False)
     poses, keep = [], []
     listed = []
@@ -127,11 +144,11 @@ def test_vis_lists_leave_the_fold_where_it_was(oracle, name):
         np.testing.assert_array_equal(part, full, err_msg=f'{name}: hit lines differ at fov {fov}')
         for k in ('distances', 'locations', 'dots'):
             np.testing.assert_array_equal(rp[k], rf[k], err_msg=f'{name}: {k} differ at fov {fov}')
-    if name.startswith('plan') or name == 'large':
+    if name.startswith('plan') or name.startswith('oblique') or name == 'large':
         assert np.mean(listed) < .6, f'the lists hold {np.mean(listed):.2f} of the walls: nothing is being culled'
 
 
-@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'box'])
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'box', 'oblique0', 'oblique2_mutated'])
 def test_near_lists_hold_every_wall_within_reach(name):
     walls = case_walls(name)
     rng = np.random.RandomState(2)
@@ -173,7 +190,7 @@ def test_one_wall_hides_another_only_when_it_really_does():
     assert not hidden(cell, wide, (4., -.5, 4., -.5 + 1e-30))
 
 
-@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'large', 'box'])
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'large', 'box', 'oblique1', 'oblique2_mutated', 'obliquelarge'])
 def test_a_wall_is_only_ever_seen_inside_its_arc(name):
     """The view arcs the vis entries carry (wg_arc) and the test the render kernel makes with them (wg_wedge,
     wg_arcs_meet): whenever a ray from a point of the cell can hit a wall at all - its direction is that of some point of
@@ -390,7 +407,7 @@ def test_three_key_slots_settle_a_ray_like_the_literal_fold():
     assert settled > unsure > 1000, 'settled by the slots more often than not, even here; and the sample does reach the cases they leave to the fold'
 
 
-@pytest.mark.parametrize('name', ['plan0', 'plan1', 'plan3', 'large', 'box', 'column'])
+@pytest.mark.parametrize('name', ['plan0', 'plan1', 'plan3', 'large', 'box', 'column', 'oblique0', 'oblique3', 'obliquelarge'])
 def test_light_grid_verdicts_and_candidates_hold_on_every_sampled_point(name):
     """The light grid (ms_bake) may call a light LIT or DARK for a cell only where the reference's
     obstructed() (kernels.cu:253-257) says so at EVERY point of the cell, and the candidate walls it lists for the lights
@@ -399,10 +416,10 @@ def test_light_grid_verdicts_and_candidates_hold_on_every_sampled_point(name):
     corners.  (tests/test_gpu_parity.py does the same with the grid a GPU built.)"""
     from tests import util
     rng = np.random.RandomState(3)
-    if name.startswith('plan') or name == 'large':
-        g = cubicasa.sample(1, n_unique=16, large=True)[0] if name == 'large' else cubicasa.sample(4, n_unique=16)[int(name[4])]
+    if name.startswith('plan'):
+        g = cubicasa.sample(4, n_unique=16)[int(name[4])]
     else:
-        g = toys.box() if name == 'box' else toys.column()
+        g = case_geometry(name)
     walls = np.ascontiguousarray(g.walls, np.float32)
     pos = np.asarray(g.lights, np.float32).reshape(-1, 2)
     lo, hi = walls.reshape(-1, 2).min(0), walls.reshape(-1, 2).max(0)
@@ -412,7 +429,7 @@ def test_light_grid_verdicts_and_candidates_hold_on_every_sampled_point(name):
     lib = _lib.lib()
     flat = np.ascontiguousarray(walls.reshape(-1, 4))
     n_lit = n_dark = n_open = 0
-    for c in rng.choice(dims[0]*dims[1], min(40 if name == 'large' else 120, dims[0]*dims[1]), replace=False):
+    for c in rng.choice(dims[0]*dims[1], min({'large': 40, 'obliquelarge': 100}.get(name, 120), dims[0]*dims[1]), replace=False):
         words, cands = np.zeros(4, np.uint32), np.zeros(4096, np.uint32)
         n = lib.ms_host_lightgrid_cell(flat.ctypes.data, len(flat), lights.ctypes.data, len(lights), float(origin[0]), float(origin[1]),
                                        int(dims[0]), int(dims[1]), CELL, int(c), words.ctypes.data, cands.ctypes.data, len(cands))
@@ -440,7 +457,8 @@ def test_light_grid_verdicts_and_candidates_hold_on_every_sampled_point(name):
 
 
 @pytest.mark.parametrize('name,res,fov', [('plan0', 64, 130.), ('plan1', 256, 130.), ('plan2_mutated', 128, 90.), ('plan6', 512, 60.),
-                                          ('large', 64, 160.), ('column', 32, 130.)])
+                                          ('large', 64, 160.), ('column', 32, 130.), ('oblique0', 64, 130.), ('oblique1', 256, 130.),
+                                          ('oblique2_mutated', 128, 70.), ('obliquelarge', 256, 130.)])
 def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fov):
     """What a render wave intersects, put together on the host from the pieces the kernel is compiled from: the walls on
     the vis list of the agent's cell, less those whose view arc misses the run of directions of the wave's own rays
@@ -452,7 +470,7 @@ def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fo
     lib = _lib.lib()
     origin, dims = grid_of(walls)
     M = len(scene.agent_model())
-    cells = rng.choice(dims[0]*dims[1], 6 if name == 'large' else 16, replace=False)
+    cells = rng.choice(dims[0]*dims[1], 6 if name.endswith('large') else 16, replace=False)
     poses, cell_of = [], []
     for c in cells:
         x0, y0 = origin[0] + (c % dims[0])*CELL, origin[1] + (c//dims[0])*CELL
@@ -497,7 +515,7 @@ def test_the_whole_chain_of_culls_keeps_every_winning_pair(oracle, name, res, fo
     assert kept_pairs < .2*all_pairs, f'{kept_pairs/all_pairs:.2f} of all (wall, ray) pairs are kept: nothing is being culled'
 
 
-@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'plan7', 'box'])
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'plan7', 'box', 'oblique1', 'oblique2_mutated'])
 def test_the_walls_a_physics_wave_meets_are_all_that_can_stop_the_agent(oracle, name):
     """ms_physics' chain put together on the host: the agent's reach picks the short or the long tier of its cell's near
     list (or, past the long one, every wall), the reach cull drops what is beyond, the rest goes through the exact test -

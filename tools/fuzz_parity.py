@@ -9,20 +9,28 @@ from tests import util
 from megastep_amd import core, cubicasa, cuda, scene, toys
 
 
-def one(seed):
+def one(seed, oblique=None):
+    """`oblique` (None: every third seed): floorplans turned by seeded angles with diagonal partitions (cubicasa.sample(oblique=True):
+    the reference's walls are exteriors of arbitrary polygons, geometry.py:43-57), and, where walls are mutated, some of them
+    swung about their middles by random angles as well."""
     rng = np.random.RandomState(1000 + seed)
+    forced = oblique is True
+    oblique = (seed % 3 == 2) if oblique is None else oblique
     n_agents = int(rng.choice([1, 1, 2, 3, 4, 4, 5, 8, 17, 65, 70], p=[.15, .1, .15, .1, .15, .1, .1, .06, .05, .02, .02]))
     res = int(rng.choice([1, 3, 8, 64, 64, 100, 128, 256, 512, 600]))
     if n_agents > 8:
         res = min(res, 128)
     fov = float(rng.choice([20, 70, 90, 130, 130, 170, 175]))
     kind = rng.choice(['plans', 'plans', 'plans', 'large', 'box', 'column'])
+    if forced and kind in ('box', 'column'):
+        kind = 'plans'
     n_envs = int(rng.randint(1, 4 if kind == 'large' or n_agents > 8 else 12))
     np.random.seed(seed)
     if kind in ('box', 'column'):
         geometries = n_envs*[getattr(toys, kind)()]
     else:
-        geometries = cubicasa.sample(n_envs, n_unique=16, seed=seed + 1, large=kind == 'large')
+        geometries = cubicasa.sample(n_envs, n_unique=16, seed=seed + 1, large=kind == 'large', oblique=oblique)
+        kind = kind + ('/o' if oblique else '')
     sc = scene.scenery(geometries, n_agents, device='cuda', random=np.random.RandomState(seed))
     c = core.Core(sc, res=res, fov=fov, fps=float(rng.choice([10, 10, 30, 3])))
     util.spawn(c, geometries, seed=seed)
@@ -38,8 +46,13 @@ def one(seed):
                 continue
             for _ in range(max(2, len(walls)//8)):
                 i, j = rng.choice(walls, 2, replace=False)
-                how = rng.randint(5)
-                if how == 0:   lines[i] = lines[j]                                   # coincident
+                how = rng.randint(6 if oblique else 5)
+                if how == 5:                                                         # swung about its middle
+                    mid, half = (lines[i, :2] + lines[i, 2:])/2, (lines[i, 2:] - lines[i, :2])/2
+                    th = float(rng.uniform(0, np.pi))
+                    half = torch.stack([np.cos(th)*half[0] - np.sin(th)*half[1], np.sin(th)*half[0] + np.cos(th)*half[1]])
+                    lines[i] = torch.cat([mid - half, mid + half])
+                elif how == 0:   lines[i] = lines[j]                                   # coincident
                 elif how == 1: lines[i] = lines[j][[2, 3, 0, 1]]                     # coincident, reversed
                 elif how == 2: lines[i, 2:] = lines[i, :2]                           # a point
                 elif how == 3: lines[i] = lines[j] + float(rng.choice([2e-5, 9e-5, 1.1e-4, 1e-3]))   # inside / outside the band
@@ -64,7 +77,7 @@ def one(seed):
         prog_ref, agents_ref = ref.physics()
         util.assert_physics_matches(c, p, prog_ref, agents_ref)
         util.assert_render_matches(c, r, ref.render())
-    return f'{kind:6s} envs {n_envs:2d} agents {n_agents:2d} rays {res:3d} fov {fov:5.1f}{mutated}'
+    return f'{kind:8s} envs {n_envs:2d} agents {n_agents:2d} rays {res:3d} fov {fov:5.1f}{mutated}'
 
 
 def one_fused(seed):
