@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 12
+#define MS_ABI_VERSION 13
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -266,6 +266,30 @@ int ms_step_physics(const MsScenery* scenery, const MsAgents* agents, const MsMo
  * draw (rewrites the agent rows of lines_vals) -> raycast -> shade, one fused launch. */
 int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* out,
               const MsConfig* config, void* hip_stream);
+
+/* What the reference's Deathmatch env does between one frame and the next - `_reset` + `_shoot` + the `health` observation,
+ * megastep/demo/envs/deathmatch.py:46-88: some twenty tensor ops on (N, A) tensors - as one element-wise launch behind
+ * ms_render, whose obs_centre it reads.  Per agent-row i = n A + a, in this order:
+ *   revive   where `dead` is set (the mask this step's physics launch respawned by): health = 1, damage = 0      (:46-52)
+ *   shoot    hits = distinct agents in centre[i][0..1] (ids outside 0 .. A-1 are nobody); wounds = agents b of the env with
+ *            a in centre[b][0..1]; outside = position below -clearance or above upper[n] (= extent + clearance) in x or y;
+ *            damage += hit_damage * hits;  health += -hit_damage * (wounds + outside) - tick_damage               (:54-72)
+ *   report   reset_out = the incoming `dead`; reward = hits; health_obs = health; dead = health <= 0 - the next step's
+ *            respawn mask; matchings[i][b] = b in centre[i][0..1]   (each optional: NULL = skipped, except `dead`) */
+typedef struct MsDeathmatch {
+    const int*      centre;        /* (N, A, 2): MsRender.obs_centre of this frame                              */
+    const float*    positions;     /* (N, A, 2): MsAgents.positions                                             */
+    const float*    upper;         /* (N, 2): the floorplan's extent (masks.shape * res) + clearance            */
+    float           clearance, hit_damage, tick_damage;       /* the reference's: 1, .05, .001                 */
+    float*          health;        /* (N, A) in / out                                                           */
+    float*          damage;        /* (N, A) in / out                                                           */
+    unsigned char*  dead;          /* (N, A) in: revived at this step's start; out: dead now                    */
+    unsigned char*  reset_out;     /* (N, A) out, optional                                                      */
+    float*          reward;        /* (N, A) out, optional                                                      */
+    float*          health_obs;    /* (N, A) out, optional                                                      */
+    unsigned char*  matchings;     /* (N, A, A) out, optional                                                   */
+} MsDeathmatch;
+int ms_deathmatch_shoot(int n_envs, int n_agents, const MsDeathmatch* dm, void* hip_stream);
 
 /* Builds the wall grid (MsScenery.wg_*): per level of cells two launches with a prefix sum by the caller in between.
  *   ms_wallgrid_scan  for every cell of every env listed in `reps` (the representatives, MsScenery.env_geom; n_reps of

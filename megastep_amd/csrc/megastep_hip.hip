@@ -4,7 +4,7 @@
 // launches); the kernels are in kernels/*.h, included below inside the anonymous namespace - math.h (scalar helpers shared
 // with the ms_host_* test hooks), physics.h, lighting.h, render.h, bake.h, wallgrid.h.
 //
-// Eleven kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
+// Twelve kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
 //
 //   physics_kernel<MOVE, EXTRA, PACK>   one wavefront per env (PACK = 1: per few consecutive envs, side by side - large
 //                   worlds of few agents per env): lane = agent for the state, the reach and the agent-agent
@@ -37,6 +37,9 @@
 //   wallgrid_scan_kernel, wallgrid_fill_kernel   the wall grid: per cell of a floorplan which walls can matter to a ray
 //                   from the cell (one wall hiding another from the whole cell, exactly) and which an agent in it can
 //                   touch; and the lists made of that.   (replaces the all-lines loops kernels.cu:203-205,352-377)
+//   deathmatch_kernel   the Deathmatch env's game logic between frames (revive, crosshairs, hits and wounds, health, damage,
+//                   reward, next step's dead) as one element-wise launch behind ms_render.
+//                                                            (reference: demo/envs/deathmatch.py:46-88)
 //
 // Numerics contract: IEEE binary32 evaluated as the reference source is written -- compiled with
 // -ffp-contract=off, correctly rounded divide/sqrt, no fast-math -- so that collision masks and hit
@@ -117,6 +120,7 @@ struct Probe {
 #include "kernels/render.h"
 #include "kernels/bake.h"
 #include "kernels/wallgrid.h"
+#include "kernels/envlogic.h"
 
 // ------------------------------------------------------------------------------------------------
 // launch geometry (host): what ms_render / ms_step_physics decide before a launch - also behind ms_host_render_plan /
@@ -585,6 +589,17 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     // inside the near plane), so there is nothing to light.
     if (!grid && sc->n_agents > 1 && colour)
         hipLaunchKernelGGL(dynlight_kernel, dim3((int)n_fans), dim3(WG), 0, (hipStream_t)stream, scn, *ag, *out, R);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+int ms_deathmatch_shoot(int n_envs, int n_agents, const MsDeathmatch* dm, void* stream) {
+    if (n_envs <= 0 || n_agents <= 0 || !dm || !dm->centre || !dm->positions || !dm->upper || !dm->health || !dm->damage || !dm->dead ||
+        ((uintptr_t)dm->centre % 8) || ((uintptr_t)dm->positions % 8) || ((uintptr_t)dm->upper % 8) ||
+        !(dm->clearance == dm->clearance) || !(dm->hit_damage == dm->hit_damage) || !(dm->tick_damage == dm->tick_damage)) return MS_EINVAL;
+    const long long rows = (long long)n_envs*n_agents, blocks = (rows + WG - 1)/WG;
+    if (blocks > 0x7fffffffLL) return MS_EUNSUPPORTED;
+    hipLaunchKernelGGL(deathmatch_kernel, dim3((unsigned)blocks), dim3(WG), 0, (hipStream_t)stream, *dm, n_envs, n_agents);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }

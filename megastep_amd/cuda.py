@@ -817,6 +817,34 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
     return Physics(progress) if out is None else out
 
 
+def deathmatch_shoot(centre, positions, upper, health, damage, dead, clearance=1., hit_damage=.05, tick_damage=.001,
+                     out=None, matchings=False):
+    """The Deathmatch env's game logic between one frame and the next as ONE launch (include/megastep_hip.h, MsDeathmatch;
+    reference: demo/envs/deathmatch.py:46-88 - ``_reset`` + ``_shoot`` + the ``health`` observation, some twenty tensor ops).
+
+    ``centre`` (N, A, 2) int32: :func:`render`'s ``obs_centre`` of this frame; ``positions`` (N, A, 2); ``upper`` (N, 2): the
+    floorplans' extents + clearance; ``health``, ``damage`` (N, A) float32 and ``dead`` (N, A) bool, all updated IN PLACE:
+    agents marked in ``dead`` (the mask this step's physics launch respawned by) start from health 1 / damage 0, then
+    everyone takes this frame's hits, wounds and strays, and ``dead`` becomes ``health <= 0`` - the next step's mask.
+    Returns ``(reset, reward, health_obs[, matchings])``: the incoming ``dead``, the hits dealt, a copy of the new health -
+    fresh tensors, or the ones of an earlier call passed as ``out``."""
+    n, a = health.shape
+    _check(centre, 'centre', torch.int32, 3); _check(positions, 'positions', torch.float32, 3); _check(upper, 'upper', torch.float32, 2)
+    _check(health, 'health', torch.float32, 2); _check(damage, 'damage', torch.float32, 2); _check(dead, 'dead', torch.bool, 2)
+    if centre.shape != (n, a, 2) or positions.shape != (n, a, 2) or upper.shape != (n, 2) or damage.shape != (n, a) or dead.shape != (n, a):
+        raise RuntimeError('deathmatch_shoot: centre (N, A, 2), positions (N, A, 2), upper (N, 2), health / damage / dead (N, A)')
+    dev = _require_gpu(centre, positions, upper, health, damage, dead)
+    if out is None:
+        out = (torch.empty_like(dead), torch.empty_like(health), torch.empty_like(health)) + \
+              ((torch.empty((n, a, a), dtype=torch.bool, device=dev),) if matchings else ())
+    dm = _lib.MsDeathmatch(centre.data_ptr(), positions.data_ptr(), upper.data_ptr(), float(clearance), float(hit_damage), float(tick_damage),
+                           health.data_ptr(), damage.data_ptr(), dead.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                           out[3].data_ptr() if len(out) > 3 else None)
+    with _on(dev):
+        _lib.check(_lib.lib().ms_deathmatch_shoot(n, a, C.byref(dm), _stream(dev)))
+    return out
+
+
 FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
 #: MEGASTEP_CHECK_GRID=1: every render / physics call first makes sure the static walls are still the ones the wall grid
 #: was built from (a reduction over the lines and a host sync per call - for debugging and the test suite, off by default)

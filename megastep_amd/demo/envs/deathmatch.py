@@ -40,9 +40,12 @@ def crosshair_matrix(line_indices, n_model, n_agents, subsample):
 
 class Deathmatch:
 
-    def __init__(self, n_envs, n_agents, *args, device='cuda', geometries=None, **kwargs):
+    def __init__(self, n_envs, n_agents, *args, device='cuda', geometries=None, fused=None, **kwargs):
         """``n_envs`` counts agent-rows, as the reference's does; without ``geometries`` it samples ``n_envs//4``
-        floorplans (deathmatch.py:24)."""
+        floorplans (deathmatch.py:24). ``fused`` (default: on a GPU): the game logic between frames - revive, crosshairs,
+        hits and wounds, health, damage, reward, who is dead - runs as ONE launch behind the render kernel
+        (:func:`megastep_amd.cuda.deathmatch_shoot`) instead of some twenty tensor ops; ``False`` keeps the tensor ops,
+        which are the same arithmetic and what the CPU-side tests pin against the reference's own methods."""
         if geometries is None:
             geometries = cubicasa.sample(max(n_envs//4, 1))
         self.core = core.Core(scene.scenery(geometries, n_agents, device=device), *args, res=4*128, fov=70, **kwargs)
@@ -64,7 +67,25 @@ class Deathmatch:
         self._everyone = torch.arange(c.n_agents, device=c.device)
         self._health = c.agent_full(np.nan)                  # NaN until the first reset
         self._damage = c.agent_full(np.nan)
-        self.matchings = torch.zeros((c.n_envs, c.n_agents, c.n_agents), dtype=torch.bool, device=c.device)
+        self._matchings = torch.zeros((c.n_envs, c.n_agents, c.n_agents), dtype=torch.bool, device=c.device)
+        self._fused = c.device.type == 'cuda' if fused is None else bool(fused)
+        # (fused) who is dead as of the last frame - written by the kernel, read by the next step's physics launch as its
+        # respawn mask; the floorplans' extents + clearance as the kernel wants them, (n_floorplans, 2); the last frame's crosshairs
+        self._dead = c.agent_full(False)
+        self._upper_rows = (self._bounds + CLEARANCE).float().contiguous()
+        self._centre = None
+
+    @property
+    def matchings(self):
+        """(n_floorplans, n_agents, n_agents) bools, [f, a, b] = agent a's two central observation pixels show agent b - of the
+        last frame (worked out from the render kernel's crosshair ids when somebody asks, on the fused path)."""
+        if self._centre is not None:
+            self._matchings, self._centre = (self._centre[..., None] == self._everyone).any(-2), None
+        return self._matchings
+
+    @matchings.setter
+    def matchings(self, value):
+        self._matchings, self._centre = value, None
 
     # -- pieces of a step ---------------------------------------------------------------------------------------
 
@@ -94,6 +115,19 @@ class Deathmatch:
         self._health -= HIT_DAMAGE*(taken + strayed) + TICK_DAMAGE
         return dealt.reshape(-1)
 
+    def _look_fused(self):
+        """Render, then everything `_revive` + `_exchange_fire` + the health observation do, as one launch: the agents marked in
+        ``_dead`` (whom this step's physics launch has respawned) start from full health, the frame's fire is settled, and
+        ``_dead`` becomes who is dead now. Returns (obs, reward, reset) per agent-row."""
+        c = self.core
+        frame = modules.render(c, observers=(self._rgb, self._depth), fields=(), centre=True)
+        from ... import cuda
+        reset, reward, health = cuda.deathmatch_shoot(frame.centre, c.agents.positions, self._upper_rows, self._health, self._damage,
+                                                      self._dead, CLEARANCE, HIT_DAMAGE, TICK_DAMAGE)
+        self._centre = frame.centre
+        obs = arrdict.arrdict(rgb=self._rgb(frame), d=self._depth(frame), imu=self._imu(), health=health.unsqueeze(-1))
+        return per_agent(obs), reward.reshape(-1), reset.reshape(-1)
+
     def _look(self):
         # pooled RGB-D and who sits in whose crosshair, straight from the render kernel: no per-ray output is needed
         frame = modules.render(self.core, observers=(self._rgb, self._depth), fields=(), centre=True)
@@ -106,12 +140,23 @@ class Deathmatch:
 
     @torch.no_grad()
     def reset(self):
+        if self._fused:
+            self._dead.fill_(True)
+            self._respawn(self._dead)                        # (the kernel does the reviving: `_dead` is its list)
+            obs, reward, reset = self._look_fused()
+            return arrdict.arrdict(obs=obs, reward=reward, reset=reset)
         reset = self._revive(self.core.agent_full(True))
         obs, reward = self._look()
         return arrdict.arrdict(obs=obs, reward=reward, reset=reset)
 
     @torch.no_grad()
     def step(self, decision):
+        if self._fused:
+            # four launches: the spawn draw, physics (respawn of last frame's dead + movement + step + IMU), render (pooled
+            # RGB-D + crosshair ids), the game logic (revive, fire, health, reward, who is dead now)
+            self._mover(per_floorplan(decision, self.core.n_agents), respawn=self._respawn.draw(self._dead), imu=self._imu)
+            obs, reward, reset = self._look_fused()
+            return arrdict.arrdict(obs=obs, reward=reward, reset=reset)
         dead = self._health <= 0                             # the dead come back before anyone moves:
         reset = self._revive(dead, respawn=False)            # respawn, movement, physics and the IMU reading are one launch
         self._mover(per_floorplan(decision, self.core.n_agents), respawn=self._respawn.draw(dead), imu=self._imu)

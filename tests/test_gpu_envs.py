@@ -63,6 +63,88 @@ def test_deathmatch_env():
     assert env.state(0).matchings.shape == (4, 4)
 
 
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_deathmatch_logic_kernel_equals_the_references_observe_and_shoot(tag):
+    """ms_deathmatch_shoot (the Deathmatch env's game logic as one launch) on the inputs the REFERENCE's `_observe` + `_shoot`
+    were run on (tests/golden/make_golden.py: deathmatch.py:54-80 called unbound on seeded tensors): the same matchings, hits
+    (the reward), health, damage and health observation; then the `_reset` half (deathmatch.py:46-52): agents marked dead start
+    the frame from health 1 / damage 0, and `dead` comes back as health <= 0."""
+    import os
+    from megastep_amd import cuda
+    from megastep_amd.demo.envs import deathmatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_host.npz'))
+    F, A, res, sub, M = (int(v) for v in g[f'dm_{tag}_shape'])
+    idx = torch.as_tensor(g[f'dm_{tag}_indices']).cuda()
+    W = res//sub
+    mid = idx[:, :, 0, [(W//2 - 1)*sub + sub//2, (W//2)*sub + sub//2]]       # what render_kernel's obs_centre holds
+    centre = torch.where((mid >= 0) & (mid < A*M), torch.div(mid, M, rounding_mode='floor'), torch.full_like(mid, -1)).int().contiguous()
+    positions = torch.as_tensor(g[f'dm_{tag}_positions']).cuda().contiguous()
+    upper = (torch.as_tensor(g[f'dm_{tag}_bounds']).cuda() + deathmatch.CLEARANCE).float().contiguous()
+    health, damage = torch.as_tensor(g[f'dm_{tag}_health0'].copy()).cuda(), torch.as_tensor(g[f'dm_{tag}_damage0'].copy()).cuda()
+    dead = torch.zeros((F, A), dtype=torch.bool, device='cuda')
+    reset, reward, health_obs, matchings = cuda.deathmatch_shoot(centre, positions, upper, health, damage, dead, matchings=True)
+    np.testing.assert_array_equal(matchings.cpu().numpy(), g[f'dm_{tag}_matchings'])
+    np.testing.assert_array_equal(reward.reshape(-1).cpu().numpy(), g[f'dm_{tag}_hits'])
+    np.testing.assert_allclose(health.cpu().numpy(), g[f'dm_{tag}_health'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(damage.cpu().numpy(), g[f'dm_{tag}_damage'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(health_obs.unsqueeze(-1).cpu().numpy(), g[f'dm_{tag}_obs_health'], rtol=0, atol=1e-6)
+    # bit for bit the reference's statements in binary32 (deathmatch.py:64,70)
+    m = torch.as_tensor(g[f'dm_{tag}_matchings']).cuda()
+    pos = positions
+    outside = (pos < -deathmatch.CLEARANCE).any(-1) | (pos > upper[:, None]).any(-1)
+    want_h = torch.as_tensor(g[f'dm_{tag}_health0'].copy()).cuda()
+    want_h += -.05*(m.sum(1).float() + outside) - .001
+    assert torch.equal(health, want_h) and not reset.any() and torch.equal(dead, health <= 0)
+    # the revive half: everybody flagged starts from (1, 0) whatever they held
+    health2, damage2 = torch.full_like(health, -3.), torch.full_like(damage, 7.)
+    flagged = torch.rand((F, A), device='cuda') < .5
+    dead2 = flagged.clone()
+    reset2, reward2, obs2 = cuda.deathmatch_shoot(centre, positions, upper, health2, damage2, dead2)
+    base_h = torch.where(flagged, torch.ones_like(health), torch.full_like(health, -3.))
+    base_d = torch.where(flagged, torch.zeros_like(damage), torch.full_like(damage, 7.))
+    assert torch.equal(reset2, flagged) and torch.equal(reward2, reward)
+    assert torch.equal(health2, base_h + (-.05*(m.sum(1).float() + outside) - .001)) and torch.equal(damage2, base_d + .05*m.sum(2).float())
+    assert torch.equal(dead2, health2 <= 0) and torch.equal(obs2, health2)
+
+
+def test_deathmatch_steps_the_same_with_and_without_the_logic_kernel():
+    """Two Deathmatch envs from the same seeds, one settling each frame with the tensor ops, one with the single launch: the same
+    observations, rewards, resets and agent state step after step - through deaths (health pushed down by hand so that agents
+    die and respawn inside the physics launch) - and the same matchings when asked."""
+    from megastep_amd.demo import Deathmatch
+    from megastep_amd import arrdict, cubicasa
+    gs = cubicasa.sample(6, n_unique=16)
+
+    def rollout(fused):
+        torch.manual_seed(3); np.random.seed(3)
+        env = Deathmatch(24, 4, geometries=gs, fused=fused)
+        assert env._fused == fused
+        torch.manual_seed(4)
+        frames = [env.reset()]
+        for t in range(25):
+            if t in (5, 11, 12):
+                env._health[t % 6, (t + 1) % 4] = -.5          # somebody dies: back at full health after the next step's respawn
+                if fused:
+                    env._dead[t % 6, (t + 1) % 4] = True       # (the kernel's list is what the fused step reads)
+            acts = torch.randint(0, 7, (24, 1), device='cuda', generator=torch.Generator('cuda').manual_seed(100 + t))
+            frames.append(env.step(arrdict.arrdict(actions=acts)))
+            frames[-1]['matchings'] = env.matchings.clone()
+            frames[-1]['state'] = torch.cat([env.core.agents.positions.reshape(-1), env._health.reshape(-1), env._damage.reshape(-1)])
+        return frames
+
+    a, b = rollout(False), rollout(True)
+    resets = 0
+    for t, (fa, fb) in enumerate(zip(a, b)):
+        assert torch.equal(fa.reset, fb.reset) and torch.equal(fa.reward, fb.reward), t
+        for k in ('rgb', 'd', 'imu', 'health'):
+            torch.testing.assert_close(fa.obs[k], fb.obs[k], rtol=0, atol=1e-6, msg=f'{k} at step {t}')
+        if t:
+            assert torch.equal(fa.matchings, fb.matchings)
+            torch.testing.assert_close(fa.state, fb.state, rtol=0, atol=1e-6)
+            resets += int(fa.reset.sum())
+    assert a[0].reset.all() and resets >= 3
+
+
 def test_observation_modules_against_a_torch_restatement():
     """Depth/RGB on a real render equal their definition (modules.py:170-184,211-224) applied to the raw outputs."""
     from megastep_amd import core, cubicasa, modules, scene, cuda
