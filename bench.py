@@ -398,9 +398,20 @@ class _Gpu:
     def event(self):
         return torch.cuda.Event(enable_timing=True)
 
-    def hot_path(self, scenery, fields=None):
+    def hot_path(self, scenery, fields=None, one_launch=False):
         from megastep_amd import cuda
         state = {}
+
+        def fused(view, ev=None):
+            # ms_step_render: the step as ONE launch (single-agent worlds of up to 64 rays) - the "render" events then
+            # bracket the whole step
+            if ev is not None:
+                ev[1].record()
+            state['pr'] = cuda.step_render(scenery, view, fields=fields, out=state.get('pr'))
+            if ev is not None:
+                ev[2].record()
+        if one_launch:
+            return fused
 
         def step(view, ev=None):
             state['p'] = cuda.physics(scenery, view, out=state.get('p'))
@@ -437,7 +448,7 @@ class _Stub:
                 return 1e3*(other.t - self.t)
         return E()
 
-    def hot_path(self, scenery, fields=None):
+    def hot_path(self, scenery, fields=None, one_launch=False):
         def step(view, ev=None):
             view.positions.add_(view.velocity, alpha=.1)
             if ev is not None:
@@ -472,7 +483,8 @@ def launch_ranks(args, argv):
     raise SystemExit(subprocess.call(cmd, env=env, cwd=ROOT))
 
 
-def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields=None, graph=True, eager_floor=None, graph_floor=.25):
+def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields=None, graph=True, eager_floor=None, graph_floor=.25,
+                  one_launch=False):
     """The timing protocol (module docstring) on one world: a dry run of the env loop records the W + K steps' inputs;
     the K timed steps are then launched one by one with HIP events around every step and every render (`eager`) and, with
     `graph`, replayed as one HIP graph - timed regions repeated until they add up to the floors. Returns the raw numbers."""
@@ -485,7 +497,7 @@ def time_hot_path(dev, core, steps, warmup, barrier=lambda: None, rank=0, fields
     mover = modules.MomentumMovement(core)
     actions = torch.randint(0, 7, (total, N, A), device=device)
     scenery, agents = core.scenery, core.agents
-    hot = dev.hot_path(scenery, fields)
+    hot = dev.hot_path(scenery, fields, one_launch)
 
     # The velocities the hot path is handed at each step are produced by the (untimed) torch movement glue ahead of
     # time: a dry run of the env loop from the spawn points, W + K steps, recording what ms_physics is given - the
@@ -597,10 +609,10 @@ def grids(core):
     return out
 
 
-def shape_entry(dev, core, steps, warmup, fields=None, note=None):
+def shape_entry(dev, core, steps, warmup, fields=None, note=None, one_launch=False):
     """One line of the `shapes` block: the hot path on another of BASELINE.json's shapes, timed like the headline (same
     protocol, shorter floors), with that shape's own algorithmic bytes against the HBM peak."""
-    m = time_hot_path(dev, core, steps, warmup, fields=fields, eager_floor=.05, graph_floor=.12)
+    m = time_hot_path(dev, core, steps, warmup, fields=fields, eager_floor=.05, graph_floor=.12, one_launch=one_launch)
     s = float(np.median(m['runs']))
     render_ms = float(np.median(m['render_each']))
     rb, pb = algorithmic_bytes(core, fields)
@@ -618,6 +630,13 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None):
          **measured_block(core, fields, render_ms, 1e3*s/steps, large=sc.lines.vals.shape[0]/core.n_envs > 600),
          'ray_groups_per_wave': ray_groups(dev, core), **grids(core),
          **({'world_build_seconds': core.build_seconds} if hasattr(core, 'build_seconds') else {})}
+    if one_launch:
+        from megastep_amd import _lib
+        e['launches_per_step'] = 1 if _lib.lib().ms_debug_last_step_fused() else 2
+        e['step'] = 'ms_step_render (physics + render of an env as one wave: one launch a step); render_launch_ms is the whole step'
+        # (the one launch does both halves' work: its algorithmic bytes are the step's)
+        e['roofline_frac'] = (rb + pb)/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS
+        e.pop('traffic', None); e.pop('frac_measured', None); e.pop('step_traffic', None); e.pop('step_measured_GBps', None)
     if note:
         e['note'] = note
     return e
@@ -644,6 +663,10 @@ def other_shapes(dev, steps=20, warmup=5):
     out['c2_rgbd'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 2 (Explorer shape, one floorplan per env) with all five planes')
     out['c2_depth_only'] = shape_entry(dev, c, steps, warmup, fields=('distances',),
                                        note="BASELINE config 2 as stated: depth-only - render_kernel<2,1,1,0,1>, no shading pass")
+    out['c2_rgbd_one_launch'] = shape_entry(dev, c, steps, warmup, one_launch=True,
+                                            note='BASELINE config 2 with all five planes, the step as ONE launch (ms_step_render)')
+    out['c2_depth_only_one_launch'] = shape_entry(dev, c, steps, warmup, fields=('distances',), one_launch=True,
+                                                  note='BASELINE config 2 as stated (depth-only), the step as ONE launch: render_kernel<2,1,1,0,1,1>')
     del c
     torch.cuda.empty_cache()
     c = world('C3', 4096, 4, 128, 70., n_unique=plan_count(4096, 4))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 13
+#define MS_ABI_VERSION 14
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -266,6 +266,15 @@ int ms_step_physics(const MsScenery* scenery, const MsAgents* agents, const MsMo
  * draw (rewrites the agent rows of lines_vals) -> raycast -> shade, one fused launch. */
 int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* out,
               const MsConfig* config, void* hip_stream);
+
+/* One step of the hot path - ms_physics then ms_render (the reference's every env.step(): wrappers.cpp:69 + :82) - in one
+ * call, and where the shapes allow it in ONE LAUNCH: with one agent per env and at most 64 rays (BASELINE config 2: Explorer's
+ * shape) the agent is a single wavefront, which runs its env's physics step (kernels.cu:179-230) and renders from the pose it
+ * ends on (kernels.cu:297-475); nothing crosses waves, so there is nothing to order between two launches.  Every other shape
+ * (several agents per env, more than 64 rays, a wall grid that serves one half of the step only) is ms_physics followed by
+ * ms_render, as if the caller had made the two calls.  Same results as the two calls, bit for bit, either way. */
+int ms_step_render(const MsScenery* scenery, const MsAgents* agents, float* progress, const MsRender* out,
+                   const MsConfig* config, void* hip_stream);
 
 /* What the reference's Deathmatch env does between one frame and the next - `_reset` + `_shoot` + the `health` observation,
  * megastep/demo/envs/deathmatch.py:46-88: some twenty tensor ops on (N, A) tensors - as one element-wise launch behind

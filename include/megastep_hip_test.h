@@ -29,6 +29,8 @@ int ms_debug_physics_pack(int envs);
  * account, which a caller re-deriving the rule cannot know; 0 before the thread's first call.  bench.py labels its
  * lines with it. */
 int ms_debug_last_render_groups(void);
+/* Did the calling thread's last ms_step_render go out as one launch (1) or as ms_physics + ms_render (0)? */
+int ms_debug_last_step_fused(void);
 /* The launch geometry ms_render / ms_step_physics decide on the host, and the render kernel's own block -> rays mapping
  * (render_block), for tests that walk whole launches on the CPU.  `slots`: the machine's wave slots for the render kernel (CUs x
  * 4 SIMDs x 6 waves; 6144 on MI355X); pinned_groups / tail_rounds / tail_envs as the ms_debug_* hooks (0 / < 0 / < 0: the rules).

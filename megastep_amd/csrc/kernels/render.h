@@ -129,6 +129,15 @@ struct RenderConsts {
     int telemetry;                 // ms_debug_pair_telemetry: pair / window counts into workspace[3], [4]
     int ws_headings;               // where in MsRender.workspace the (sin, cos) pairs of render_prep_kernel start, in 4-byte words
 };
+// ... and what the STEP = 1 instantiations (ms_step_render: physics and render of a single-agent env as one wave's work) take on
+// top: as a type of its own, so that the kernel-argument segment of every other instantiation is byte for byte what it was
+// (they sit at 80 registers and 150 spilled scalars: four more bytes of arguments once cost the widest of them 5 %).
+struct RenderConstsStep : RenderConsts {
+    float* progress;               // (N, 1): MsPhysics' output
+    float fps;
+    const unsigned* wg_cells_physics;   // the wall grid's cell headers as ms_step_physics would be given them (ms_render's copy of the scenery
+                                        // drops them when the call's near plane / field of view is outside what the vis lists were built for)
+};
 // Which of MsRender's optional outputs are there, as bits - for the COLOURLESS instantiations, which ask a scalar register the
 // wave has had since its first instruction whether an output is wanted and only fetch a pointer from the kernel-argument segment
 // when it is: asked of the pointers themselves every check was a scalar load and a wait of its own, per group of rays, for
@@ -359,7 +368,11 @@ __host__ __device__ inline void ray_interval(float xa, float ya, float xb, float
 // interval of all of them, pass 2 deals the (line, ray) pairs to the lanes whichever group the ray is in, and only the
 // per-ray ends of the kernel - ray set-up, resolution, shading, stores - run group after group.  (ms_render picks NG from
 // the resolution: 1 up to 64 rays - the headline's instantiation is what it was -, 2 up to 128, 4 beyond.)
-template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
+// STEP = 1 (ms_step_render; one agent per env, up to 64 rays: the agent IS one wave): the wave runs its env's physics step first
+// - kernels.cu:179-230 for one agent: reach, the near list of its cell (or every wall), the exact test, the integration epilogue -
+// and renders from the pose it ends on.  Nothing crosses waves (no other wave reads this agent), so the step is ONE launch: the
+// physics launch it replaces is 6 of C2's 17 us, 4 of them what launching any kernel behind another costs.
+template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1, int STEP = 0>
 // Occupancy knobs of the render kernel (A/B builds; the defaults are the product): waves per SIMD the register allocation
 // is held to, chunks of rows in flight, capacity of a wave's list of visible lines (which sizes its LDS block)
 #ifndef MS_WAVES
@@ -395,7 +408,9 @@ template <int IMPL, int RW, int OBS, int SHADE = 1, int NG = 1>
 #endif
 __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 ? MS_WAVES_WIDE : MS_WAVES, NG > 1 ? MS_WAVES_WIDE : MS_WAVES))) void render_kernel(
         const MsScenery sc, const MsAgents ag, const MsRender out,
-        const float agent_radius, const float half_screen, const int R, const int n_fans, const RenderConsts rc) {
+        const float agent_radius, const float half_screen, const int R, const int n_fans,
+        const std::conditional_t<STEP == 1, RenderConstsStep, RenderConsts> rc) {
+    static_assert(STEP == 0 || (IMPL == 2 && RW == 1 && NG == 1), "the fused step: the product raycast, one wave per workgroup, one group of rays");
     // Per-wave LDS, one raw block so that the lighting at the end can reuse what the raycast is done with:
     //      0 cand   (64 x 16 B)  the chunk's 64 lines               | lighting: (wall, light) pair list, 2 KiB
     //   1024 ray    (64 x 16 B)  per ray: rx, ry, near              |
@@ -492,7 +507,66 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         ag_p = reinterpret_cast<const float2*>(ag.positions)[n*A + lane];
     }
     };
-    load_agents();
+    if constexpr (STEP == 1) {
+        // ---- the env's physics step (physics_kernel for its one agent, kernels.cu:179-230), every lane with the agent's state,
+        // lane = wall for the tests.  Same functions, same operations in the same order as physics_kernel: the same bits.
+        const float2 p_ = reinterpret_cast<const float2*>(ag.positions)[n], v_ = reinterpret_cast<const float2*>(ag.velocity)[n];
+        const float w_ = ag.angvelocity[n], ang_ = ag.angles[n];
+        const P2 p0 = p2(p_.x, p_.y);
+        const P2 v0 = p2(v_.x, v_.y)/rc.fps;
+        const float reach = wall_reach(p0, v0, agent_radius);
+        const float reach2 = reach_squared(reach);
+        const float my_reach = (reach == reach) ? reach : INFINITY;
+        const float4 tk = make_float4(p0.x, p0.y, v0.x, v0.y);
+        // the walls it can touch: the near list of its cell (the tier its reach asks for), or - outside the grid, faster than
+        // the lists cover, crawling (wall_reach), no grid - every wall of the env
+        bool listed_p = false;
+        unsigned near_first = 0u;
+        int n_src = max(L - AF, 0);
+        if (rc.wg_cells_physics) {                                          // (uniform)
+            const float4 geom = wg_geom_n;
+            const float inv_cell = __builtin_amdgcn_rcpf(sc.wg_cell);
+            const float fx = floorf((p0.x - geom.x)*inv_cell), fy = floorf((p0.y - geom.y)*inv_cell);
+            const bool inside = (fx >= 0.f) & (fx < geom.z) & (fy >= 0.f) & (fy < geom.w);       // (NaNs: outside)
+            const int cell_id = __builtin_amdgcn_readfirstlane(wg_start_n + (inside ? (int)fy*(int)geom.z + (int)fx : 0));
+            const uint4 hdr = reinterpret_cast<const uint4*>(rc.wg_cells_physics)[cell_id];
+            listed_p = __builtin_amdgcn_readfirstlane((inside & (my_reach <= sc.wg_reach)) ? 1 : 0) != 0;
+            if (listed_p) {
+                near_first = (unsigned)__builtin_amdgcn_readfirstlane((int)hdr.z);
+                n_src = __builtin_amdgcn_readfirstlane((int)((my_reach <= sc.wg_reach_lo) ? (hdr.w & 0xffffu) : (hdr.w >> 16)));
+            }
+        }
+        unsigned xb = f_bits(1.f);
+        for (int k0 = 0; k0 < n_src; k0 += WAVE) {
+            float4 u;
+            if (listed_p) u = reinterpret_cast<const float4*>(sc.wg_near_rows)[near_first + (unsigned)min(k0 + lane, n_src - 1)];
+            else u = rows.chunk(lane, AF + k0);
+            if ((k0 + lane < n_src) && !wall_beyond(tk, u, reach2)) {
+                const float xw = collision_cs(p2(tk.x, tk.y), p2(tk.z, tk.w), p2(u.x, u.y), p2(u.z, u.w), agent_radius);
+                if (xw < 1.f) xb = min(xb, f_bits(xw));                      // (values in [+0, 1]: the bits order like the floats, as physics_kernel's atomicMin has it)
+            }
+        }
+        #pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) xb = min(xb, (unsigned)__shfl_xor((int)xb, o, WAVE));
+        const float x = bits_f(xb);
+        // the epilogue, kernels.cu:224-227
+        float2 p_new = make_float2(p_.x + x*v_.x/rc.fps, p_.y + x*v_.y/rc.fps);
+        const float turned = normalize_degrees(ang_ + x*w_/rc.fps);
+        const float2 hsc = sincospi_called(turned/180.f);
+        if (lane == 0) {
+            reinterpret_cast<float2*>(ag.positions)[n] = p_new;
+            ag.angles[n] = turned;
+            if (ag.headings) reinterpret_cast<float4*>(ag.headings)[n] = make_float4(turned, hsc.x, hsc.y, 0.f);
+            if (x < 1) {
+                reinterpret_cast<float2*>(ag.velocity)[n] = make_float2(0.f, 0.f);
+                ag.angvelocity[n] = 0.f;
+            }
+            rc.progress[n] = x;
+        }
+        ag_s = hsc.x; ag_c = hsc.y; ag_p = p_new;                            // the pose the rays are cast from
+    } else {
+        load_agents();
+    }
     constexpr int AHEAD = MS_AHEAD;              // chunks of lines in flight (IMPL 2)
 
     // An agent's model line in world coordinates (draw_kernel, kernels.cu:297-318), from the cached heading where

@@ -72,6 +72,7 @@ thread_local int g_ray_groups = 0;          // ms_debug_ray_groups: 0 = ms_rende
 thread_local int g_physics_pack = 0;        // ms_debug_physics_pack: 0 = ms_step_physics picks the envs a physics wave takes side by side, k >= 1 = k
 thread_local float g_tail_rounds = -1.f;    // ms_debug_ray_group_tail: < 0 = ms_render's own share of one-group waves at the end of a launch of wide ones
 thread_local int g_tail_envs = -1;          //   ... >= 0: that many envs exactly
+thread_local int g_last_step_fused = 0;     // ms_debug_last_step_fused: did this thread's last ms_step_render go out as one launch?
 thread_local int g_last_render_groups = 0;  // ms_debug_last_render_groups: the NG this thread's last ms_render launched
 
 // -DMS_PROBE=1 (`make probe`, tools/probe_waves.py): every wave of physics_kernel and render_kernel leaves a record of
@@ -474,7 +475,9 @@ int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const M
     return ms_step_physics(sc, ag, nullptr, nullptr, progress, cfg, stream);
 }
 
-int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {
+// ms_render, and - with `progress` - ms_step_render's fused launch (returns MS_EUNSUPPORTED, having launched nothing, where that
+// one does not apply: the caller then makes the two calls)
+static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream, float* progress) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !sc->textures_vals || !sc->textures_widths ||
         !sc->textures_starts || !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
     if ((out->seen_stamp != nullptr) != (out->seen_epoch != nullptr) || (out->seen_stamp != nullptr) != (out->seen_count != nullptr)) return MS_EINVAL;
@@ -535,7 +538,7 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     if (ag->headings && one_kernel) {
         if ((uintptr_t)ag->headings % 16) return MS_EINVAL;
         outn.workspace = nullptr;
-    } else {
+    } else if (!progress) {
         agn.headings = nullptr;
         if (out->workspace) {
             if ((uintptr_t)out->workspace % 8) return MS_EINVAL;
@@ -550,6 +553,21 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     if (colour && (!all_planes || pooled) && !(grid || sc->n_agents == 1)) return MS_EUNSUPPORTED;   // dynlight_kernel patches `screen` afterwards
     if (!all_planes && !pooled && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen) return MS_EINVAL;
     const bool obs = pooled || !all_planes;
+    if (progress) {
+        // The fused step (render_kernel<..., STEP = 1>): one agent per env and at most 64 rays - the agent is ONE wave, which
+        // runs the env's physics first and renders from the pose it ends on; the product raycast; and a wall grid that either
+        // serves both halves of the step or neither (ms_render goes without it when the call's near plane or field of view is
+        // outside what its vis lists were built for, ms_step_physics never does).
+        bool older = false;
+#if MS_AB_IMPLS
+        older = seq || pairs1;
+#endif
+        const bool physics_listed = sc->wg_cells != nullptr;
+        if (sc->n_agents != 1 || R > WAVE || ng != 1 || older || physics_listed != walls_listed ||
+            (physics_listed && (!sc->wg_near_rows || ((uintptr_t)sc->wg_near_rows % 16)))) return MS_EUNSUPPORTED;
+        agn = *ag;                                                       // (the wave works the heading out itself and leaves it in the cache, if there is one)
+        outn.workspace = nullptr;
+    }
     rc.x_clip = 0.5f*cfg->agent_radius/sqrtf(1.f + half_screen*half_screen);
     rc.c_b = 0.5f*(float)R/half_screen;
     rc.by_m = divisor_of((unsigned)sc->n_model);
@@ -579,7 +597,16 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     hipLaunchKernelGGL((render_kernel<2, RW, O, S, NG_>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
 #define MS_LAUNCH_RENDER_OS(NG_) \
     { if (!colour) MS_LAUNCH_RENDER_NG(1, 0, NG_); else if (obs) MS_LAUNCH_RENDER_NG(1, 1, NG_); else MS_LAUNCH_RENDER_NG(0, 1, NG_); }
-    if (ng == 4) MS_LAUNCH_RENDER_OS(4)
+    if (progress) {
+        RenderConstsStep rcs;
+        static_cast<RenderConsts&>(rcs) = rc;
+        rcs.progress = progress; rcs.fps = cfg->fps; rcs.wg_cells_physics = sc->wg_cells;
+#define MS_LAUNCH_STEP(O, S) \
+    hipLaunchKernelGGL((render_kernel<2, RW, O, S, 1, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rcs)
+        if (!colour) MS_LAUNCH_STEP(1, 0); else if (obs) MS_LAUNCH_STEP(1, 1); else MS_LAUNCH_STEP(0, 1);
+#undef MS_LAUNCH_STEP
+    }
+    else if (ng == 4) MS_LAUNCH_RENDER_OS(4)
     else if (ng == 2) MS_LAUNCH_RENDER_OS(2)
     else MS_LAUNCH_RENDER_OS(1)
 #undef MS_LAUNCH_RENDER_OS
@@ -603,6 +630,20 @@ int ms_deathmatch_shoot(int n_envs, int n_agents, const MsDeathmatch* dm, void* 
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
+
+int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream) {
+    return render_launch(sc, ag, out, cfg, stream, nullptr);
+}
+
+int ms_step_render(const MsScenery* sc, const MsAgents* ag, float* progress, const MsRender* out, const MsConfig* cfg, void* stream) {
+    if (!progress) return MS_EINVAL;
+    const int fused = render_launch(sc, ag, out, cfg, stream, progress);
+    g_last_step_fused = fused == MS_OK ? 1 : 0;
+    if (fused != MS_EUNSUPPORTED) return fused;
+    const int p = ms_step_physics(sc, ag, nullptr, nullptr, progress, cfg, stream);
+    return p != MS_OK ? p : render_launch(sc, ag, out, cfg, stream, nullptr);
+}
+int ms_debug_last_step_fused(void) { return g_last_step_fused; }
 
 int ms_bake(const MsScenery* sc, const MsConfig* cfg, void* stream) {
     (void)cfg;

@@ -859,7 +859,25 @@ def _check_grid(scenery, dev):
             scenery.check_wall_grid()
 
 
-def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None, seen=None, config=None):
+def step_render(scenery, agents, fields=None, pooled=None, out=None, seen=None, config=None):
+    """One step of the hot path - :func:`physics` then :func:`render`, what every ``env.step()`` of the reference runs
+    (wrappers.cpp:69 + :82) - as one call, and where the shapes allow it as ONE LAUNCH (include/megastep_hip.h,
+    ``ms_step_render``): with one agent per env and at most 64 rays (BASELINE config 2, the Explorer shape) an agent is a single
+    wavefront, which runs its env's physics step and renders from the pose it ends on. Any other shape is the two launches,
+    as if the two calls had been made. Same bits either way (tests/test_gpu_step_render.py).
+
+    Arguments as :func:`render`'s; ``out``: the ``(Physics, Render)`` of an earlier call, to write into. Returns ``(Physics, Render)``."""
+    physics_out, render_out = out if out is not None else (None, None)
+    progress = torch.empty_like(agents.angles) if physics_out is None else physics_out.progress
+    if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
+        raise RuntimeError('agents do not match the scenery')
+    r = render(scenery, agents, fields=fields, pooled=pooled, out=render_out, seen=seen, config=config, _progress=progress)
+    agents._cached = agents._use_cache
+    agents._epoch += 1
+    return (Physics(progress) if physics_out is None else physics_out), r
+
+
+def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None, seen=None, config=None, _progress=None):
     """Casts ``res`` rays per agent and shades them; also rewrites the agents' model lines in ``scenery.lines``
     (reference: wrappers.cpp:82, kernels.cu:452-475). Returns :class:`Render`.
 
@@ -913,8 +931,12 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
         if telemetry:
             _lib.lib().ms_debug_pair_telemetry(1)               # the kernels' pair counters too (tools/pair_stats.py)
         try:
-            _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
-                                            C.byref(result._struct), C.byref(cfg), _stream(dev)))
+            if _progress is not None:                            # step_render: the physics step first, in the same launch where it can be
+                _lib.check(_lib.lib().ms_step_render(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
+                                                     C.c_void_p(_progress.data_ptr()), C.byref(result._struct), C.byref(cfg), _stream(dev)))
+            else:
+                _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
+                                                C.byref(result._struct), C.byref(cfg), _stream(dev)))
         finally:
             if telemetry:
                 _lib.lib().ms_debug_pair_telemetry(0)
