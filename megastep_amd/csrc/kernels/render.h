@@ -675,8 +675,16 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     constexpr bool COLOUR = SHADE != 0;
     static_assert(COLOUR || OBS == 1, "without colour `screen` is NULL: the OBS instantiation");
     // (is an optional output wanted?  colourless: a bit of the mask ms_render left in obs_subsample's upper half; else the pointer)
-    [[maybe_unused]] const int out_mask_ = COLOUR ? 0 : (out.obs_subsample >> 8);
-#define MS_WANTED(BIT, PTR) (COLOUR ? ((PTR) != nullptr) : ((out_mask_ & (BIT)) != 0))
+    // (round 6, MS_OBS_MASK: the colour instantiation with optional outputs - pooled RGB-D, crosshair ids - of ONE ray group a wave
+    // asks the mask too: a whole env.step() at the headline shape 41.85 -> 41.56 us per step, two passes each way on one box; the
+    // instantiation of four groups a wave does not - the Deathmatch shape's 512-ray render 150.6 -> 153.8 us with it: one more
+    // live scalar in a kernel of 150 spilled ones (profiles/r06_ab_obs_mask.txt).  The plain one has no optional output to ask about.)
+#ifndef MS_OBS_MASK
+#define MS_OBS_MASK 1
+#endif
+    constexpr bool MASKED = !COLOUR || (MS_OBS_MASK != 0 && OBS == 1 && IMPL == 2 && NG == 1);   // (the A/B builds' older raycasts ask the pointers)
+    [[maybe_unused]] const int out_mask_ = MASKED ? (out.obs_subsample >> 8) : 0;
+#define MS_WANTED(BIT, PTR) (MASKED ? ((out_mask_ & (BIT)) != 0) : ((PTR) != nullptr))
     // what depends on the winner's number alone: its row, its texel count and first texel
     // (plain scalars in and out: as a struct by value this cost every wave 32 bytes of scratch memory)
     auto winner_of = [&](const int nearest_idx, float4& hw_mem, int& tex_w, int& tstart) {
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     const size_t o = ((size_t)n*A + a)*R + r;
     const float dist = nearest_s*rlen;
     {
-        if (COLOUR || (out_mask_ & (OUT_INDICES | OUT_LOCATIONS | OUT_DOTS | OUT_DISTANCES))) {      // (uniform)
+        if (!MASKED || (out_mask_ & (OUT_INDICES | OUT_LOCATIONS | OUT_DOTS | OUT_DISTANCES))) {      // (uniform)
             int* const o_indices = late->out.indices;
             float* const o_locations = late->out.locations;
             float* const o_dots = late->out.dots;
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         if (MS_WANTED(OUT_CENTRE, late->out.obs_centre)) {         // deathmatch.py:74-80: who is in the crosshair
             // (obs_subsample is a power of two - ms_render checks: shifts, not the thirty-instruction integer divisions a runtime
             // divisor costs here)
-            const int sub = COLOUR ? late->out.obs_subsample : (late->out.obs_subsample & 0xff), sh = __builtin_ctz((unsigned)sub), W = R >> sh;
+            const int sub = MASKED ? (late->out.obs_subsample & 0xff) : late->out.obs_subsample, sh = __builtin_ctz((unsigned)sub), W = R >> sh;
             const int r1 = (((W >> 1) - 1) << sh) + (sub >> 1), r2 = ((W >> 1) << sh) + (sub >> 1);
             if ((r == r1) | (r == r2)) {
                 int seen = -1;
@@ -836,7 +844,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
         }
         float* const o_screen = late->out.screen;
-        if (!OBS || o_screen) {
+        if (!OBS || MS_WANTED(OUT_SCREEN, o_screen)) {
             // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
             s_screen_w[3*lane] = s0; s_screen_w[3*lane + 1] = s1; s_screen_w[3*lane + 2] = s2;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -853,8 +861,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     }
     // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
     // and of the depth 1 - clamp((distance - agent_radius)/max_depth, 0, 1), summed pairwise across lanes
-    if (OBS && ((COLOUR && late->out.obs_rgb) || MS_WANTED(OUT_DEPTH, late->out.obs_depth))) {
-        const int sub = COLOUR ? late->out.obs_subsample : (late->out.obs_subsample & 0xff);   // power of two, divides 64 and R (checked by the host)
+    if (OBS && ((COLOUR && MS_WANTED(OUT_RGB, late->out.obs_rgb)) || MS_WANTED(OUT_DEPTH, late->out.obs_depth))) {
+        const int sub = MASKED ? (late->out.obs_subsample & 0xff) : late->out.obs_subsample;   // power of two, divides 64 and R (checked by the host)
         float p0 = s0, p1 = s1, p2 = s2;
         float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
         // (the first two rounds - lanes 1 and 2 apart: all of them at the demo envs' four rays a pixel - stay inside quads of lanes:
@@ -888,7 +896,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             const float inv = bits_f((uint32_t)(127 - sh) << 23);
             const int W = R >> sh, px = r >> sh;
             const size_t na = (size_t)n*A + a;
-            if (COLOUR && late->out.obs_rgb) {
+            if (COLOUR && MS_WANTED(OUT_RGB, late->out.obs_rgb)) {
                 late->out.obs_rgb[(na*3 + 0)*W + px] = p0*inv;
                 late->out.obs_rgb[(na*3 + 1)*W + px] = p1*inv;
                 late->out.obs_rgb[(na*3 + 2)*W + px] = p2*inv;

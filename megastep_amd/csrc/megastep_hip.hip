@@ -578,10 +578,13 @@ static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender
 #if MS_AB_IMPLS
     older_raycast = seq || pairs1;                                       // (their instantiations are the colour ones, whatever is asked for)
 #endif
-    if (!colour && !older_raycast)   // (the colourless instantiations read which optional outputs are wanted from here: see OUT_* in render.h)
+    // (the instantiations with optional outputs - every colourless one, and with MS_OBS_MASK the colour one of pooled observations
+    // at one ray group a wave - read which are wanted from here: see OUT_* in render.h)
+    if ((!colour || (MS_OBS_MASK && obs && ng == 1)) && !older_raycast)
         outn.obs_subsample = (out->obs_subsample & 0xff) | (((out->indices ? OUT_INDICES : 0) | (out->locations ? OUT_LOCATIONS : 0) |
                               (out->dots ? OUT_DOTS : 0) | (out->distances ? OUT_DISTANCES : 0) | (out->obs_depth ? OUT_DEPTH : 0) |
-                              (out->obs_centre ? OUT_CENTRE : 0) | (out->seen_stamp ? OUT_SEEN : 0)) << 8);
+                              (out->obs_centre ? OUT_CENTRE : 0) | (out->seen_stamp ? OUT_SEEN : 0) | (out->screen ? OUT_SCREEN : 0) |
+                              (out->obs_rgb ? OUT_RGB : 0)) << 8);
     constexpr int RW = 1;
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
