@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 14
+#define MS_ABI_VERSION 15
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -299,6 +299,29 @@ typedef struct MsDeathmatch {
     unsigned char*  matchings;     /* (N, A, A) out, optional                                                   */
 } MsDeathmatch;
 int ms_deathmatch_shoot(int n_envs, int n_agents, const MsDeathmatch* dm, void* hip_stream);
+
+/* What the reference's Explorer env does between one frame and the next - `_reward`'s arithmetic, `_reset`'s counters and the
+ * episode rule of `step`, megastep/demo/envs/explorer.py:45-90 - as one launch of N threads behind ms_render, whose first-sight
+ * tally (MsRender.seen_count; the stamps and epochs are MsRender.seen_stamp / seen_epoch) it reads.  Per env n, in this order:
+ *   reward   reset_out = over (this step began with a respawn); reward = over ? 0 : (tally - before) / pixels;
+ *            potential = tally, length_out = lengths - as this step leaves them (for display; optional)
+ *   next     lengths += 1;  over = lengths >= tally + slack - the NEXT step's respawn mask (MsStepExtras.respawn_mask,
+ *            respawn_after = 1) - and where it is set: epoch += 1 (the env forgets every texel at once), tally = lengths = 0;
+ *            before = tally */
+typedef struct MsExplorer {
+    int*            tally;         /* (N) in / out: MsRender.seen_count                                          */
+    int*            before;        /* (N) in / out: tally at the last reward                                      */
+    int*            lengths;       /* (N) in / out: episode lengths                                               */
+    int*            epoch;         /* (N) in / out: MsRender.seen_epoch                                           */
+    unsigned char*  over;          /* (N) in: respawned this step; out: to be respawned by the next               */
+    int             slack;         /* steps an episode lasts on top of one per texel seen (the reference's 200)   */
+    int             pixels;        /* observation pixels per agent: res / subsample                               */
+    unsigned char*  reset_out;     /* (N) out, optional                                                           */
+    float*          reward;        /* (N) out                                                                     */
+    float*          potential;     /* (N) out, optional                                                           */
+    int*            length_out;    /* (N) out, optional                                                           */
+} MsExplorer;
+int ms_explorer_books(int n_envs, const MsExplorer* books, void* hip_stream);
 
 /* Builds the wall grid (MsScenery.wg_*): per level of cells two launches with a prefix sum by the caller in between.
  *   ms_wallgrid_scan  for every cell of every env listed in `reps` (the representatives, MsScenery.env_geom; n_reps of

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -73,9 +73,15 @@ class MsDeathmatch(C.Structure):
                 ('reward', C.c_void_p), ('health_obs', C.c_void_p), ('matchings', C.c_void_p)]
 
 
+class MsExplorer(C.Structure):
+    _fields_ = [('tally', C.c_void_p), ('before', C.c_void_p), ('lengths', C.c_void_p), ('epoch', C.c_void_p), ('over', C.c_void_p),
+                ('slack', C.c_int), ('pixels', C.c_int), ('reset_out', C.c_void_p), ('reward', C.c_void_p), ('potential', C.c_void_p),
+                ('length_out', C.c_void_p)]
+
+
 #: every symbol include/megastep_hip.h (the boundary) and include/megastep_hip_test.h (test hooks) declare
 SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_last_render_groups', 'ms_debug_last_step_fused', 'ms_step_render', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
-           'ms_step_physics', 'ms_deathmatch_shoot',
+           'ms_step_physics', 'ms_deathmatch_shoot', 'ms_explorer_books',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
            'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
            'ms_host_wedge_meets', 'ms_host_agents_apart', 'ms_host_wall_beyond_reach', 'ms_host_ray_interval', 'ms_host_fold_hits', 'ms_host_lightgrid_cell', 'ms_host_wall_reach')
@@ -161,6 +167,8 @@ def lib():
         handle.ms_step_render.restype = C.c_int
         handle.ms_debug_last_step_fused.argtypes = []
         handle.ms_debug_last_step_fused.restype = C.c_int
+        handle.ms_explorer_books.argtypes = [C.c_int, C.POINTER(MsExplorer), C.c_void_p]
+        handle.ms_explorer_books.restype = C.c_int
         handle.ms_deathmatch_shoot.argtypes = [C.c_int, C.c_int, C.POINTER(MsDeathmatch), C.c_void_p]
         handle.ms_deathmatch_shoot.restype = C.c_int
         handle.ms_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]

@@ -51,3 +51,31 @@ __global__ __launch_bounds__(WG) void deathmatch_kernel(const MsDeathmatch dm, c
         for (int b = 0; b < n_agents; b++) row[b] = ((mine.x == b) | (mine.y == b)) ? 1 : 0;
     }
 }
+
+// explorer_kernel: the Explorer env's bookkeeping between one frame and the next (reference: megastep/demo/envs/explorer.py:45-58
+// `_reward`, :68-72 `_reset`'s counters, :83-90 the episode rule in `step`) - a dozen tensor ops on (N,) tensors, 35 us of a 79 us
+// step (profiles/r05_env_explorer_kernel_stats.csv) - as one launch of N threads behind ms_render, whose first-sight tally
+// (MsRender.seen_count) it reads.  Per env: this frame's reward - the texels seen for the first time, per observation pixel; none
+// for a frame that began with a respawn - and then, ahead of time, the NEXT step's episode rule: the length ticks, an env whose
+// length has reached its tally + slack is marked over (the mask the next physics launch respawns by, MsStepExtras) and forgets
+// what it has seen (its epoch moves on, its counters start over) - exactly what the reference does at the top of that step;
+// nothing in between looks at these counters.
+__global__ __launch_bounds__(WG) void explorer_kernel(const MsExplorer ex, const int n_envs) {
+    const int n = blockIdx.x*WG + threadIdx.x;
+    if (n >= n_envs) return;
+    const bool fresh = ex.over[n] != 0;                  // this step began with a respawn
+    int tally = ex.tally[n], length = ex.lengths[n];
+    const int gained = tally - ex.before[n];
+    if (ex.reset_out) ex.reset_out[n] = fresh ? 1 : 0;
+    ex.reward[n] = fresh ? 0.f : (float)gained/(float)ex.pixels;     // explorer.py:52-56 (an int tensor over an int: true division in binary32)
+    if (ex.potential) ex.potential[n] = (float)tally;    // (as this step leaves them, for Explorer.state())
+    if (ex.length_out) ex.length_out[n] = length;
+    // ---- the next step's top (explorer.py:86-89)
+    length += 1;
+    const bool over = length >= tally + ex.slack;
+    if (over) { ex.epoch[n] += 1; tally = 0; length = 0; }
+    ex.tally[n] = tally;
+    ex.before[n] = tally;
+    ex.lengths[n] = length;
+    ex.over[n] = over ? 1 : 0;
+}

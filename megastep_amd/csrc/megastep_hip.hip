@@ -4,7 +4,7 @@
 // launches); the kernels are in kernels/*.h, included below inside the anonymous namespace - math.h (scalar helpers shared
 // with the ms_host_* test hooks), physics.h, lighting.h, render.h, bake.h, wallgrid.h.
 //
-// Twelve kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
+// Thirteen kernels, all written wave64-first (DESIGN.md section 3 has the full story of each):
 //
 //   physics_kernel<MOVE, EXTRA, PACK>   one wavefront per env (PACK = 1: per few consecutive envs, side by side - large
 //                   worlds of few agents per env): lane = agent for the state, the reach and the agent-agent
@@ -37,6 +37,8 @@
 //   wallgrid_scan_kernel, wallgrid_fill_kernel   the wall grid: per cell of a floorplan which walls can matter to a ray
 //                   from the cell (one wall hiding another from the whole cell, exactly) and which an agent in it can
 //                   touch; and the lists made of that.   (replaces the all-lines loops kernels.cu:203-205,352-377)
+//   explorer_kernel     the Explorer env's books between frames (reward, episode rule, forgetting) as one launch.
+//                                                            (reference: demo/envs/explorer.py:45-90)
 //   deathmatch_kernel   the Deathmatch env's game logic between frames (revive, crosshairs, hits and wounds, health, damage,
 //                   reward, next step's dead) as one element-wise launch behind ms_render.
 //                                                            (reference: demo/envs/deathmatch.py:46-88)
@@ -630,6 +632,14 @@ int ms_deathmatch_shoot(int n_envs, int n_agents, const MsDeathmatch* dm, void* 
     const long long rows = (long long)n_envs*n_agents, blocks = (rows + WG - 1)/WG;
     if (blocks > 0x7fffffffLL) return MS_EUNSUPPORTED;
     hipLaunchKernelGGL(deathmatch_kernel, dim3((unsigned)blocks), dim3(WG), 0, (hipStream_t)stream, *dm, n_envs, n_agents);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MS_OK : hip_fail(e);
+}
+
+int ms_explorer_books(int n_envs, const MsExplorer* ex, void* stream) {
+    if (n_envs <= 0 || !ex || !ex->tally || !ex->before || !ex->lengths || !ex->epoch || !ex->over || !ex->reward || ex->pixels <= 0 ||
+        ((uintptr_t)ex->tally % 4) || ((uintptr_t)ex->before % 4) || ((uintptr_t)ex->lengths % 4) || ((uintptr_t)ex->epoch % 4)) return MS_EINVAL;
+    hipLaunchKernelGGL(explorer_kernel, dim3((unsigned)((n_envs + WG - 1)/WG)), dim3(WG), 0, (hipStream_t)stream, *ex, n_envs);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }

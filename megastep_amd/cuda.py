@@ -845,6 +845,30 @@ def deathmatch_shoot(centre, positions, upper, health, damage, dead, clearance=1
     return out
 
 
+def explorer_books(tally, before, lengths, epoch, over, slack, pixels, display=False):
+    """The Explorer env's bookkeeping between one frame and the next as ONE launch (include/megastep_hip.h, MsExplorer;
+    reference: demo/envs/explorer.py:45-90 - the reward, the counters of ``_reset`` and the episode rule of ``step``, a dozen
+    tensor ops). ``tally`` is the first-sight count :func:`render` keeps (``seen=``), ``epoch`` its epochs; ``before``,
+    ``lengths`` (N,) int32 and ``over`` (N,) bool are the env's own - all updated IN PLACE: ``over`` comes in as the envs this
+    step respawned (they get no reward) and leaves as the envs the next step is to respawn, which have already forgotten what
+    they saw. Returns ``(reset, reward)`` - the incoming ``over`` and this frame's reward - plus, with ``display``, the
+    potential and the lengths as this step leaves them."""
+    n = tally.shape[0]
+    for name, t in (('tally', tally), ('before', before), ('lengths', lengths), ('epoch', epoch)):
+        _check(t, name, torch.int32, 1)
+        if t.shape != (n,):
+            raise RuntimeError('explorer_books: tally, before, lengths, epoch and over must all be (N,)')
+    _check(over, 'over', torch.bool, 1)
+    dev = _require_gpu(tally, before, lengths, epoch, over)
+    out = (torch.empty_like(over), torch.empty(n, dtype=torch.float32, device=dev)) + \
+          ((torch.empty(n, dtype=torch.float32, device=dev), torch.empty_like(lengths)) if display else ())
+    ex = _lib.MsExplorer(tally.data_ptr(), before.data_ptr(), lengths.data_ptr(), epoch.data_ptr(), over.data_ptr(), int(slack), int(pixels),
+                         out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr() if display else None, out[3].data_ptr() if display else None)
+    with _on(dev):
+        _lib.check(_lib.lib().ms_explorer_books(n, C.byref(ex), _stream(dev)))
+    return out
+
+
 FIELDS = ('indices', 'locations', 'dots', 'distances', 'screen')
 #: MEGASTEP_CHECK_GRID=1: every render / physics call first makes sure the static walls are still the ones the wall grid
 #: was built from (a reduction over the lines and a host sync per call - for debugging and the test suite, off by default)

@@ -64,9 +64,12 @@ class SeenTexels:
 
 class Explorer:
 
-    def __init__(self, n_envs, *args, device='cuda', geometries=None, depth_only=False, **kwargs):
+    def __init__(self, n_envs, *args, device='cuda', geometries=None, depth_only=False, fused=None, **kwargs):
         """``depth_only=True``: observations are depth + IMU, no RGB (BASELINE config 2's "64-ray depth-only"); the
-        renderer then runs without its shading pass."""
+        renderer then runs without its shading pass. ``fused`` (default: on a GPU): the bookkeeping between frames - the
+        reward, the episode rule, the forgetting - is ONE launch behind the render kernel
+        (:func:`megastep_amd.cuda.explorer_books`) instead of a dozen tensor ops; ``False`` keeps the tensor ops, the same
+        arithmetic."""
         if geometries is None:
             geometries = cubicasa.sample(n_envs)
         self.core = core.Core(scene.scenery(geometries, 1, device=device), *args, res=4*64, fov=130, **kwargs)
@@ -85,10 +88,18 @@ class Explorer:
 
         self._memory = SeenTexels(c.scenery, c.n_envs)
         self._lengths = self._memory.spare                                  # (cleared together with the books)
+        self._fused = c.device.type == 'cuda' if fused is None else bool(fused)
+        # (fused) who the next step is to respawn - written by the kernel at the end of a step, read by the next physics launch
+        # as its respawn mask; the potential and the lengths as the last step left them (the kernel has by then moved the
+        # counters themselves on to the next step's top)
+        self._over = c.env_full(False)
+        self._shown = None
 
     # what the tests and `state` look at
-    _potential = property(lambda self: self._memory.count)
-    _seen = property(lambda self: self._memory.mask())
+    _potential = property(lambda self: self._memory.count if self._shown is None else self._shown[0])
+    # (fused: an env marked over has already moved its epoch on - until its respawn it is shown what it saw under the old one)
+    _seen = property(lambda self: self._memory.mask() if self._shown is None else
+                     self._memory.stamp == (self._memory.epoch - self._over.int())[self._memory.texel_env])
     _tex_to_env = property(lambda self: self._memory.texel_env)
 
     def _restart(self, which):
@@ -107,14 +118,36 @@ class Explorer:
             obs['rgb'] = self._rgb(frame)
         return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
 
+    def _world_fused(self):
+        """Render (which keeps the first-sight books), then the reward, the episode rule and the forgetting as one launch."""
+        from ... import cuda
+        observers = (self._depth,) if self._rgb is None else (self._rgb, self._depth)
+        frame = modules.render(self.core, observers=observers, fields=(), seen=self._memory.books)
+        m = self._memory
+        reset, reward, potential, lengths = cuda.explorer_books(m.tally, m._before, self._lengths, m.epoch, self._over, EPISODE_SLACK,
+                                                                self.core.res//self._depth.subsample, display=True)
+        self._shown = (potential, lengths)
+        obs = arrdict.arrdict(d=self._depth(frame), imu=self._imu())
+        if self._rgb is not None:
+            obs['rgb'] = self._rgb(frame)
+        return arrdict.arrdict(obs=obs, reset=reset, reward=reward)
+
     @torch.no_grad()
     def reset(self):
         everyone = self.core.env_full(True)
         self._restart(everyone)
+        if self._fused:
+            self._over.fill_(True)
+            return self._world_fused()
         return self._world(everyone)
 
     @torch.no_grad()
     def step(self, decision):
+        if self._fused:
+            # four launches: the spawn draw, physics (movement + step + respawn of the envs marked over + IMU), render (pooled
+            # observations + first-sight books), the env's books (reward; the next step's episode rule and forgetting)
+            self._mover(decision, respawn=self._respawner.draw(self._over.unsqueeze(-1), after=True), imu=self._imu)
+            return self._world_fused()
         # Who is over does not depend on this step's movement (explorer.py:83-90 moves first, then checks), so it is
         # settled up front and the respawn rides in the physics launch, after the integration - as does the IMU reading.
         self._lengths += 1
@@ -126,5 +159,6 @@ class Explorer:
     def state(self, e=0):
         seen = self._memory.mask()[self._memory.texel_env == e]
         return arrdict.arrdict(core=self.core.state(e), **({} if self._rgb is None else dict(rgb=self._rgb.state(e))), d=self._depth.state(e),
-                               potential=self._memory.count[e].clone(), seen=seen.clone(),
-                               length=self._lengths[e].clone(), max_length=self._memory.count[e].add(EPISODE_SLACK).clone())
+                               potential=self._potential[e].clone(), seen=seen.clone(),
+                               length=(self._lengths if self._shown is None else self._shown[1])[e].clone(),
+                               max_length=self._potential[e].add(EPISODE_SLACK).clone())

@@ -44,13 +44,13 @@ def test_struct_layouts_match_the_header():
     """ctypes mirrors of the structs must have the C layout: check sizes against a C compile of the header."""
     import subprocess, tempfile
     from megastep_amd import _lib
-    src = '#include <stdio.h>\n#include "megastep_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(MsConfig), sizeof(MsScenery), sizeof(MsAgents), sizeof(MsRender), sizeof(MsMovement), sizeof(MsStepExtras), sizeof(MsDeathmatch));}'
+    src = '#include <stdio.h>\n#include "megastep_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu", sizeof(MsConfig), sizeof(MsScenery), sizeof(MsAgents), sizeof(MsRender), sizeof(MsMovement), sizeof(MsStepExtras), sizeof(MsDeathmatch), sizeof(MsExplorer));}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, 't.c'), 'w').write(src)
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), os.path.join(d, 't.c'), '-o', os.path.join(d, 't')])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, 't')]).split()))
     assert sizes == [C.sizeof(_lib.MsConfig), C.sizeof(_lib.MsScenery), C.sizeof(_lib.MsAgents), C.sizeof(_lib.MsRender),
-                     C.sizeof(_lib.MsMovement), C.sizeof(_lib.MsStepExtras), C.sizeof(_lib.MsDeathmatch)]
+                     C.sizeof(_lib.MsMovement), C.sizeof(_lib.MsStepExtras), C.sizeof(_lib.MsDeathmatch), C.sizeof(_lib.MsExplorer)]
 
 
 def test_bad_arguments_are_rejected_before_any_launch():
@@ -62,6 +62,7 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert h.ms_bake(None, None, None) == -1
     assert h.ms_deathmatch_shoot(4, 4, None, None) == -1 and h.ms_deathmatch_shoot(0, 4, C.byref(_lib.MsDeathmatch()), None) == -1
     assert h.ms_deathmatch_shoot(4, 4, C.byref(_lib.MsDeathmatch()), None) == -1          # (null tensors)
+    assert h.ms_explorer_books(4, None, None) == -1 and h.ms_explorer_books(4, C.byref(_lib.MsExplorer()), None) == -1
     sc, ag, out = _lib.MsScenery(), _lib.MsAgents(), _lib.MsRender()
     assert h.ms_physics(C.byref(sc), C.byref(ag), None, C.byref(cfg), None) == -1
     with pytest.raises(RuntimeError, match='invalid argument'):

@@ -169,7 +169,7 @@ def test_explorer_reward_equals_the_reference_formula():
     from megastep_amd.demo import Explorer
     from megastep_amd import cubicasa
     torch.manual_seed(1); np.random.seed(1)
-    env = Explorer(8, geometries=cubicasa.sample(8, n_unique=16))
+    env = Explorer(8, geometries=cubicasa.sample(8, n_unique=16), fused=False)      # (the tensor-op books; the one-launch ones: next test)
     env.reset()
     prev = env._potential.clone()
     for step in range(30):
@@ -184,6 +184,45 @@ def test_explorer_reward_equals_the_reference_formula():
             torch.testing.assert_close(world.reward, want)
         prev = potential
     assert world.reset.sum() == 0 and env._potential.min() > 0
+
+
+@pytest.mark.parametrize('depth_only', [False, True])
+def test_explorer_steps_the_same_with_and_without_the_books_kernel(depth_only):
+    """Two Explorers from the same seeds, one keeping its books between frames with the tensor ops, one with the single launch
+    (ms_explorer_books): the same observations, rewards, resets, potentials and seen-masks step after step, through respawns -
+    two forced (an episode length pushed past its limit: the tensor ops apply the rule at the top of the step, the kernel at
+    the end of the step before, so the push comes a step earlier there) and the reference's formula for the rest."""
+    from megastep_amd.demo import Explorer
+    from megastep_amd import arrdict, cubicasa
+    gs = cubicasa.sample(8, n_unique=16)
+
+    def rollout(fused):
+        torch.manual_seed(5); np.random.seed(5)
+        env = Explorer(8, geometries=gs, fused=fused, depth_only=depth_only)
+        assert env._fused == fused
+        torch.manual_seed(6)
+        frames = [env.reset()]
+        for t in range(24):
+            for when, who in ((7, 2), (15, 5)):
+                if t == (when - 1 if fused else when):
+                    env._lengths[who] = 10_000
+            acts = torch.randint(0, 7, (8, 1), device='cuda', generator=torch.Generator('cuda').manual_seed(200 + t))
+            w = env.step(arrdict.arrdict(actions=acts))
+            w['potential'], w['seen'] = env._potential.clone(), env._seen.clone()
+            w['pose'] = torch.cat([env.core.agents.positions.reshape(-1), env.core.agents.angles.reshape(-1)])
+            frames.append(w)
+        return frames
+
+    a, b = rollout(False), rollout(True)
+    for t, (fa, fb) in enumerate(zip(a, b)):
+        assert torch.equal(fa.reset, fb.reset), t
+        torch.testing.assert_close(fa.reward, fb.reward, rtol=0, atol=0, msg=f'reward at step {t}')
+        for k in fa.obs:
+            torch.testing.assert_close(fa.obs[k], fb.obs[k], rtol=0, atol=1e-6, msg=f'{k} at step {t}')
+        if t:
+            assert torch.equal(fa.potential, fb.potential) and torch.equal(fa.seen, fb.seen) and torch.equal(fa.pose, fb.pose), t
+    assert a[0].reset.all() and sum(int(f.reset.sum()) for f in a[1:]) == 2 and a[8].reset[2] and a[16].reset[5]
+    assert (torch.stack([f.reward for f in a[1:]]) > 0).any()
 
 
 @pytest.mark.parametrize('cls,kwargs', [('MomentumMovement', dict(accel=5, ang_accel=180, decay=.125)),
