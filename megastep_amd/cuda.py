@@ -661,7 +661,14 @@ class Physics:
 # ---------------------------------------------------------------------------------------------------------------------
 # kernels
 # ---------------------------------------------------------------------------------------------------------------------
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream(dev):
+    # (the current stream's handle straight from torch's C side: torch.cuda.current_stream() builds a Stream object around it
+    # first - 5 us of the host's 25 per launch, three launches a step)
+    if _raw_stream is not None and dev.index is not None:
+        return C.c_void_p(_raw_stream(dev.index))
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
@@ -860,10 +867,11 @@ def explorer_books(tally, before, lengths, epoch, over, slack, pixels, display=F
             raise RuntimeError('explorer_books: tally, before, lengths, epoch and over must all be (N,)')
     _check(over, 'over', torch.bool, 1)
     dev = _require_gpu(tally, before, lengths, epoch, over)
-    out = (torch.empty_like(over), torch.empty(n, dtype=torch.float32, device=dev)) + \
-          ((torch.empty(n, dtype=torch.float32, device=dev), torch.empty_like(lengths)) if display else ())
+    reset = torch.empty_like(over)
+    rest = torch.empty((3 if display else 1, n), dtype=torch.float32, device=dev)         # (one allocation: reward | potential | lengths)
+    out = (reset, rest[0]) + ((rest[1], rest[2].view(torch.int32)) if display else ())
     ex = _lib.MsExplorer(tally.data_ptr(), before.data_ptr(), lengths.data_ptr(), epoch.data_ptr(), over.data_ptr(), int(slack), int(pixels),
-                         out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr() if display else None, out[3].data_ptr() if display else None)
+                         reset.data_ptr(), rest.data_ptr(), rest.data_ptr() + 4*n if display else None, rest.data_ptr() + 8*n if display else None)
     with _on(dev):
         _lib.check(_lib.lib().ms_explorer_books(n, C.byref(ex), _stream(dev)))
     return out
@@ -967,15 +975,43 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
     return result
 
 
+_layouts = {}
+
+
 def _render_buffers(scenery, n, a, r, fields, pooled, dev):
     """One allocation for the wanted outputs (reference: five at::empty calls, kernels.cu:461-469), the pooled
     observations and the kernels' scratch (MS_RENDER_WORKSPACE_INTS), and the MsRender that points into it."""
+    scenery._as_struct()
+    lit = a == 1 or scenery._lg[0] is not None
+    key = (n, a, r, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), lit)
+    layout = _layouts.get(key)
+    if layout is None:
+        layout = _layouts[key] = _render_layout(n, a, r, fields, pooled, lit)
+        if len(_layouts) > 64:
+            _layouts.pop(next(iter(_layouts)))
+    total, offs, sizes, shapes, sub, max_depth, has_pool = layout
+    buf = torch.empty(total, dtype=torch.float32, device=dev)
+    base = buf.data_ptr()
+    pieces = [buf[offs[i]:offs[i] + shapes[i][1]].view(shapes[i][0]) if sizes[i] else None for i in range(8)]
+    if pieces[0] is not None:
+        pieces[0] = pieces[0].view(torch.int32)
+    if pieces[7] is not None:
+        pieces[7] = pieces[7].view(torch.int32)
+    result = Render(*pieces[:5], pieces[5], pieces[6], sub if has_pool else None, pieces[7])
+    ptrs = [base + 4*offs[i] if sizes[i] else None for i in range(8)]
+    result._struct = _lib.MsRender(*ptrs[:5], base + 4*offs[-1], ptrs[5], ptrs[6], sub, max_depth, ptrs[7])
+    result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel (which zeroes it); read by the tests
+    return result
+
+
+def _render_layout(n, a, r, fields, pooled, lit):
+    """Where everything sits in a render call's one allocation - worked out once per (shapes, fields, pooling) and kept: it is
+    a fifth of the host's share of a render call."""
     want = FIELDS if fields is None else tuple(fields)
     if any(f not in FIELDS for f in want):
         raise RuntimeError(f'fields must be among {FIELDS}')
-    scenery._as_struct()
     colour = 'screen' in want or (pooled is not None and pooled.get('rgb', True))
-    if a > 1 and scenery._lg[0] is None and colour:
+    if not lit and colour:
         # no light grid (Scenery.LIGHT_GRID switched off): agent hits are lit by a second launch that reads all five
         # planes back and patches `screen` - after any pooling. All planes then, and the caller pools.  (Without colour
         # there is nothing to light: the depth-only kernel serves such sceneries like any other.)
@@ -996,17 +1032,7 @@ def _render_buffers(scenery, n, a, r, fields, pooled, dev):
     offs = [0]
     for x in sizes:
         offs.append(offs[-1] + x)
-    buf = torch.empty(offs[-1] + 18 + n*a*((r + 63)//64) + 2*n*a, dtype=torch.float32, device=dev)
-    base = buf.data_ptr()
-    ptr = lambda i: base + 4*offs[i] if sizes[i] else None
-    piece = lambda i, shape: buf[offs[i]:offs[i] + int(torch.Size(shape).numel())].view(shape) if sizes[i] else None
-    outs = [piece(i, (n, a, r, 3) if f == 'screen' else (n, a, r)) for i, f in enumerate(FIELDS)]
-    if outs[0] is not None:
-        outs[0] = outs[0].view(torch.int32)
-    obs_rgb, obs_depth, obs_centre = piece(5, (n, a, 3, w)), piece(6, (n, a, w)), piece(7, (n, a, 2))
-    if obs_centre is not None:
-        obs_centre = obs_centre.view(torch.int32)
-    result = Render(*outs, obs_rgb, obs_depth, sub if pooled is not None else None, obs_centre)
-    result._struct = _lib.MsRender(*(ptr(i) for i in range(5)), base + 4*offs[-1], ptr(5), ptr(6), sub, max_depth, ptr(7))
-    result._telemetry = buf[offs[-1]:offs[-1] + 16].view(torch.int32)     # see render_prep_kernel (which zeroes it); read by the tests
-    return result
+    total = offs[-1] + 18 + n*a*((r + 63)//64) + 2*n*a
+    shapes = [((n, a, r, 3) if f == 'screen' else (n, a, r)) for f in FIELDS] + [(n, a, 3, w), (n, a, w), (n, a, 2)]
+    shapes = [(sh, int(torch.Size(sh).numel())) for sh in shapes]
+    return total, offs, sizes, shapes, sub, max_depth, pooled is not None

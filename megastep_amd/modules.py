@@ -129,12 +129,7 @@ def render(core, observers=None, fields=None, centre=False, seen=None):
     (needs observers); ``seen`` is passed on to :func:`cuda.render` (first-sight texel bookkeeping)."""
     pooled = None
     if observers:
-        subs = {o.subsample for o in observers}
-        depth = [o for o in observers if isinstance(o, Depth)]
-        if len(subs) != 1 or len({o.max_depth for o in depth}) > 1:
-            raise ValueError('observers of one render must share their subsample and max_depth')
-        pooled = dict(subsample=subs.pop(), max_depth=depth[0].max_depth if depth else 10.,
-                      rgb=any(isinstance(o, RGB) for o in observers), depth=bool(depth), centre=bool(centre))
+        pooled = _pooling(tuple(observers), bool(centre))
     raw = cuda.render(core.scenery, core.agents, fields=fields, pooled=pooled, seen=seen)
     r = arrdict.arrdict({k: getattr(raw, k).unsqueeze(2) for k in cuda.FIELDS if getattr(raw, k) is not None})
     if 'screen' in r:
@@ -149,6 +144,27 @@ def render(core, observers=None, fields=None, centre=False, seen=None):
         if raw.obs_centre is not None:
             r['centre'] = raw.obs_centre
     return r
+
+
+_poolings = {}
+
+
+def _pooling(observers, centre):
+    """What :func:`cuda.render` is asked to pool for these observers - worked out once per set of them (an env hands over the
+    same modules every step)."""
+    key = (tuple((id(o), o.subsample, getattr(o, 'max_depth', None)) for o in observers), centre)
+    pooled = _poolings.get(key)
+    if pooled is None:
+        subs = {o.subsample for o in observers}
+        depth = [o for o in observers if isinstance(o, Depth)]
+        if len(subs) != 1 or len({o.max_depth for o in depth}) > 1:
+            raise ValueError('observers of one render must share their subsample and max_depth')
+        pooled = dict(subsample=subs.pop(), max_depth=depth[0].max_depth if depth else 10.,
+                      rgb=any(isinstance(o, RGB) for o in observers), depth=bool(depth), centre=centre)
+        if len(_poolings) > 256:
+            _poolings.clear()
+        _poolings[key] = pooled
+    return pooled
 
 
 def downsample(screen, subsample):
