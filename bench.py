@@ -364,6 +364,11 @@ def cpu_baselines(core, budget_s=8.):
                              'waking threads up (256 threads turned one step into minutes); cpu_baseline_c uses every core',
         'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/torch_step.py, torch.set_num_threads({threads})'}
 
+    # ... and the same step on EVERY host core (north_star: "the box's own host cores"), once, in a process of its
+    # own with a deadline - in round 3 the 256-thread pool turned one step into minutes, which this run cannot afford to wait for
+    if usable > threads:
+        out['cpu_baseline']['all_cores'] = _torch_step_all_cores(core, usable, min(n, 64))
+
     n, scene, agents = _oracle_sample(core, 4096)
     scene = O.Scene(scene)
     cfg = O.config(core.agent_radius, core.res, core.fov, core.fps)
@@ -382,6 +387,54 @@ def cpu_baselines(core, budget_s=8.):
         'host_cores': cores,
         'sample': f'first {n} envs of the workload x {steps} steps (physics+render), oracle/megastep_oracle.c'}
     return out
+
+
+_ALL_CORES = """
+import pickle, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from oracle import torch_step
+scene, agents, consts, threads = pickle.load(open(sys.argv[2], 'rb'))
+torch.set_num_threads(threads)
+world = torch_step.World(scene, *consts)
+ag = {k: torch.as_tensor(v) for k, v in agents.items()}
+torch_step.step(world, ag)                       # (thread pool and allocator warm)
+rng = np.random.RandomState(0)
+steps, t0 = 0, time.perf_counter()
+while steps < 20 and time.perf_counter() - t0 < 6:
+    ag['velocity'] = torch.as_tensor(rng.uniform(-3, 3, agents['velocity'].shape).astype(np.float32))
+    ag['angvelocity'] = torch.as_tensor(rng.uniform(-180, 180, agents['angvelocity'].shape).astype(np.float32))
+    torch_step.step(world, ag)
+    steps += 1
+print('RESULT', steps, time.perf_counter() - t0, flush=True)
+"""
+
+
+def _torch_step_all_cores(core, threads, n, deadline_s=40.):
+    """The pure-PyTorch step with torch.set_num_threads(every usable core) on the first `n` envs, in a subprocess that is given
+    `deadline_s` seconds: its rate, or the statement that it did not get there."""
+    import pickle
+    import subprocess
+    import tempfile
+    n, scene, agents = _oracle_sample(core, n)
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'sample.pkl')
+        pickle.dump((scene, agents, (core.agent_radius, core.res, core.fov, core.fps), threads), open(path, 'wb'), protocol=4)
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+        try:
+            got = subprocess.run([sys.executable, '-c', _ALL_CORES, ROOT, path], capture_output=True, text=True, timeout=deadline_s, env=env)
+            line = [l for l in got.stdout.splitlines() if l.startswith('RESULT')]
+            if line:
+                steps, dt = int(line[0].split()[1]), float(line[0].split()[2])
+                log(f'pure-PyTorch CPU step on {threads} threads: {steps} steps of {n} envs in {dt:.1f}s')
+                return {'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': threads,
+                        'sample': f'first {n} envs x {steps} steps, torch.set_num_threads({threads}), own process'}
+            return {'value': None, 'cores': threads, 'note': 'the all-cores run failed: ' + got.stderr[-200:]}
+        except subprocess.TimeoutExpired:
+            log(f'pure-PyTorch CPU step on {threads} threads: not through its first steps of {n} envs after {deadline_s:.0f}s')
+            return {'value': None, 'cores': threads, 'upper_bound': n*2/deadline_s,
+                    'note': f'with torch.set_num_threads({threads}) the step of {n} envs did not get through two steps (one to warm up) in '
+                            f'{deadline_s:.0f} s: thousands of small tensor ops, each waking {threads} threads'}
 
 
 class _Gpu:
