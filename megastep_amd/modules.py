@@ -301,8 +301,26 @@ class RandomSpawns:
         """The respawn of the agents marked in the (n_env, n_agent) bool mask ``reset`` as a request that
         :func:`cuda.physics` (through the movement modules' ``respawn=``) carries out inside its launch - before the
         step, or after it with ``after=True``. Same draw as :meth:`__call__`."""
-        choices = torch.randint(0, self._spawns.angles.shape[1], reset.shape, device=reset.device)
-        return dict(mask=reset.contiguous(), choices=choices, positions=self._spawns.positions, angles=self._spawns.angles, after=after)
+        return dict(mask=reset.contiguous(), choices=self._choices(reset), positions=self._spawns.positions, angles=self._spawns.angles, after=after)
+
+    #: steps' worth of spawn choices drawn per torch.randint call (see _choices)
+    DRAW_AHEAD = 64
+
+    def _choices(self, reset):
+        """This step's spawn choice for every agent: uniform among the first ``spawns.shape[1]`` spawn points, from torch's
+        generator - drawn DRAW_AHEAD steps at a time and handed out a step's slice per call: on (4096, 1) tensors the draw is a
+        launch of its own that lasts as long as the env's whole bookkeeping kernel, every step, for numbers that a handful of
+        agents in thousands ever look at. Inside a stream capture the draw stays in the step (a captured slice would be the
+        same numbers at every replay; torch.randint is graph-safe)."""
+        n = self._spawns.angles.shape[1]
+        if reset.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ahead = getattr(self, '_ahead', None)
+            if ahead is None or self._ahead_at >= len(ahead) or ahead.shape[1:] != reset.shape:
+                ahead = self._ahead = torch.randint(0, n, (self.DRAW_AHEAD,) + tuple(reset.shape), device=reset.device)
+                self._ahead_at = 0
+            self._ahead_at += 1
+            return ahead[self._ahead_at - 1]
+        return torch.randint(0, n, reset.shape, device=reset.device)
 
     def __call__(self, reset):
         """``reset`` is an (n_env, n_agent) bool mask; the marked agents get a new pose and zero velocity.
