@@ -806,6 +806,8 @@ def main(argv=None):
                                                          'multi-agent world, one per env for a single-agent one)')
     ap.add_argument('--legacy-plans', action='store_true', help="rounds 1-3's pool: the training split of a 512-plan sample (460 plans)")
     ap.add_argument('--depth-only', action='store_true', help="ask the renderer for `distances` alone (BASELINE config 2)")
+    ap.add_argument('--one-launch', action='store_true', help="the step through ms_step_render: one launch a step for single-agent worlds of up "
+                                                            "to 64 rays (BASELINE config 2), the two launches for every other shape")
     ap.add_argument('--fast-build', action='store_true', help="draw textures, lights and spawns on the device (10^4+ envs)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-env-fps', action='store_true', help="skip the whole-env.step() rates")
@@ -882,7 +884,7 @@ def main(argv=None):
     scenery = core.scenery
     log(f'world built: {N} envs on this rank')
     fields = ('distances',) if args.depth_only else None
-    m = time_hot_path(dev, core, args.steps, args.warmup, barrier, rank, fields=fields, graph=not args.no_graph)
+    m = time_hot_path(dev, core, args.steps, args.warmup, barrier, rank, fields=fields, graph=not args.no_graph, one_launch=args.one_launch)
     eager_runs, graph_runs, runs = m['eager_runs'], m['graph_runs'], m['runs']
     step_ms, render_each = m['step_ms'], m['render_each']
     eager_s = float(np.median(eager_runs))
@@ -917,7 +919,8 @@ def main(argv=None):
         'config': {
             'workload': f'{args.envs} envs x {A} agents x {args.res}-ray {outputs} per GPU, fov {args.fov:g}, synthetic cubicasa floorplans'
                         + (' (large maps)' if args.large else ''),
-            'step': 'ms_physics + ms_render (C-ABI), per-step velocities from random momentum actions resident in HBM',
+            'step': ('ms_step_render (C-ABI: physics + render as one launch where an agent is one wave, else the two launches)' if args.one_launch
+                     else 'ms_physics + ms_render (C-ABI)') + ', per-step velocities from random momentum actions resident in HBM',
             'launch': 'the K timed steps replayed as one HIP graph' if graph_s is not None else 'one Python call per kernel (eager)',
             'hip_force_dev_kernarg': os.environ.get('HIP_FORCE_DEV_KERNARG'),
             'envs_per_gpu': args.envs, 'envs_this_rank': N, 'envs_total': n_total, 'agents': A, 'res': args.res,
@@ -935,7 +938,8 @@ def main(argv=None):
             # (<IMPL, RW, OBS, SHADE, NG>; NG - 64-ray groups per wave - as ms_render picks it: four from 256 rays up on launches
             # of two and a half rounds of such waves)
             'kernel': 'ms_render = render_kernel<2,1,%s,%d> (headings cached by ms_physics)' % (
-                '1,0' if args.depth_only else '0,1', ray_groups(dev, core)),
+                '1,0' if args.depth_only else '0,1', ray_groups(dev, core)) + (' with STEP = 1: the env\'s physics step in the same wave'
+                                                                                 if args.one_launch else ''),
             'bound': 'hbm', 'achieved': achieved,
             'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': traffic_source,
