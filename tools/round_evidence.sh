@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6's evidence in one call: the whole GPU suite, 300 fuzz seeds (every third on oblique plans), the bench lines (defaults; the
+# A round's evidence in one gpurun call (round 6's, as it was run): the whole GPU suite, 300 fuzz seeds (every third on oblique plans), the bench lines (defaults; the
 # driver's K = 20; 8 ranks sharing the one GPU), the per-shape rocprofv3 profiles (headline, C2 depth-only as two launches and as one).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6z; O=gpurun_out/r6z
 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/build.log 2>&1; echo "build+smoke rc=$?"; tail -1 $O/build.log
