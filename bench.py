@@ -248,7 +248,7 @@ def replay_steps(step, actions, repeats=5):
     return float(np.median(times))
 
 
-def traffic_entry(envs, agents, res, large=False, depth_only=False, plans=None):
+def traffic_entry(envs, agents, res, large=False, depth_only=False, plans=None, one_launch=False, oblique=False):
     """The newest profiles/rNN_traffic.json entry for a workload (tools/profile.sh: FETCH_SIZE and WRITE_SIZE in separate PMC
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; since round 5 also the vector ALUs' busy
     fraction from the SQ pass of the same profile) and the file it was read from; (None, None) for a shape nobody profiled -
@@ -259,7 +259,8 @@ def traffic_entry(envs, agents, res, large=False, depth_only=False, plans=None):
         t = json.load(open(path))
         for entry in t.get('shapes', [t]):                              # (one shape per file up to round 2, a list since)
             w = entry.get('workload', {})
-            if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False)), bool(w.get('depth_only', False))) == want:
+            if (w.get('envs'), w.get('agents'), w.get('res'), bool(w.get('large', False)), bool(w.get('depth_only', False))) == want \
+                    and bool(w.get('one_launch', False)) == bool(one_launch) and bool(w.get('oblique', False)) == bool(oblique):
                 # (`plans`: the world's distinct floorplans - a profile of the same shape on another plan count moved other bytes:
                 # the 64-plan C5 world lives in the caches, the 4096-plan one does not.  An entry that does not say is a profile of
                 # the shape's default world, SURVEY 8(d)'s count; a line for another count gets no traffic rather than a wrong one.)
@@ -272,11 +273,11 @@ def traffic_entry(envs, agents, res, large=False, depth_only=False, plans=None):
 def measured_traffic(args):
     """HBM bytes per ms_render launch of this exact workload from the rocprofv3 PMC passes (see traffic_entry)."""
     plans = 460 if args.legacy_plans else plan_count(args.envs, args.agents, args.unique)
-    entry, path = traffic_entry(args.envs, args.agents, args.res, args.large, args.depth_only, plans)
+    entry, path = traffic_entry(args.envs, args.agents, args.res, args.large, args.depth_only, plans, args.one_launch)
     return (entry['render_bytes_per_launch'], path) if entry else (None, None)
 
 
-def measured_block(core, fields, render_ms, step_ms, large=False):
+def measured_block(core, fields, render_ms, step_ms, large=False, one_launch=False, oblique=False):
     """What the counters say about a shape, next to its algorithmic-bytes roofline figure: the fabric traffic of the render
     launch and of the step, what fraction of the HBM peak THAT is over the measured time, and how busy the vector ALUs are -
     with the verdict on what bounds the shape. (The algorithmic formula of SURVEY 8(d) counts every line of an env once per
@@ -284,7 +285,7 @@ def measured_block(core, fields, render_ms, step_ms, large=False):
     were never moved is no utilisation, and round 4's C5 line read 8190 GB/s on an 8000 GB/s part that way.)"""
     sc = core.scenery
     plans = int((sc.geom == torch.arange(core.n_envs, device=sc.geom.device)).sum()) if getattr(sc, 'geom', None) is not None else core.n_envs
-    entry, path = traffic_entry(core.n_envs, core.n_agents, core.res, large, fields is not None and 'screen' not in fields, plans)
+    entry, path = traffic_entry(core.n_envs, core.n_agents, core.res, large, fields is not None and 'screen' not in fields, plans, one_launch, oblique)
     if entry is None:
         return {'traffic': None, 'traffic_note': f'no profile of this shape on {plans} floorplans under profiles/'}
     rt, pt = entry['render_bytes_per_launch'], entry.get('physics_bytes_per_launch', 0.)
@@ -680,7 +681,8 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None, one_launch=Fal
          'roofline_frac': rb/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS, 'physics_algorithmic_bytes': pb,
          'roofline_frac_note': 'render_algorithmic_bytes (SURVEY 8(d): every line of an env once per launch, whether the kernel '
                                'reads it or not) over the render launch against 8 TB/s; what was actually moved: traffic / frac_measured',
-         **measured_block(core, fields, render_ms, 1e3*s/steps, large=sc.lines.vals.shape[0]/core.n_envs > 600),
+         **measured_block(core, fields, render_ms, 1e3*s/steps, large=sc.lines.vals.shape[0]/core.n_envs > 600, one_launch=one_launch,
+                          oblique=getattr(core, 'oblique', False)),
          'ray_groups_per_wave': ray_groups(dev, core), **grids(core),
          **({'world_build_seconds': core.build_seconds} if hasattr(core, 'build_seconds') else {})}
     if one_launch:
@@ -689,7 +691,6 @@ def shape_entry(dev, core, steps, warmup, fields=None, note=None, one_launch=Fal
         e['step'] = 'ms_step_render (physics + render of an env as one wave: one launch a step); render_launch_ms is the whole step'
         # (the one launch does both halves' work: its algorithmic bytes are the step's)
         e['roofline_frac'] = (rb + pb)/(render_ms*1e-3)/1e9/HBM_PEAK_GBPS
-        e.pop('traffic', None); e.pop('frac_measured', None); e.pop('step_traffic', None); e.pop('step_measured_GBps', None)
     if note:
         e['note'] = note
     return e
@@ -748,6 +749,7 @@ def other_shapes(dev, steps=20, warmup=5):
     del c
     torch.cuda.empty_cache()
     c = world('headline, oblique plans', 4096, 4, 64, 130., n_unique=plan_count(4096, 4), oblique=True)
+    c.oblique = True
     out['headline_oblique'] = shape_entry(dev, c, steps, warmup, note="the headline shape on floorplans turned by seeded angles, with diagonal partitions "
                                           "(cubicasa.sample(oblique=True)): the reference's walls are exteriors of arbitrary SVG polygons "
                                           "(geometry.py:43-57), the synthetic generator's are axis-aligned - same plan count as the headline")

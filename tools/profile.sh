@@ -23,7 +23,7 @@ import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument('--envs', type=int, default=4096); ap.add_argument('--agents', type=int, default=4); ap.add_argument('--res', type=int, default=64)
 ap.add_argument('--large', action='store_true'); ap.add_argument('--depth-only', action='store_true')
-ap.add_argument('--unique', type=int, default=0); ap.add_argument('--legacy-plans', action='store_true')
+ap.add_argument('--unique', type=int, default=0); ap.add_argument('--legacy-plans', action='store_true'); ap.add_argument('--one-launch', action='store_true')
 w, _ = ap.parse_known_args(shape)
 # (the world's distinct floorplans, as bench.py counts them: a profile belongs to a shape AND a plan count)
 plans = 460 if w.legacy_plans else max(1, min(w.unique, w.envs)) if w.unique else (w.envs if w.agents == 1 else max(w.envs//4, 1))
@@ -42,7 +42,7 @@ for c, f in [('FETCH_SIZE', 'fetch'), ('WRITE_SIZE', 'write')]:
 # calibrated here on physics_kernel's 16 B/lane wall stream in round 2), WRITE_SIZE (KB) as reported.
 rb = sum(2*1024*res['FETCH_SIZE'].get(k, 0) + 1024*res['WRITE_SIZE'].get(k, 0) for k in ('render_kernel', 'render_prep_kernel', 'dynlight_kernel'))
 pb = 2*1024*res['FETCH_SIZE'].get('physics_kernel', 0) + 1024*res['WRITE_SIZE'].get('physics_kernel', 0)
-traffic = {'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large, 'depth_only': w.depth_only, 'plans': plans}, 'shape': tag,
+traffic = {'workload': {'envs': w.envs, 'agents': w.agents, 'res': w.res, 'large': w.large, 'depth_only': w.depth_only, 'plans': plans, **({'one_launch': True} if w.one_launch else {})}, 'shape': tag,
            'render_bytes_per_launch': rb, 'physics_bytes_per_launch': pb, 'raw_counters_KB': res,
            'kernel_us': {re.search(r'((?:render|physics)_kernel<[^>]*>)', r.Name).group(1): r.AverageNs/1e3
                          for r in st.itertuples() if re.search(r'(?:render|physics)_kernel<', r.Name)},
