@@ -368,7 +368,7 @@ def cpu_baselines(core, budget_s=8.):
     # ... and the same step on EVERY host core (north_star: "the box's own host cores"), once, in a process of its
     # own with a deadline - in round 3 the 256-thread pool turned one step into minutes, which this run cannot afford to wait for
     if usable > threads:
-        out['cpu_baseline']['all_cores'] = _torch_step_all_cores(core, usable, min(n, 64))
+        out['cpu_baseline']['all_cores'] = _torch_step_all_cores(core, usable, min(n, 16))
 
     n, scene, agents = _oracle_sample(core, 4096)
     scene = O.Scene(scene)
@@ -411,7 +411,7 @@ print('RESULT', steps, time.perf_counter() - t0, flush=True)
 """
 
 
-def _torch_step_all_cores(core, threads, n, deadline_s=40.):
+def _torch_step_all_cores(core, threads, n, deadline_s=25.):
     """The pure-PyTorch step with torch.set_num_threads(every usable core) on the first `n` envs, in a subprocess that is given
     `deadline_s` seconds: its rate, or the statement that it did not get there."""
     import pickle
