@@ -356,6 +356,11 @@ __host__ __device__ inline void ray_interval(float xa, float ya, float xb, float
 // LDS back the moment it is done instead of waiting for the slowest of four.
 // OBS = 1: any of the five per-ray outputs may be NULL, and pooled observations are written on request (the plain
 // instantiation stays within 80 VGPRs: six waves per SIMD)
+// OBS = 2 (round 6, with SHADE = 1): NONE of the five per-ray planes is wanted - only what the OBS = 1 epilogue can write besides
+// them: pooled RGB-D, crosshair ids, first-sight books.  It is what both demo envs ask for (`modules.render(core, observers=...,
+// fields=())`), every step, and in the OBS = 1 instantiation it was a question asked of five pointers per group of rays - a scalar
+// load and a wait each - plus the staging of `screen` through LDS behind a branch, in a kernel of 150 spilled scalars: here the
+// plane stores, their pointers and the staging are not in the kernel at all.
 // SHADE = 0 (with OBS = 1): the caller wants no colour - neither `screen` nor pooled RGB (modules.Depth reads distances
 // only, reference modules.py:170-184; BASELINE config 2 is depth-only).  Pass 3 is then not in the kernel at all: no
 // texel row, no texel and baked-light gathers, no filter, no dynamic lighting of rays that landed on an agent - and the
@@ -674,6 +679,8 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     // it; they are CALLED at the wave's end, and it is there that they read their kernel arguments: see RenderArgs.)
     constexpr bool COLOUR = SHADE != 0;
     static_assert(COLOUR || OBS == 1, "without colour `screen` is NULL: the OBS instantiation");
+    static_assert(OBS != 2 || (COLOUR && IMPL == 2 && STEP == 0), "no per-ray planes at all: a colour instantiation of the product raycast");
+    constexpr bool PLANES = OBS != 2;            // (some per-ray plane may be wanted)
     // (is an optional output wanted?  colourless: a bit of the mask ms_render left in obs_subsample's upper half; else the pointer)
     // (round 6, MS_OBS_MASK: the colour instantiation with optional outputs - pooled RGB-D, crosshair ids - of ONE ray group a wave
     // asks the mask too: a whole env.step() at the headline shape 41.85 -> 41.56 us per step, two passes each way on one box; the
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
 #ifndef MS_OBS_MASK
 #define MS_OBS_MASK 1
 #endif
-    constexpr bool MASKED = !COLOUR || (MS_OBS_MASK != 0 && OBS == 1 && IMPL == 2 && NG == 1);   // (the A/B builds' older raycasts ask the pointers)
+    constexpr bool MASKED = !COLOUR || (MS_OBS_MASK != 0 && OBS >= 1 && IMPL == 2 && NG == 1);   // (the A/B builds' older raycasts ask the pointers)
     [[maybe_unused]] const int out_mask_ = MASKED ? (out.obs_subsample >> 8) : 0;
 #define MS_WANTED(BIT, PTR) (MASKED ? ((out_mask_ & (BIT)) != 0) : ((PTR) != nullptr))
     // what depends on the winner's number alone: its row, its texel count and first texel
@@ -724,9 +731,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             dt = div_inrange(dtop, dbot + 1.e-6f);
         }
     }
-    const size_t o = ((size_t)n*A + a)*R + r;
+    [[maybe_unused]] const size_t o = ((size_t)n*A + a)*R + r;
     const float dist = nearest_s*rlen;
-    {
+    if constexpr (PLANES) {
         if (!MASKED || (out_mask_ & (OUT_INDICES | OUT_LOCATIONS | OUT_DOTS | OUT_DISTANCES))) {      // (uniform)
             int* const o_indices = late->out.indices;
             float* const o_locations = late->out.locations;
@@ -795,7 +802,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         tl0 = tl[0]; tl1 = tl[1]; tl2 = tl[2]; tr0 = tr[0]; tr1 = tr[1]; tr2 = tr[2];
         if (is_hit & !dynamic) intensity = f.lw*bk_l + f.rw*bk_r;
     }
-    if constexpr (OBS == 1) {
+    if constexpr (OBS >= 1) {
         if (MS_WANTED(OUT_SEEN, late->out.seen_stamp)) {           // explorer.py:34-58: which texels are seen for the first time
             bool fresh = false, fresh_last = false;
             const int last_env = sc.n_envs - 1;
@@ -843,6 +850,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             s1 = dn*intensity*(f.lw*tl1 + f.rw*tr1);
             s2 = dn*intensity*(f.lw*tl2 + f.rw*tr2);
         }
+        if constexpr (PLANES) {
         float* const o_screen = late->out.screen;
         if (!OBS || MS_WANTED(OUT_SCREEN, o_screen)) {
             // stage RGB through LDS so the (R, 3) rows leave as three fully coalesced 256 B stores
@@ -857,6 +865,7 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
                 const int j = lane + k*WAVE;
                 if (j < nfl) MS_OUT_STORE(s_screen_w[j], &scr[j]);
             }
+        }
         }
     }
     // ---- pooled observations (modules.py:138-145,170-184,211-224): the mean over `sub` adjacent rays of the colour
