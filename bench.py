@@ -657,7 +657,7 @@ def grids(core):
     for k in ('wall_grid', 'light_grid'):
         r = rep.get(k)
         if r:
-            out[k] = {kk: r[kk] for kk in ('bytes', 'cell', 'cells', 'floorplans', 'coarsened', 'candidate_rows', 'budget', 'vis_entries', 'near_rows') if kk in r}
+            out[k] = {kk: r[kk] for kk in ('bytes', 'bytes_per_floorplan', 'cell', 'cells', 'floorplans', 'coarsened', 'candidate_rows', 'budget', 'vis_entries', 'near_rows') if kk in r}
     if rep.get('bake_seconds'):
         out['bake_seconds'] = rep['bake_seconds']                        # (one-off: ms_bake with its light grid; the wall grid's levels)
     return out

@@ -79,6 +79,11 @@ float ms_host_wall_reach(const float* agent, float agent_radius);
 /* Host instantiation of the scan's test, for CPU tests: does wall o = (ax, ay, bx, by) hide wall w from every point of
  * the cell [x0, x1] x [y0, y1] (as ms_wallgrid_scan grows it) for near planes below `near_plane`? */
 int ms_host_wall_hidden(float x0, float y0, float x1, float y1, const float* o, const float* w, float near_plane);
+/* The scan's sort of a cell's occluders into sectors of directions (wallgrid_scan_kernel, WG_SECTORS): the run of sectors
+ * [first, first + count) modulo 64 that occluder o touches as seen from the centre of the cell [x0, x1] x [y0, y1], and the one
+ * sector target w's middle lies in - a target is only tried against the occluders of its sector, so whenever ms_host_wall_hidden
+ * says o hides w from the cell, `sector` must be in o's run (tests/test_wallgrid.py). */
+void ms_host_wall_sectors(float x0, float y0, float x1, float y1, const float* o, int* first, int* count, const float* w, int* sector);
 /* ... and of the scan of one whole cell (c, row-major in a grid of nx x ny cells of size `cell` from (ox, oy)) over
  * n_walls walls (n_walls x 4 floats, HOST memory): vis[t] = 1 where wall t goes on the cell's vis list, close[t] = 2 / 1
  * where it is within reach_lo / reach of the cell. */

@@ -83,7 +83,7 @@ class MsExplorer(C.Structure):
 SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_last_render_groups', 'ms_debug_last_step_fused', 'ms_step_render', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics', 'ms_deathmatch_shoot', 'ms_explorer_books',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
-           'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
+           'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wall_sectors', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
            'ms_host_wedge_meets', 'ms_host_agents_apart', 'ms_host_wall_beyond_reach', 'ms_host_ray_interval', 'ms_host_fold_hits', 'ms_host_lightgrid_cell', 'ms_host_wall_reach')
 
 
@@ -181,6 +181,8 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_void_p]
         handle.ms_wallgrid_fill.argtypes = [C.POINTER(MsScenery), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        handle.ms_host_wall_sectors.argtypes = [C.c_float]*4 + [_f32p, _i32p, _i32p, _f32p, _i32p]
+        handle.ms_host_wall_sectors.restype = None
         handle.ms_host_wall_arc.argtypes = [C.c_float]*4 + [_f32p, _i32p, _i32p]
         handle.ms_host_wall_arc.restype = None
         handle.ms_host_wedge_meets.argtypes = [C.c_float]*4 + [C.c_int, C.c_int]

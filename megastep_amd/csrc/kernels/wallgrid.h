@@ -183,6 +183,35 @@ __host__ __device__ inline void wg_arc(const WgCell& k, const float4 w, int& lo8
 // time, results OR-ed into the cells' bitmaps (one bit per wall; rows: vis, near within wg_reach_lo, near beyond that)
 // and counted once the group is through.
 constexpr int WG_GROUP = 4, WG_STAGE = 2048, WG_ROWS = 3;
+// Round 6: which occluders a target wall is tried against.  Until then a wall that stays visible met every staged occluder - a
+// hundred of them on a large plan, for two hundred candidates, for each of 51 million cells: 16 of the 17 seconds C5's share takes
+// to build (profiles/r05_c5_kernel_stats.csv).  But O can only hide W from the cell if every segment from the cell to W crosses it
+// (above) - the one from the cell's centre to W's middle among them: O must SPAN THE DIRECTION in which W's middle lies from the
+// cell's centre.  So per cell the occluders are sorted into WG_SECTORS sectors of directions around its centre - each into every
+// sector its own span touches, widened by WG_SECTOR_MARGIN (in pseudo-angle units: a full turn is 4; the margin is 10^4 roundings
+// wide) - and a target meets the occluders of the ONE sector its middle lies in: half a dozen.  An exact cull of the loop, not of
+// the lists: the bits come out as they did (tests/test_gpu_wallgrid.py holds them against the host's unsorted scan).  Lists that
+// overflow WG_SECTOR_CAP (a cell hemmed in by hundreds of long walls) fall back to meeting every occluder.
+constexpr int WG_SECTORS = 64, WG_SECTOR_CAP = 4096;
+constexpr float WG_SECTOR_MARGIN = 0.02f;
+// the run of sectors [first, first + count) (modulo WG_SECTORS) that wall o's directions from (cx, cy) touch; all of them where the
+// span is half a turn or more, or undefined (a wall through the centre, NaNs)
+__host__ __device__ inline void wg_sectors_of(const float cx, const float cy, const float4 o, int& first, int& count) {
+    const float pa = pseudo_angle(o.x - cx, o.y - cy), pb = pseudo_angle(o.z - cx, o.w - cy);
+    float d = pb - pa;                                                   // from a to b, the short way round
+    d = d > 2.f ? d - 4.f : (d <= -2.f ? d + 4.f : d);
+    const float lo = (d >= 0.f ? pa : pb) - WG_SECTOR_MARGIN, span = fabsf(d) + 2.f*WG_SECTOR_MARGIN;
+    first = 0; count = WG_SECTORS;
+    if (!(span < 1.9f) || !(lo == lo)) return;
+    const float scale = WG_SECTORS/4.f;
+    const int s0 = (int)floorf(lo*scale), s1 = (int)floorf((lo + span)*scale);
+    first = s0 & (WG_SECTORS - 1);
+    count = min(s1 - s0 + 1, WG_SECTORS);
+}
+__host__ __device__ inline int wg_sector_of(const float cx, const float cy, const float4 w) {
+    const float p = pseudo_angle(.5f*(w.x + w.z) - cx, .5f*(w.y + w.w) - cy);
+    return (p == p) ? ((int)floorf(p*(WG_SECTORS/4.f)) & (WG_SECTORS - 1)) : 0;   // (a NaN wall is hidden by nothing: any sector will do)
+}
 
 struct WgParent { const unsigned* cells; const int* starts; const float* geom; float cell; const unsigned short* pool; };
 
@@ -192,6 +221,8 @@ __global__ __launch_bounds__(WG) void wallgrid_scan_kernel(const MsScenery sc, c
     __shared__ float4 s_occ[WG_STAGE];
     __shared__ unsigned short s_occ_id[WG_STAGE];
     __shared__ int s_n_occ;
+    __shared__ int s_sect_at[WG_SECTORS + 1], s_sect_fill[WG_SECTORS];   // where each sector's list starts (an exclusive scan: [s] .. [s + 1]), how far it is filled
+    __shared__ unsigned short s_sect[WG_SECTOR_CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = reps[blockIdx.y];
     const float4 geom = reinterpret_cast<const float4*>(sc.wg_geom)[n];
@@ -240,21 +271,74 @@ __global__ __launch_bounds__(WG) void wallgrid_scan_kernel(const MsScenery sc, c
     const int n_occ = min(s_n_occ, WG_STAGE);
     const int W32 = (n_walls + 31) >> 5;
     unsigned* __restrict__ rows = bits + bits_starts[n];
-    // vis: lane = candidate, every staged occluder in turn (uniform LDS reads)
+    // vis: cell after cell of the group - its occluders sorted into sectors of directions (see WG_SECTORS), then lane = candidate,
+    // 64 to a wave, each against the occluders of the sector its middle lies in
     const int vis_chunks = (n_vis + WAVE - 1)/WAVE;
-    for (int item = wave; item < n_group*vis_chunks; item += WAVES) {
-        const int j = item/vis_chunks, i = (item - j*vis_chunks)*WAVE + lane;
+#ifndef MS_WG_SECTORS
+#define MS_WG_SECTORS 1                                                  // (0: every target meets every occluder, as until round 6 - the A/B)
+#endif
+    for (int j = 0; j < n_group; j++) {
         const int c = cell_of(j);
-        const bool live = i < n_vis;
-        const int id = cand_vis ? (int)cand_vis[min(i, n_vis - 1)] : min(i, n_vis - 1);
         const WgCell k = wg_cell_of(geom, sc.wg_cell, c);
-        const WgTarget tg = wg_target(k, ln[id]);
-        bool hidden = !live;
-        for (int o = 0; o < n_occ; o++) {
-            if (__all(hidden)) break;
-            if (((int)s_occ_id[o] != id) && wg_hides(k, tg, s_occ[o], sc.wg_near)) hidden = true;
+        const float cx = .5f*(k.x0 + k.x1), cy = .5f*(k.y0 + k.y1);
+        bool sorted = false;
+        if (MS_WG_SECTORS && n_occ > 16) {
+            if (tid <= WG_SECTORS) s_sect_at[tid] = 0;
+            if (tid < WG_SECTORS) s_sect_fill[tid] = 0;
+            __syncthreads();
+            for (int o = tid; o < n_occ; o += WG) {
+                int first, count;
+                wg_sectors_of(cx, cy, s_occ[o], first, count);
+                for (int t = 0; t < count; t++) atomicAdd(&s_sect_at[1 + ((first + t) & (WG_SECTORS - 1))], 1);
+            }
+            __syncthreads();
+            if (wave == 0) {                                             // counts -> where each sector's list starts
+                const int n_ = s_sect_at[1 + lane];
+                const int incl = wave_scan_add(n_);
+                __builtin_amdgcn_wave_barrier();
+                s_sect_at[1 + lane] = incl;
+            }
+            __syncthreads();
+            sorted = s_sect_at[WG_SECTORS] <= WG_SECTOR_CAP;              // (uniform: every thread reads the same word)
+            if (sorted) {
+                for (int o = tid; o < n_occ; o += WG) {
+                    int first, count;
+                    wg_sectors_of(cx, cy, s_occ[o], first, count);
+                    for (int t = 0; t < count; t++) {
+                        const int sct = (first + t) & (WG_SECTORS - 1);
+                        s_sect[s_sect_at[sct] + atomicAdd(&s_sect_fill[sct], 1)] = (unsigned short)o;
+                    }
+                }
+            }
+            __syncthreads();
         }
-        if (!hidden) atomicOr(&rows[(long long)(WG_ROWS*c)*W32 + (id >> 5)], 1u << (id & 31));
+        for (int chunk = wave; chunk < vis_chunks; chunk += WAVES) {
+            const int i = chunk*WAVE + lane;
+            const bool live = i < n_vis;
+            const int id = cand_vis ? (int)cand_vis[min(i, n_vis - 1)] : min(i, n_vis - 1);
+            const float4 w = ln[id];
+            const WgTarget tg = wg_target(k, w);
+            bool hidden = !live;
+            if (sorted) {
+                const int sct = wg_sector_of(cx, cy, w);
+                int q = s_sect_at[sct];
+                const int q_end = s_sect_at[sct + 1];
+                while (__ballot(!hidden & (q < q_end))) {
+                    if (!hidden & (q < q_end)) {
+                        const int o = (int)s_sect[q];
+                        if (((int)s_occ_id[o] != id) && wg_hides(k, tg, s_occ[o], sc.wg_near)) hidden = true;
+                    }
+                    q++;
+                }
+            } else {
+                for (int o = 0; o < n_occ; o++) {
+                    if (__all(hidden)) break;
+                    if (((int)s_occ_id[o] != id) && wg_hides(k, tg, s_occ[o], sc.wg_near)) hidden = true;
+                }
+            }
+            if (!hidden) atomicOr(&rows[(long long)(WG_ROWS*c)*W32 + (id >> 5)], 1u << (id & 31));
+        }
+        if (MS_WG_SECTORS && n_occ > 16) __syncthreads();                 // (the next cell sorts into the same lists)
     }
     // near: lane = candidate
     const int near_chunks = (n_near + WAVE - 1)/WAVE;

@@ -384,6 +384,11 @@ void ms_host_wallgrid_cell(const float* walls, int n_walls, float ox, float oy, 
     }
 }
 
+void ms_host_wall_sectors(float x0, float y0, float x1, float y1, const float* o, int* first, int* count, const float* w, int* sector) {
+    const float cx = .5f*(x0 + x1), cy = .5f*(y0 + y1);
+    wg_sectors_of(cx, cy, make_float4(o[0], o[1], o[2], o[3]), *first, *count);
+    *sector = wg_sector_of(cx, cy, make_float4(w[0], w[1], w[2], w[3]));
+}
 void ms_host_wall_arc(float x0, float y0, float x1, float y1, const float* w, int* lo8, int* hi8) {
     wg_arc(WgCell{x0, y0, x1, y1}, make_float4(w[0], w[1], w[2], w[3]), *lo8, *hi8);
 }

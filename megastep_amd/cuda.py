@@ -590,7 +590,8 @@ class Scenery:
                 size = sum(t.numel()*t.element_size() for t in (hdr, starts, geom, pool, near, pool_base))
                 arange = torch.arange(len(ln), device=hdr.device)
                 reps = int((usable & ((self._geom.long() if self._geom is not None else arange) == arange)).sum())
-                self._wg_report = dict(bytes=size, cell=float(cell), cells=int(hdr.shape[0] - 1), envs=int(usable.sum()), floorplans=reps,
+                self._wg_report = dict(bytes=size, bytes_per_floorplan=size/max(reps, 1), cell=float(cell), cells=int(hdr.shape[0] - 1),
+                                       envs=int(usable.sum()), floorplans=reps,
                                        vis_entries=int(pool.numel() - 64), near_rows=int(near.shape[0] - 1), budget=self._wall_grid_budget(),
                                        coarsened=cell != self.WALL_GRID_CELL)
                 if os.environ.get('MEGASTEP_VERBOSE') or cell != self.WALL_GRID_CELL:

@@ -190,6 +190,43 @@ def test_one_wall_hides_another_only_when_it_really_does():
     assert not hidden(cell, wide, (4., -.5, 4., -.5 + 1e-30))
 
 
+@pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'large', 'plan7', 'oblique0', 'oblique2_mutated', 'obliquelarge'])
+def test_an_occluder_spans_the_direction_of_what_it_hides(name):
+    """The scan's sort of a cell's occluders into sectors of directions (wallgrid_scan_kernel, WG_SECTORS, round 6): a target wall
+    is only tried against the occluders of the ONE sector its middle lies in, seen from the cell's centre. That is exact if every
+    occluder that hides a wall from the cell (wg_hides: every segment from the cell to the wall crosses it) has that sector in its
+    own run - checked here for every (occluder, wall) pair of sampled cells of the case floorplans, cells of both levels of the
+    build, the library's own predicates on both sides; and the sort is worth having: a wall's sector holds a fraction of the
+    occluders."""
+    walls = case_walls(name)
+    flat = np.ascontiguousarray(walls.reshape(-1, 4), np.float32)
+    rng = np.random.RandomState(9)
+    lib = _lib.lib()
+    hides = tried = in_sector = 0
+    for cell in (CELL, 4*CELL):
+        origin, dims = grid_of(walls, cell)
+        for c in rng.choice(dims[0]*dims[1], min(6 if name.endswith('large') else 14, dims[0]*dims[1]), replace=False):
+            x0, y0 = float(origin[0] + (c % dims[0])*cell - .01), float(origin[1] + (c//dims[0])*cell - .01)
+            x1, y1 = x0 + cell + .02, y0 + cell + .02
+            pick = rng.choice(len(flat), min(len(flat), 120), replace=False)
+            for o in pick:
+                oc = (C.c_float*4)(*flat[o])
+                for w in pick:
+                    if w == o:
+                        continue
+                    wc = (C.c_float*4)(*flat[w])
+                    first, count, sector = C.c_int(), C.c_int(), C.c_int()
+                    lib.ms_host_wall_sectors(x0, y0, x1, y1, oc, C.byref(first), C.byref(count), wc, C.byref(sector))
+                    inside = (sector.value - first.value) % 64 < count.value
+                    tried += 1
+                    in_sector += inside
+                    if lib.ms_host_wall_hidden(x0, y0, x1, y1, oc, wc, NEAR):
+                        hides += 1
+                        assert inside, (name, cell, int(c), flat[o], flat[w], first.value, count.value, sector.value)
+    assert hides > 500, hides
+    assert in_sector < .35*tried, f'{in_sector/tried:.2f} of the (occluder, wall) pairs share a sector: the sort buys nothing'
+
+
 @pytest.mark.parametrize('name', ['plan0', 'plan2_mutated', 'large', 'box', 'oblique1', 'oblique2_mutated', 'obliquelarge'])
 def test_a_wall_is_only_ever_seen_inside_its_arc(name):
     """The view arcs the vis entries carry (wg_arc) and the test the render kernel makes with them (wg_wedge,
