@@ -38,6 +38,12 @@ def crosshair_matrix(line_indices, n_model, n_agents, subsample):
     return (seen_agent[..., None] == everyone).any(-2)
 
 
+def _plan_workers():
+    """Processes that generate the floorplans nobody handed over (numpy-only subprocesses: safe beside an initialised GPU)."""
+    import os
+    return min(os.cpu_count() or 1, 32)
+
+
 class Deathmatch:
 
     def __init__(self, n_envs, n_agents, *args, device='cuda', geometries=None, fused=None, **kwargs):
@@ -47,7 +53,7 @@ class Deathmatch:
         (:func:`megastep_amd.cuda.deathmatch_shoot`) instead of some twenty tensor ops; ``False`` keeps the tensor ops,
         which are the same arithmetic and what the CPU-side tests pin against the reference's own methods."""
         if geometries is None:
-            geometries = cubicasa.sample(max(n_envs//4, 1))
+            geometries = cubicasa.sample(max(n_envs//4, 1), workers=_plan_workers(), context='subprocess')
         self.core = core.Core(scene.scenery(geometries, n_agents, device=device), *args, res=4*128, fov=70, **kwargs)
         c = self.core
         self.device, self.n_envs = c.device, c.n_envs*c.n_agents

@@ -24,6 +24,12 @@ def texels_hit(scenery, frame):
     return torch.where(hit, texel, torch.full_like(texel, -1))
 
 
+def _plan_workers():
+    """Processes that generate the floorplans nobody handed over (numpy-only subprocesses: safe beside an initialised GPU)."""
+    import os
+    return min(os.cpu_count() or 1, 32)
+
+
 class SeenTexels:
     """Which texels each env has seen since its last respawn, and how many.
 
@@ -71,7 +77,7 @@ class Explorer:
         (:func:`megastep_amd.cuda.explorer_books`) instead of a dozen tensor ops; ``False`` keeps the tensor ops, the same
         arithmetic."""
         if geometries is None:
-            geometries = cubicasa.sample(n_envs)
+            geometries = cubicasa.sample(n_envs, workers=_plan_workers(), context='subprocess')       # (4096 plans: 3 s on worker processes, 30 in this one)
         self.core = core.Core(scene.scenery(geometries, 1, device=device), *args, res=4*64, fov=130, **kwargs)
         c = self.core
         self.device = c.device

@@ -79,6 +79,11 @@ def test_c5_per_gpu_shape_on_the_references_floorplan_diversity():
     device's memory; rounds 3-4's flat 8 GiB sent this world to 1 m cells). A sample of envs from both ends of the pool against
     the oracle: the entries past the 2^32nd are the ones the last envs' rays walk."""
     from megastep_amd import cuda
+    free, total = torch.cuda.mem_get_info()
+    if total < 140 << 30 or free < 110 << 30:
+        # (the un-coarsened grid of this world is 35 GB, twice that while it is built, under a budget of a quarter of the device:
+        # on a smaller GPU - or a busy one - the grid coarsens itself, which is right, and not what this test is about; ADVICE r5)
+        pytest.skip(f'needs an idle GPU of 140 GB or more: this one has {total >> 30} GB, {free >> 30} free')
     c, geoms, t = _big_world(32768, 1, 256, 130, n_distinct=4096, large=True, fast=True)
     rep = c.scenery.grid_report()['wall_grid']
     print('C5 / 4096 plans timings (s):', t, 'wall grid:', rep)
