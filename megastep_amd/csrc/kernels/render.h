@@ -1,4 +1,4 @@
-// kernels/render.h -- render_prep_kernel, render_kernel<IMPL, RW, OBS, SHADE, NG>, dynlight_kernel.
+// kernels/render.h -- render_prep_kernel, render_kernel<IMPL, RW, OBS, SHADE, NG, STEP>, dynlight_kernel.
 // Part of megastep_hip.hip's one translation unit (included there, inside its anonymous namespace, in this order: math,
 // physics, lighting, render, bake, wallgrid); not a header to compile on its own.
 // ------------------------------------------------------------------------------------------------

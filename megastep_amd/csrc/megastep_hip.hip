@@ -15,7 +15,9 @@
 //                   agent's sin/cos for the renderer.  MOVE = 1 runs the movement modules' velocity update first,
 //                   EXTRA = 1 the envs' respawn / lifespan / IMU bookkeeping.
 //                                                            (reference: kernels.cu:179-230, modules.py:24-118,263-366)
-//   render_kernel<IMPL, RW, OBS, SHADE, NG>   one wavefront per (env, agent, 64-ray group) - or, NG = 4, per four such groups
+//   render_kernel<IMPL, RW, OBS, SHADE, NG, STEP>   (OBS = 2: pooled observations only, no plane stores in the kernel; STEP = 1: a
+//                   single-agent env's physics step first, in the same wave - ms_step_render's one launch a step)
+//                   one wavefront per (env, agent, 64-ray group) - or, NG = 4, per four such groups
 //                   that share one list of lines, the launch's last envs left to one-group waves (256 rays and up on large
 //                   launches; SHADE = 0: no shading pass, for callers that want no colour).  The lines it meets: the other agents'
 //                   and the walls on the vis list of the agent's cell of the wall grid, less those whose view arc misses
