@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MS_ABI_VERSION 15
+#define MS_ABI_VERSION 16
 
 #define MS_OK            0
 #define MS_EINVAL       -1   /* bad argument (null pointer, non-positive size, ...) */
@@ -275,6 +275,11 @@ int ms_render(const MsScenery* scenery, const MsAgents* agents, const MsRender* 
  * ms_render, as if the caller had made the two calls.  Same results as the two calls, bit for bit, either way. */
 int ms_step_render(const MsScenery* scenery, const MsAgents* agents, float* progress, const MsRender* out,
                    const MsConfig* config, void* hip_stream);
+/* ... with the movement prologue and the env's bookkeeping of ms_step_physics around the step (either may be NULL): a whole
+ * env.step() of a single-agent env of up to 64 rays - the reference's tutorial env, demo/envs/minimal.py: SimpleMovement, physics,
+ * render - is then one launch. */
+int ms_move_step_render(const MsScenery* scenery, const MsAgents* agents, const MsMovement* movement, const MsStepExtras* extras,
+                        float* progress, const MsRender* out, const MsConfig* config, void* hip_stream);
 
 /* What the reference's Deathmatch env does between one frame and the next - `_reset` + `_shoot` + the `health` observation,
  * megastep/demo/envs/deathmatch.py:46-88: some twenty tensor ops on (N, A) tensors - as one element-wise launch behind

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 # MEGASTEP_HIP_LIB points at an alternative build of the same ABI (A/B experiments); default is the in-tree build
 LIB_PATH = os.environ.get('MEGASTEP_HIP_LIB') or os.path.join(CSRC, 'libmegastep_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int)
@@ -80,7 +80,7 @@ class MsExplorer(C.Structure):
 
 
 #: every symbol include/megastep_hip.h (the boundary) and include/megastep_hip_test.h (test hooks) declare
-SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_last_render_groups', 'ms_debug_last_step_fused', 'ms_step_render', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
+SYMBOLS = ('ms_host_ray_interval_wide', 'ms_debug_ray_groups', 'ms_debug_last_render_groups', 'ms_debug_last_step_fused', 'ms_step_render', 'ms_move_step_render', 'ms_debug_ray_group_tail', 'ms_debug_physics_pack', 'ms_host_render_plan', 'ms_host_render_block', 'ms_host_physics_pack', 'ms_debug_pair_telemetry', 'ms_test_arithmetic', 'ms_abi_version', 'ms_strerror', 'ms_last_hip_error', 'ms_device_count', 'ms_bake', 'ms_physics', 'ms_move_physics',
            'ms_step_physics', 'ms_deathmatch_shoot', 'ms_explorer_books',
            'ms_render', 'ms_host_sincospi', 'ms_host_bake_point_bin', 'ms_host_bake_wall_bins',
            'ms_wallgrid_scan', 'ms_wallgrid_fill', 'ms_host_wall_hidden', 'ms_host_wall_sectors', 'ms_host_wallgrid_cell', 'ms_host_wall_arc',
@@ -165,6 +165,9 @@ def lib():
                                            C.c_void_p, C.POINTER(MsConfig), C.c_void_p]
         handle.ms_step_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.c_void_p, C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]
         handle.ms_step_render.restype = C.c_int
+        handle.ms_move_step_render.argtypes = [C.POINTER(MsScenery), C.POINTER(MsAgents), C.POINTER(MsMovement), C.POINTER(MsStepExtras),
+                                               C.c_void_p, C.POINTER(MsRender), C.POINTER(MsConfig), C.c_void_p]
+        handle.ms_move_step_render.restype = C.c_int
         handle.ms_debug_last_step_fused.argtypes = []
         handle.ms_debug_last_step_fused.restype = C.c_int
         handle.ms_explorer_books.argtypes = [C.c_int, C.POINTER(MsExplorer), C.c_void_p]

@@ -137,6 +137,8 @@ struct RenderConstsStep : RenderConsts {
     float fps;
     const unsigned* wg_cells_physics;   // the wall grid's cell headers as ms_step_physics would be given them (ms_render's copy of the scenery
                                         // drops them when the call's near plane / field of view is outside what the vis lists were built for)
+    MsMovement mv;                 // ms_step_physics' optional prologue and bookkeeping, as it takes them (all-NULL structs: none)
+    MsStepExtras ex;
 };
 // Which of MsRender's optional outputs are there, as bits - for the COLOURLESS instantiations, which ask a scalar register the
 // wave has had since its first instruction whether an output is wanted and only fetch a pointer from the kernel-argument segment
@@ -515,8 +517,58 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     if constexpr (STEP == 1) {
         // ---- the env's physics step (physics_kernel for its one agent, kernels.cu:179-230), every lane with the agent's state,
         // lane = wall for the tests.  Same functions, same operations in the same order as physics_kernel: the same bits.
-        const float2 p_ = reinterpret_cast<const float2*>(ag.positions)[n], v_ = reinterpret_cast<const float2*>(ag.velocity)[n];
-        const float w_ = ag.angvelocity[n], ang_ = ag.angles[n];
+        float2 p_ = reinterpret_cast<const float2*>(ag.positions)[n], v_ = reinterpret_cast<const float2*>(ag.velocity)[n];
+        float w_ = ag.angvelocity[n], ang_ = ag.angles[n];
+        // ---- what ms_step_physics runs around the step (MsStepExtras, MsMovement; physics_kernel<MOVE, EXTRA>), for this one agent,
+        // statement for statement in its order; every lane works the same values out, lane 0 writes (uniform branches: a caller
+        // that hands over neither pays two scalar compares)
+        const MsStepExtras& ex = rc.ex;
+        const MsMovement& mv = rc.mv;
+        bool respawn_now = false;
+        float2 spawn_p = make_float2(0.f, 0.f);
+        float spawn_ang = 0.f;
+        if (ex.respawn_mask || ex.lifespans) {                               // modules.py:361-366, :312-326
+            bool reset = ex.respawn_mask && ex.respawn_mask[n];
+            if (ex.lifespans) {
+                int life = ex.lifespans[n] + 1;
+                reset = reset | (life >= ex.max_lifespans[n]);
+                const int fresh = ex.fresh_max[n];
+                __builtin_amdgcn_wave_barrier();                                 // (every lane has read before lane 0 writes)
+                if (lane == 0) {
+                    if (reset) ex.max_lifespans[n] = fresh;
+                    ex.lifespans[n] = reset ? 0 : life;
+                    if (ex.respawn_mask) ex.respawn_mask[n] = reset ? 1 : 0;
+                }
+            }
+            if (reset && ex.spawn_positions) {
+                const long long c_ = min(max(ex.respawn_choice[n], 0ll), (long long)ex.n_spawns - 1);
+                spawn_p = reinterpret_cast<const float2*>(ex.spawn_positions)[(size_t)n*ex.n_spawns + c_];
+                spawn_ang = ex.spawn_angles[(size_t)n*ex.n_spawns + c_];
+                respawn_now = true;
+                if (!ex.respawn_after) {
+                    p_ = spawn_p; ang_ = spawn_ang; v_ = make_float2(0.f, 0.f); w_ = 0.f;
+                    if (lane == 0) {
+                        reinterpret_cast<float2*>(ag.positions)[n] = p_;
+                        ag.angles[n] = ang_;
+                        reinterpret_cast<float2*>(ag.velocity)[n] = v_;
+                        ag.angvelocity[n] = 0.f;
+                    }
+                }
+            }
+        }
+        if (mv.actions) {                                                    // modules.py:57-66,106-118
+            const long long act = min(max(mv.actions[n], 0ll), (long long)mv.n_actions - 1);
+            const float dx = mv.table[3*act], dy = mv.table[3*act + 1], dw = mv.table[3*act + 2];
+            const float a_ = 0.017453292519943295f*ang_;                     // np.pi/180*angles, in binary32 like torch
+            const float s_ = sinf(a_), c_ = cosf(a_);
+            const float gx = c_*dx - s_*dy, gy = s_*dx + c_*dy;
+            if (mv.keep == 0.f) { w_ = dw; v_ = make_float2(gx, gy); }
+            else { w_ = mv.keep*w_ + dw; v_ = make_float2(mv.keep*v_.x + gx, mv.keep*v_.y + gy); }
+            if (lane == 0) {
+                ag.angvelocity[n] = w_;
+                reinterpret_cast<float2*>(ag.velocity)[n] = v_;
+            }
+        }
         const P2 p0 = p2(p_.x, p_.y);
         const P2 v0 = p2(v_.x, v_.y)/rc.fps;
         const float reach = wall_reach(p0, v0, agent_radius);
@@ -556,17 +608,33 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
         const float x = bits_f(xb);
         // the epilogue, kernels.cu:224-227
         float2 p_new = make_float2(p_.x + x*v_.x/rc.fps, p_.y + x*v_.y/rc.fps);
-        const float turned = normalize_degrees(ang_ + x*w_/rc.fps);
+        float turned = normalize_degrees(ang_ + x*w_/rc.fps);
+        bool stopped = x < 1;
+        if (stopped) { v_ = make_float2(0.f, 0.f); w_ = 0.f; }
+        if (respawn_now && ex.respawn_after && ex.respawn_mask) {            // Explorer's order: the step first, then the new pose
+            p_new = spawn_p; turned = spawn_ang;
+            v_ = make_float2(0.f, 0.f); w_ = 0.f;
+            stopped = true;
+        }
         const float2 hsc = sincospi_called(turned/180.f);
         if (lane == 0) {
             reinterpret_cast<float2*>(ag.positions)[n] = p_new;
             ag.angles[n] = turned;
             if (ag.headings) reinterpret_cast<float4*>(ag.headings)[n] = make_float4(turned, hsc.x, hsc.y, 0.f);
-            if (x < 1) {
-                reinterpret_cast<float2*>(ag.velocity)[n] = make_float2(0.f, 0.f);
-                ag.angvelocity[n] = 0.f;
+            if (stopped) {
+                reinterpret_cast<float2*>(ag.velocity)[n] = v_;
+                ag.angvelocity[n] = w_;
             }
             rc.progress[n] = x;
+        }
+        if (ex.imu) {                                                        // modules.py:263-270, to_local_frame :24-31
+            const float a_ = 0.017453292519943295f*turned;
+            const float s_ = sinf(a_), c_ = cosf(a_);
+            if (lane == 0) {
+                ex.imu[3*n] = w_/ex.imu_ang_scale;
+                ex.imu[3*n + 1] = (c_*v_.x + s_*v_.y)/ex.imu_speed_scale;
+                ex.imu[3*n + 2] = (-s_*v_.x + c_*v_.y)/ex.imu_speed_scale;
+            }
         }
         ag_s = hsc.x; ag_c = hsc.y; ag_p = p_new;                            // the pose the rays are cast from
     } else {

@@ -437,18 +437,24 @@ int ms_wallgrid_fill(const MsScenery* sc, const int* reps, int n_reps, int max_c
     return e == hipSuccess ? MS_OK : hip_fail(e);
 }
 
+// (the optional structs of ms_step_physics / ms_move_step_render, checked alike)
+static bool step_options_ok(const MsMovement* mv, const MsStepExtras* ex) {
+    if (mv && (!mv->actions || !mv->table || mv->n_actions < 1 || !(mv->keep == mv->keep))) return false;
+    if (ex) {
+        if (ex->spawn_positions && (!ex->spawn_angles || !ex->respawn_mask || !ex->respawn_choice || ex->n_spawns < 1 ||
+                                    ((uintptr_t)ex->spawn_positions % 8))) return false;
+        if (ex->lifespans && (!ex->max_lifespans || !ex->fresh_max)) return false;
+        if (ex->imu && !(ex->imu_ang_scale == ex->imu_ang_scale && ex->imu_speed_scale == ex->imu_speed_scale)) return false;
+    }
+    return true;
+}
+
 int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, const MsStepExtras* ex, float* progress,
                     const MsConfig* cfg, void* stream) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !progress || !config_ok(cfg)) return MS_EINVAL;
-    if (mv && (!mv->actions || !mv->table || mv->n_actions < 1 || !(mv->keep == mv->keep))) return MS_EINVAL;
+    if (!step_options_ok(mv, ex)) return MS_EINVAL;
     if (sc->wg_cells && (!sc->wg_starts || !sc->wg_geom || !sc->wg_near_rows || !(sc->wg_cell > 0.f) || ((uintptr_t)sc->wg_cells % 16) ||
                          ((uintptr_t)sc->wg_geom % 16) || ((uintptr_t)sc->wg_near_rows % 16))) return MS_EINVAL;
-    if (ex) {
-        if (ex->spawn_positions && (!ex->spawn_angles || !ex->respawn_mask || !ex->respawn_choice || ex->n_spawns < 1 ||
-                                    ((uintptr_t)ex->spawn_positions % 8))) return MS_EINVAL;
-        if (ex->lifespans && (!ex->max_lifespans || !ex->fresh_max)) return MS_EINVAL;
-        if (ex->imu && !(ex->imu_ang_scale == ex->imu_ang_scale && ex->imu_speed_scale == ex->imu_speed_scale)) return MS_EINVAL;
-    }
     const int pack = physics_pack_of(sc->n_envs, sc->n_agents, sc->wg_cells != nullptr, g_physics_pack);
     // per wave: 2 float4 + a float + an unsigned per agent, rounded up to whole float4s
     const size_t slice = ((sizeof(float)*8 + sizeof(float) + sizeof(unsigned))*(size_t)sc->n_agents*pack + 15)/16;
@@ -486,7 +492,8 @@ int ms_physics(const MsScenery* sc, const MsAgents* ag, float* progress, const M
 
 // ms_render, and - with `progress` - ms_step_render's fused launch (returns MS_EUNSUPPORTED, having launched nothing, where that
 // one does not apply: the caller then makes the two calls)
-static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream, float* progress) {
+static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender* out, const MsConfig* cfg, void* stream, float* progress,
+                         const MsMovement* mv = nullptr, const MsStepExtras* ex = nullptr) {
     if (!scenery_ok(sc) || !agents_ok(ag) || !config_ok(cfg) || !out || !sc->textures_vals || !sc->textures_widths ||
         !sc->textures_starts || !sc->baked_vals || !sc->lights_widths || !sc->lights_starts) return MS_EINVAL;
     if ((out->seen_stamp != nullptr) != (out->seen_epoch != nullptr) || (out->seen_stamp != nullptr) != (out->seen_count != nullptr)) return MS_EINVAL;
@@ -616,6 +623,8 @@ static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender
         RenderConstsStep rcs;
         static_cast<RenderConsts&>(rcs) = rc;
         rcs.progress = progress; rcs.fps = cfg->fps; rcs.wg_cells_physics = sc->wg_cells;
+        rcs.mv = mv ? *mv : MsMovement{nullptr, nullptr, 0, 0.f};
+        rcs.ex = ex ? *ex : MsStepExtras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
 #define MS_LAUNCH_STEP(O, S) \
     hipLaunchKernelGGL((render_kernel<2, RW, O, S, 1, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rcs)
         if (!colour) MS_LAUNCH_STEP(1, 0); else if (obs) MS_LAUNCH_STEP(1, 1); else MS_LAUNCH_STEP(0, 1);
@@ -658,13 +667,17 @@ int ms_render(const MsScenery* sc, const MsAgents* ag, const MsRender* out, cons
     return render_launch(sc, ag, out, cfg, stream, nullptr);
 }
 
-int ms_step_render(const MsScenery* sc, const MsAgents* ag, float* progress, const MsRender* out, const MsConfig* cfg, void* stream) {
-    if (!progress) return MS_EINVAL;
-    const int fused = render_launch(sc, ag, out, cfg, stream, progress);
+int ms_move_step_render(const MsScenery* sc, const MsAgents* ag, const MsMovement* mv, const MsStepExtras* ex, float* progress,
+                        const MsRender* out, const MsConfig* cfg, void* stream) {
+    if (!progress || !step_options_ok(mv, ex)) return MS_EINVAL;
+    const int fused = render_launch(sc, ag, out, cfg, stream, progress, mv, ex);
     g_last_step_fused = fused == MS_OK ? 1 : 0;
     if (fused != MS_EUNSUPPORTED) return fused;
-    const int p = ms_step_physics(sc, ag, nullptr, nullptr, progress, cfg, stream);
+    const int p = ms_step_physics(sc, ag, mv, ex, progress, cfg, stream);
     return p != MS_OK ? p : render_launch(sc, ag, out, cfg, stream, nullptr);
+}
+int ms_step_render(const MsScenery* sc, const MsAgents* ag, float* progress, const MsRender* out, const MsConfig* cfg, void* stream) {
+    return ms_move_step_render(sc, ag, nullptr, nullptr, progress, out, cfg, stream);
 }
 int ms_debug_last_step_fused(void) { return g_last_step_fused; }
 

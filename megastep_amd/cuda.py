@@ -748,30 +748,8 @@ def bake(scenery, scratch=True, wall_grid=True):
     scenery._bake_marks, scenery._bake_s = (marks, wall_grid), None
 
 
-def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None, config=None):
-    """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
-    returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230).
-
-    Beyond the reference, the tensor ops its callers run around the step can ride in the same launch
-    (include/megastep_hip.h, MsMovement / MsStepExtras):
-
-    * ``movement=(actions, table, keep)``: the movement modules' velocity update first: ``actions`` (N, A) int64 rows of
-      ``table`` (K, 3) = agent-frame [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns);
-    * ``respawn=dict(mask, choices, positions, angles, after=False)``: agents marked in the (N, A) bool ``mask`` get
-      pose ``positions[n, a, choices[n, a]]`` / ``angles[...]`` and zero velocities - before the step (and before the
-      movement), or after it with ``after=True``;
-    * ``lifespans=dict(lifespans, max_lifespans, fresh)``: (N, A) int32 ages tick first; agents at their maximum are
-      added to ``respawn['mask']`` (required with it), start over and take ``fresh`` as their new maximum;
-    * ``imu=(out, ang_scale, speed_scale)``: the (N, A, 3) IMU observation of the state the step leaves behind.
-
-    ``out``: the :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating.
-    ``config``: the constants of this call (:func:`config`); default: the ones ``agents`` carry (a Core's do), else initialize()'s."""
-    dev = scenery._device()
-    _agents_on(agents, dev)
-    shape = (len(scenery.lines), scenery.n_agents)
-    if agents.angles.shape != shape:
-        raise RuntimeError('agents do not match the scenery: expected (n_envs, n_agents) = '
-                           f'{shape}, got {tuple(agents.angles.shape)}')
+def _step_options(agents, shape, movement, respawn, lifespans, imu):
+    """``physics``' optional arguments (see there) as the C-ABI's MsMovement / MsStepExtras, by reference (or None)."""
     mv = None
     if movement is not None:
         actions, table, keep = movement
@@ -814,6 +792,34 @@ def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=No
             used.append(obs)
         _require_gpu(*used)
         ex = C.byref(x)
+    return mv, ex
+
+
+def physics(scenery, agents, movement=None, out=None, respawn=None, lifespans=None, imu=None, config=None):
+    """Advances the agents by one step, stopping them at walls and at each other; updates ``agents`` in place and
+    returns :class:`Physics` with the (N, A) ``progress`` (reference: wrappers.cpp:69, kernels.cu:179-230).
+
+    Beyond the reference, the tensor ops its callers run around the step can ride in the same launch
+    (include/megastep_hip.h, MsMovement / MsStepExtras):
+
+    * ``movement=(actions, table, keep)``: the movement modules' velocity update first: ``actions`` (N, A) int64 rows of
+      ``table`` (K, 3) = agent-frame [dx, dy, d angvelocity]; velocities become ``keep*old + delta`` (``keep = 0`` assigns);
+    * ``respawn=dict(mask, choices, positions, angles, after=False)``: agents marked in the (N, A) bool ``mask`` get
+      pose ``positions[n, a, choices[n, a]]`` / ``angles[...]`` and zero velocities - before the step (and before the
+      movement), or after it with ``after=True``;
+    * ``lifespans=dict(lifespans, max_lifespans, fresh)``: (N, A) int32 ages tick first; agents at their maximum are
+      added to ``respawn['mask']`` (required with it), start over and take ``fresh`` as their new maximum;
+    * ``imu=(out, ang_scale, speed_scale)``: the (N, A, 3) IMU observation of the state the step leaves behind.
+
+    ``out``: the :class:`Physics` of an earlier call, to write ``progress`` into instead of allocating.
+    ``config``: the constants of this call (:func:`config`); default: the ones ``agents`` carry (a Core's do), else initialize()'s."""
+    dev = scenery._device()
+    _agents_on(agents, dev)
+    shape = (len(scenery.lines), scenery.n_agents)
+    if agents.angles.shape != shape:
+        raise RuntimeError('agents do not match the scenery: expected (n_envs, n_agents) = '
+                           f'{shape}, got {tuple(agents.angles.shape)}')
+    mv, ex = _step_options(agents, shape, movement, respawn, lifespans, imu)
     progress = torch.empty_like(agents.angles) if out is None else out.progress      # `out`: an earlier call's Physics
     _ab_switches()
     _check_grid(scenery, dev)
@@ -892,19 +898,24 @@ def _check_grid(scenery, dev):
             scenery.check_wall_grid()
 
 
-def step_render(scenery, agents, fields=None, pooled=None, out=None, seen=None, config=None):
+def step_render(scenery, agents, fields=None, pooled=None, out=None, seen=None, config=None, movement=None, respawn=None,
+                lifespans=None, imu=None):
     """One step of the hot path - :func:`physics` then :func:`render`, what every ``env.step()`` of the reference runs
     (wrappers.cpp:69 + :82) - as one call, and where the shapes allow it as ONE LAUNCH (include/megastep_hip.h,
     ``ms_step_render``): with one agent per env and at most 64 rays (BASELINE config 2, the Explorer shape) an agent is a single
     wavefront, which runs its env's physics step and renders from the pose it ends on. Any other shape is the two launches,
     as if the two calls had been made. Same bits either way (tests/test_gpu_step_render.py).
 
-    Arguments as :func:`render`'s; ``out``: the ``(Physics, Render)`` of an earlier call, to write into. Returns ``(Physics, Render)``."""
+    Arguments as :func:`render`'s, and :func:`physics`' ``movement`` / ``respawn`` / ``lifespans`` / ``imu`` (a whole env.step() of a
+    single-agent env of up to 64 rays - the reference's tutorial env - is then one launch); ``out``: the ``(Physics, Render)`` of an
+    earlier call, to write into. Returns ``(Physics, Render)``."""
     physics_out, render_out = out if out is not None else (None, None)
     progress = torch.empty_like(agents.angles) if physics_out is None else physics_out.progress
-    if agents.angles.shape != (len(scenery.lines), scenery.n_agents):
+    shape = (len(scenery.lines), scenery.n_agents)
+    if agents.angles.shape != shape:
         raise RuntimeError('agents do not match the scenery')
-    r = render(scenery, agents, fields=fields, pooled=pooled, out=render_out, seen=seen, config=config, _progress=progress)
+    options = _step_options(agents, shape, movement, respawn, lifespans, imu)
+    r = render(scenery, agents, fields=fields, pooled=pooled, out=render_out, seen=seen, config=config, _progress=(progress, *options))
     agents._cached = agents._use_cache
     agents._epoch += 1
     return (Physics(progress) if physics_out is None else physics_out), r
@@ -965,8 +976,9 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
             _lib.lib().ms_debug_pair_telemetry(1)               # the kernels' pair counters too (tools/pair_stats.py)
         try:
             if _progress is not None:                            # step_render: the physics step first, in the same launch where it can be
-                _lib.check(_lib.lib().ms_step_render(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
-                                                     C.c_void_p(_progress.data_ptr()), C.byref(result._struct), C.byref(cfg), _stream(dev)))
+                progress, mv, ex = _progress
+                _lib.check(_lib.lib().ms_move_step_render(C.byref(scenery._as_struct()), C.byref(agents._struct if agents._use_cache else agents._plain),
+                                                          mv, ex, C.c_void_p(progress.data_ptr()), C.byref(result._struct), C.byref(cfg), _stream(dev)))
             else:
                 _lib.check(_lib.lib().ms_render(C.byref(scenery._as_struct()), C.byref(agents._struct if use_cache else agents._plain),
                                                 C.byref(result._struct), C.byref(cfg), _stream(dev)))

@@ -31,6 +31,10 @@ class Minimal:
 
     @torch.no_grad()
     def step(self, decision):
+        if self.core.device.type == 'cuda':
+            # the velocities, the physics step and the render: ONE launch - an agent of 64 rays is a single wavefront (cuda.step_render)
+            frame = modules.move_render(self.core, self.movement, decision, observers=(self.rgb,), fields=())
+            return arrdict.arrdict(obs=self.rgb(frame))
         self.movement(decision)                  # sets the velocities and runs physics, one launch
         return self._world()
 

@@ -87,6 +87,7 @@ class SimpleMovement:
         self.core = core
         self._actionset = _actionset(core, speed, ang_speed)
         self._table = _table(self._actionset)
+        self.keep = 0.                           # (of the old velocity: none - see cuda.physics' ``movement``)
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
     def __call__(self, decision, respawn=None, imu=None):
@@ -104,6 +105,7 @@ class MomentumMovement:
         self._actionset = _actionset(core, accel, ang_accel)
         self._table = _table(self._actionset)
         self.decay = decay
+        self.keep = 1 - decay
         self.space = spaces.MultiDiscrete(n_agents or core.n_agents, 7)
 
     def __call__(self, decision, respawn=None, imu=None):
@@ -131,6 +133,25 @@ def render(core, observers=None, fields=None, centre=False, seen=None):
     if observers:
         pooled = _pooling(tuple(observers), bool(centre))
     raw = cuda.render(core.scenery, core.agents, fields=fields, pooled=pooled, seen=seen)
+    return _frame(raw, pooled)
+
+
+def move_render(core, mover, decision, observers=None, fields=None, centre=False, seen=None, respawn=None, imu=None):
+    """A movement module's step and :func:`render` as ONE call - ``mover(decision, respawn=, imu=)`` then ``render(core, ...)``, same
+    arguments, same result - through :func:`cuda.step_render`: for a single-agent world of up to 64 rays (the reference's tutorial
+    env, demo/envs/minimal.py) a whole ``env.step()`` is then one launch; any other shape is the two launches it always was."""
+    agents = core.agents
+    pooled = _pooling(tuple(observers), bool(centre)) if observers else None
+    reading = None if imu is None else (torch.empty(agents.angles.shape + (3,), device=core.device), imu.ang_scale, imu.speed_scale)
+    _, raw = cuda.step_render(core.scenery, agents, fields=fields, pooled=pooled, seen=seen,
+                              movement=(decision.actions.long().contiguous(), mover._table, mover.keep), respawn=respawn, imu=reading)
+    if imu is not None:
+        imu._pending = (reading[0], agents._epoch)
+    return _frame(raw, pooled)
+
+
+def _frame(raw, pooled):
+    """A :class:`cuda.Render` as the arrdict the observation modules read (see :func:`render`)."""
     r = arrdict.arrdict({k: getattr(raw, k).unsqueeze(2) for k in cuda.FIELDS if getattr(raw, k) is not None})
     if 'screen' in r:
         r['screen'] = r.screen.permute(0, 1, 4, 2, 3)

@@ -187,3 +187,81 @@ def test_steps_replayed_as_a_hip_graph():
     for d, p in eager:
         g.replay()
         assert torch.equal(out[1].distances, d) and torch.equal(c.agents.positions, p)
+
+
+@pytest.mark.parametrize('keep,after', [(0., False), (.875, False), (.875, True)])
+def test_one_launch_with_the_movement_prologue_and_the_envs_bookkeeping(keep, after):
+    """ms_move_step_render: what ms_step_physics runs around the step - the movement modules' velocity update, lifespans, masked
+    respawns (before the step or after it), the IMU reading - inside the one launch too: agent state, progress, the IMU
+    observation, the lifespans' books and the respawn mask they report into, and every render output equal, bit for bit, to
+    cuda.physics(movement=, respawn=, lifespans=, imu=) followed by cuda.render, eight steps."""
+    from megastep_amd import cuda, modules
+    c, geometries = _world(48, 1, 64, 130., seed=9)
+    N = c.n_envs
+    rng = np.random.RandomState(13)
+    spawner = modules.RandomSpawns(geometries, c)
+    table = modules._table(modules._actionset(c, 5, 180))
+    g = torch.Generator('cuda').manual_seed(3)
+    acts = torch.randint(0, 7, (8, N, 1), device='cuda', generator=g)
+    masks = torch.rand((8, N, 1), device='cuda', generator=g) < .15
+    choices = torch.randint(0, 1, (8, N, 1), device='cuda', generator=g)            # (the reference's quirk: spawns.shape[1] = n_agents options)
+    fresh = torch.randint(3, 9, (8, N, 1), device='cuda', generator=g, dtype=torch.int32)
+    util.random_velocities(c, rng, speed=2.)
+    start = _state(c)
+    results = []
+    for fused in (False, True):
+        _restore(c, start)
+        ages = torch.zeros((N, 1), dtype=torch.int32, device='cuda')
+        maxima = torch.full((N, 1), 5, dtype=torch.int32, device='cuda')
+        out = []
+        for t in range(8):
+            mask = masks[t].clone()
+            request = dict(mask=mask, choices=choices[t], positions=spawner._spawns.positions, angles=spawner._spawns.angles, after=after)
+            life = dict(lifespans=ages, max_lifespans=maxima, fresh=fresh[t])
+            imu = torch.full((N, 1, 3), float('nan'), device='cuda')
+            kw = dict(movement=(acts[t], table, keep), respawn=request, lifespans=life, imu=(imu, 360., 10.))
+            if fused:
+                p, r = cuda.step_render(c.scenery, c.agents, **kw)
+                assert _fused()
+            else:
+                p = cuda.physics(c.scenery, c.agents, **kw)
+                r = cuda.render(c.scenery, c.agents)
+            out.append((p.progress.clone(), r, _state(c), c.agents._headings.clone(), imu, mask, ages.clone(), maxima.clone()))
+        results.append(out)
+    respawned = 0
+    for t, (a, b) in enumerate(zip(*results)):
+        assert _same(a[0], b[0]), f'progress at step {t}'
+        for k, (x, y) in enumerate(zip(a[2], b[2])):
+            assert _same(x, y), f'state tensor {k} at step {t}'
+        assert _same(a[3], b[3]) and _same(a[4], b[4]), f'heading cache / imu at step {t}'
+        assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6]) and torch.equal(a[7], b[7]), f'lifespans / mask at step {t}'
+        for f in ('indices', 'locations', 'dots', 'distances', 'screen'):
+            assert _same(getattr(a[1], f), getattr(b[1], f)), f'{f} at step {t}'
+        respawned += int(a[5].sum())
+    assert respawned > 20 and torch.isfinite(results[1][-1][4]).all()
+
+
+def test_the_tutorial_env_steps_in_one_launch():
+    """demo.Minimal (the reference's tutorial env, demo/envs/minimal.py: SimpleMovement, physics, render of 64 rays): its step
+    through modules.move_render - one launch - returns what the movement module followed by the render does."""
+    from megastep_amd import arrdict
+    from megastep_amd.demo import Minimal
+    rollouts = []
+    for fused in (True, False):
+        torch.manual_seed(2); np.random.seed(2)
+        env = Minimal(64)
+        torch.manual_seed(3)
+        frames = [env.reset().obs.clone()]
+        for t in range(12):
+            decision = arrdict.arrdict(actions=torch.randint(0, 7, (64, 1), device='cuda', generator=torch.Generator('cuda').manual_seed(50 + t)))
+            if fused:
+                frames.append(env.step(decision).obs.clone())
+                assert _fused()
+            else:
+                env.movement(decision)
+                frames.append(env._world().obs.clone())
+        frames.append(env.core.agents.positions.clone())
+        rollouts.append(frames)
+    for t, (x, y) in enumerate(zip(*rollouts)):
+        assert _same(x, y), t
+    assert (rollouts[0][-1] - 3.).abs().max() > .1
