@@ -605,6 +605,8 @@ static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender
     const int rblocks = (int)((n_fans + RW - 1)/RW);
     const dim3 rgrid(rblocks), rblock(RW*WAVE);
     const hipStream_t hs = (hipStream_t)stream;
+    // (colour, and not one per-ray plane wanted - the demo envs' request: the instantiation that has no plane stores in it)
+    [[maybe_unused]] const bool no_planes = colour && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen;
 #define MS_LAUNCH_RENDER(I, O) \
     hipLaunchKernelGGL((render_kernel<I, RW, O, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
 #if MS_AB_IMPLS
@@ -614,8 +616,6 @@ static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender
 #endif
 #define MS_LAUNCH_RENDER_NG(O, S, NG_) \
     hipLaunchKernelGGL((render_kernel<2, RW, O, S, NG_>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rc)
-    // (colour, and not one per-ray plane wanted - the demo envs' request: the instantiation that has no plane stores in it)
-    const bool no_planes = colour && !out->indices && !out->locations && !out->dots && !out->distances && !out->screen;
 #define MS_LAUNCH_RENDER_OS(NG_) \
     { if (!colour) MS_LAUNCH_RENDER_NG(1, 0, NG_); else if (no_planes) MS_LAUNCH_RENDER_NG(2, 1, NG_); else if (obs) MS_LAUNCH_RENDER_NG(1, 1, NG_); \
       else MS_LAUNCH_RENDER_NG(0, 1, NG_); }
