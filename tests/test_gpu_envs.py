@@ -145,6 +145,56 @@ def test_deathmatch_steps_the_same_with_and_without_the_logic_kernel():
     assert a[0].reset.all() and resets >= 3
 
 
+def test_envs_soak():
+    """A few hundred steps of each demo env under random actions (the one-launch game logic, respawns inside the physics launch, spawn
+    choices drawn ahead): observations finite and in range throughout, agents inside their floorplans' extents, Deathmatch's health
+    never above 1 and its dead back at full health a step later, Explorer's potential never decreasing within an episode, resets
+    and rewards happening."""
+    from megastep_amd.demo import Deathmatch, Explorer, Minimal
+    from megastep_amd import arrdict, cubicasa
+    torch.manual_seed(7); np.random.seed(7)
+    gs = cubicasa.sample(12, n_unique=16)
+    dm = Deathmatch(48, 4, geometries=gs)
+    w = dm.reset()
+    hi = dm._bounds.max() + 2
+    resets = rewards = 0
+    for t in range(400):
+        if t % 50 == 10:
+            dm._health[t % 12, t % 4] = -1.; dm._dead[t % 12, t % 4] = True        # (somebody is killed: hits alone take hundreds of steps)
+        w = dm.step(_decision(dm, 48))
+        assert torch.isfinite(w.obs.rgb).all() and torch.isfinite(w.obs.d).all() and torch.isfinite(w.obs.imu).all()
+        assert (w.obs.d >= 0).all() and (w.obs.d <= 1).all() and (w.obs.rgb >= 0).all() and (w.obs.rgb <= 1.0001).all()
+        assert (dm._health <= 1).all() and (w.reward >= 0).all()
+        pos = dm.core.agents.positions
+        assert (pos > -2).all() and (pos < hi).all()
+        if w.reset.any():
+            assert (dm._health.reshape(-1)[w.reset] > .7).all()          # revived this step: full health less at most this frame's wounds
+        resets += int(w.reset.sum()); rewards += float(w.reward.sum())
+    assert resets >= 8 and rewards > 0
+    ex = Explorer(24, geometries=cubicasa.sample(24, n_unique=32))
+    w = ex.reset()
+    last = ex._potential.clone()
+    resets = 0
+    for t in range(300):
+        if t % 60 == 20:
+            ex._lengths[t % 24] = 10_000                               # an episode is ended (200 steps + a step per texel otherwise)
+        w = ex.step(_decision(ex, 24))
+        for k in w.obs:
+            assert torch.isfinite(w.obs[k]).all(), k
+        assert (w.reward >= 0).all() and (w.reward[w.reset] == 0).all()
+        grown = ex._potential >= torch.where(w.reset, torch.zeros_like(last), last)
+        assert grown.all()
+        last = ex._potential.clone()
+        resets += int(w.reset.sum())
+    assert resets >= 4 and last.min() > 0
+    mi = Minimal(32)
+    mi.reset()
+    for t in range(200):
+        w = mi.step(_decision(mi, 32))
+        assert torch.isfinite(w.obs).all()
+    assert (mi.core.agents.positions > 1).all() and (mi.core.agents.positions < 6).all()
+
+
 def test_observation_modules_against_a_torch_restatement():
     """Depth/RGB on a real render equal their definition (modules.py:170-184,211-224) applied to the raw outputs."""
     from megastep_amd import core, cubicasa, modules, scene, cuda
