@@ -873,11 +873,14 @@ def explorer_books(tally, before, lengths, epoch, over, slack, pixels, display=F
         if t.shape != (n,):
             raise RuntimeError('explorer_books: tally, before, lengths, epoch and over must all be (N,)')
     _check(over, 'over', torch.bool, 1)
+    if over.shape != (n,):
+        raise RuntimeError('explorer_books: tally, before, lengths, epoch and over must all be (N,)')
     dev = _require_gpu(tally, before, lengths, epoch, over)
+    ptrs = (tally.data_ptr(), before.data_ptr(), lengths.data_ptr(), epoch.data_ptr(), over.data_ptr())
     reset = torch.empty_like(over)
     rest = torch.empty((3 if display else 1, n), dtype=torch.float32, device=dev)         # (one allocation: reward | potential | lengths)
     out = (reset, rest[0]) + ((rest[1], rest[2].view(torch.int32)) if display else ())
-    ex = _lib.MsExplorer(tally.data_ptr(), before.data_ptr(), lengths.data_ptr(), epoch.data_ptr(), over.data_ptr(), int(slack), int(pixels),
+    ex = _lib.MsExplorer(*ptrs, int(slack), int(pixels),
                          reset.data_ptr(), rest.data_ptr(), rest.data_ptr() + 4*n if display else None, rest.data_ptr() + 8*n if display else None)
     with _on(dev):
         _lib.check(_lib.lib().ms_explorer_books(n, C.byref(ex), _stream(dev)))
@@ -948,26 +951,28 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
     if (n, a) != (len(scenery.lines), scenery.n_agents):
         raise RuntimeError('agents do not match the scenery')
     cfg = _cfg(agents, config)            # (``config=``: see physics)
+    seen_ptrs = None
     if seen is not None:
         stamp, epoch, count = seen
         if any(t.dtype != torch.int32 or not t.is_contiguous() for t in seen) or stamp.shape != (scenery.textures.vals.shape[0],) \
                 or epoch.shape != (n,) or count.shape != (n,):
             raise RuntimeError('seen must be contiguous int32 tensors (stamp per texel, epoch per env, count per env)')
         _require_gpu(*seen)
-    if seen is not None and a > 1 and scenery._as_struct().lg_vals is None:
-        raise RuntimeError('first-sight bookkeeping (seen=) rides in the one-kernel renderer, which needs the light grid that this '
-                           'multi-agent scenery was built without (Scenery.LIGHT_GRID = False)')
-    key = (n, a, cfg.res, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), dev,
-           None if seen is None else tuple(t.data_ptr() for t in seen))
+        if a > 1 and scenery._as_struct().lg_vals is None:
+            raise RuntimeError('first-sight bookkeeping (seen=) rides in the one-kernel renderer, which needs the light grid that this '
+                               'multi-agent scenery was built without (Scenery.LIGHT_GRID = False)')
+        seen_ptrs = tuple(t.data_ptr() for t in seen)
+    # (what an `out` must have been made for: put together only when one is handed over, or asked of a result later)
+    spec = (n, a, cfg.res, fields, pooled, dev, seen_ptrs)
     if out is not None:
-        if getattr(out, '_key', None) != key:
+        if _render_key(getattr(out, '_spec', None)) != _render_key(spec):
             raise RuntimeError('`out` must come from a render call with the same shapes, fields and pooling')
         result = out
     else:
         result = _render_buffers(scenery, n, a, cfg.res, fields, pooled, dev)
-        result._key = key
+        result._spec = spec
         if seen is not None:
-            result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = (t.data_ptr() for t in seen)
+            result._struct.seen_stamp, result._struct.seen_epoch, result._struct.seen_count = seen_ptrs
     _ab_switches()
     _check_grid(scenery, dev)
     with _on(dev):
@@ -989,6 +994,12 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
 
 
 _layouts = {}
+def _render_key(spec):
+    """A render call's shapes, fields, pooling and books as a comparable value (see ``out=``)."""
+    if spec is None:
+        return None
+    n, a, res, fields, pooled, dev, seen_ptrs = spec
+    return (n, a, res, None if fields is None else tuple(fields), None if pooled is None else tuple(sorted(pooled.items())), dev, seen_ptrs)
 
 
 def _render_buffers(scenery, n, a, r, fields, pooled, dev):
