@@ -216,6 +216,14 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
     out['explorer_depth_only'] = {'fps': eager, 'fps_hip_graph': graphed,
                                   'env': f'Explorer({n_core_envs}, depth_only=True): 1 agent, 256 rays -> 64 px D+IMU', 'distinct_floorplans': plans}
     torch.cuda.empty_cache()
+    from megastep_amd.demo import Minimal
+    env = Minimal(n_core_envs, device=device)
+    eager, graphed = rate(env, n_core_envs)
+    del env
+    out['minimal'] = {'fps': eager, 'fps_hip_graph': graphed,
+                      'env': f"Minimal({n_core_envs}): the reference's tutorial env (one agent in a 5 m box, SimpleMovement, 64 rays RGB) - "
+                             f"one launch a step (ms_move_step_render)"}
+    torch.cuda.empty_cache()
     env = Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries)
     log('Deathmatch built')
     eager, graphed = rate(env, 4*n_core_envs)
