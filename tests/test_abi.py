@@ -86,9 +86,20 @@ def test_compute_entry_points_refuse_cpu_tensors():
     scenery = scene.scenery([toys.box()], 1, device='cpu', bake=False)
     cuda.initialize(core.AGENT_RADIUS, 64, 130, 10)
     agents = core._init_agents(1, 1, 'cpu')
-    for call in (lambda: cuda.bake(scenery), lambda: cuda.physics(scenery, agents), lambda: cuda.render(scenery, agents)):
+    health = torch.ones((1, 1))
+    books = [torch.zeros(1, dtype=torch.int32) for _ in range(4)]
+    for call in (lambda: cuda.bake(scenery), lambda: cuda.physics(scenery, agents), lambda: cuda.render(scenery, agents),
+                 lambda: cuda.step_render(scenery, agents),
+                 lambda: cuda.deathmatch_shoot(torch.zeros((1, 1, 2), dtype=torch.int32), torch.zeros((1, 1, 2)), torch.zeros((1, 2)), health,
+                                               health.clone(), torch.zeros((1, 1), dtype=torch.bool)),
+                 lambda: cuda.explorer_books(*books, torch.zeros(1, dtype=torch.bool), 200, 64)):
         with pytest.raises(RuntimeError, match='GPU'):
             call()
+    with pytest.raises(RuntimeError, match='N, A'):
+        cuda.deathmatch_shoot(torch.zeros((1, 1, 2), dtype=torch.int32), torch.zeros((1, 1, 2)), torch.zeros((2, 2)), health, health.clone(),
+                              torch.zeros((1, 1), dtype=torch.bool))
+    with pytest.raises(RuntimeError, match=r'\(N,\)'):
+        cuda.explorer_books(*books, torch.zeros(2, dtype=torch.bool), 200, 64)
 
 
 def test_product_never_touches_the_oracle():
