@@ -1,6 +1,7 @@
 """Random worlds against the oracle: shapes, views and speeds drawn per seed - agents per env 1..70, rays 1..600, fov
 20..175 degrees, small and large floorplans, toys - several physics + render steps each, with the movement / respawn
-extras and the pooled observations switched on at random. Prints one line per seed and a summary; exits 1 on a mismatch.
+extras and the pooled observations switched on at random; every second step goes through ms_step_render (the one-launch step
+where the shape allows it). Prints one line per seed and a summary; exits 1 on a mismatch.
 usage: python tools/fuzz_parity.py [first_seed] [n_seeds]"""
 import sys, time, traceback
 sys.path.insert(0, '.')
@@ -72,8 +73,12 @@ def one(seed, oblique=None):
             c.agents.velocity[::2] = 0.
             c.agents.velocity[0, 0] = torch.tensor([3e-6, 0.], device='cuda')
         ref.pull_agents(c)
-        p = cuda.physics(c.scenery, c.agents)
-        r = cuda.render(c.scenery, c.agents)
+        if step % 2:
+            # (through ms_step_render: ONE launch for a single agent of up to 64 rays, the two launches for every other shape)
+            p, r = cuda.step_render(c.scenery, c.agents)
+        else:
+            p = cuda.physics(c.scenery, c.agents)
+            r = cuda.render(c.scenery, c.agents)
         prog_ref, agents_ref = ref.physics()
         util.assert_physics_matches(c, p, prog_ref, agents_ref)
         util.assert_render_matches(c, r, ref.render())
