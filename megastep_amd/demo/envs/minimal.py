@@ -13,6 +13,7 @@ class Minimal:
         box = toys.box()
         rooms = [box for _ in range(n_envs)]
         self.core = core.Core(scene.scenery(rooms, n_agents=1, device=device))
+        self.device = self.core.device
 
         self.rgb = modules.RGB(self.core)
         self.movement = modules.SimpleMovement(self.core)

@@ -468,6 +468,35 @@ def test_env_steps_replayed_as_a_hip_graph():
     assert (env.core.agents.positions - at_rest).norm(dim=-1).max() < 2e-3
 
 
+def test_fused_envs_replayed_as_hip_graphs():
+    """graphs.GraphedStep around the envs with the one-launch game logic: Deathmatch (the respawn mask written by one step's logic
+    kernel and read by the next step's physics launch, both inside the captured step; the spawn draw stays torch's graph-safe
+    randint under capture) and Minimal (its whole step one launch): the replayed steps keep the books the eager envs keep."""
+    from megastep_amd import arrdict, cubicasa, graphs
+    from megastep_amd.demo import Deathmatch, Minimal
+    torch.manual_seed(11); np.random.seed(11)
+    env = graphs.GraphedStep(Deathmatch(32, 4, geometries=cubicasa.sample(8, n_unique=16)))
+    env.reset()
+    forced = 0
+    for t in range(120):
+        if t in (20, 60):
+            env.env._health[t % 8, 1] = -1.; env.env._dead[t % 8, 1] = True      # killed: the next replay respawns it at full health
+        w = env.step(_decision(env.env, 32))
+        assert torch.isfinite(w.obs.rgb).all() and torch.isfinite(w.obs.health).all() and (env.env._health <= 1).all()
+        if t in (20, 60):
+            forced += int(w.reset.reshape(8, 4)[t % 8, 1])
+            assert env.env._health[t % 8, 1] > .7
+    assert forced == 2
+    assert (env.env._health < 1 - 50*.001).any()                             # the tick damage of the replayed steps adds up
+    mini = graphs.GraphedStep(Minimal(16))
+    mini.reset()
+    start = mini.core.agents.positions.clone()
+    forward = arrdict.arrdict(actions=torch.ones((16, 1), dtype=torch.long, device='cuda'))
+    for _ in range(6):
+        w = mini.step(forward)
+    assert torch.isfinite(w.obs).all() and ((mini.core.agents.positions - start).norm(dim=-1) > .2).all()
+
+
 def test_rays_that_miss_mark_the_last_texel_like_the_reference():
     """explorer.py:36,47: a missed ray's texel index is -1 and `_seen[-1] = True` marks the scenery's LAST texel, to the
     credit of the last env. Open worlds - a lone wall per env, most rays see nothing - with and without colour, groups of
