@@ -180,7 +180,8 @@ typedef struct MsRender {
      * Each pixel is the mean over `obs_subsample` adjacent rays; obs_subsample must be a power of two dividing
      * both 64 and the resolution.  NULL = not wanted.
      *   obs_rgb    (N, A, 3, R/obs_subsample)  channel-major, as the reference's RGB module returns it
-     *   obs_depth  (N, A, R/obs_subsample)     mean of 1 - clamp((distance - agent_radius)/obs_max_depth, 0, 1) */
+     *   obs_depth  (N, A, R/obs_subsample)     mean of 1 - clamp((distance - agent_radius)/obs_max_depth, 0, 1), the quotient taken
+     *                                          as ATen takes a tensor over a scalar: times the binary32 reciprocal */
     float* obs_rgb;
     float* obs_depth;
     int    obs_subsample;

@@ -941,7 +941,10 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
     if (OBS && ((COLOUR && MS_WANTED(OUT_RGB, late->out.obs_rgb)) || MS_WANTED(OUT_DEPTH, late->out.obs_depth))) {
         const int sub = MASKED ? (late->out.obs_subsample & 0xff) : late->out.obs_subsample;   // power of two, divides 64 and R (checked by the host)
         float p0 = s0, p1 = s1, p2 = s2;
-        float pd = 1.f - ms_min(ms_max((dist - agent_radius)/late->out.obs_max_depth, 0.f), 1.f);
+        // (times the reciprocal ms_render left in the field, as ATen divides a tensor by a scalar - modules.py:176's
+        // `(distances - agent_radius)/max_depth` on the device is `a * (1.f/b)`: torch's own bits, and ten instructions a group fewer
+        // than the correctly rounded quotient this was until round 6)
+        float pd = 1.f - ms_min(ms_max((dist - agent_radius)*late->out.obs_max_depth, 0.f), 1.f);
         // (the first two rounds - lanes 1 and 2 apart: all of them at the demo envs' four rays a pixel - stay inside quads of lanes:
         // DPP quad permutes, which ride on the add itself, instead of ds_bpermute's round trips through the LDS crossbar)
         auto quad_xor = [](const float v, auto ctrl) {

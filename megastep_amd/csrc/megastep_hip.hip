@@ -549,6 +549,7 @@ static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender
     // workspace is not needed at all); otherwise from render_prep_kernel, which also resets the workspace's counters.
     MsAgents agn = *ag;
     MsRender outn = *out;
+    if (out->obs_depth) outn.obs_max_depth = 1.f/out->obs_max_depth;     // (the kernel multiplies: see the pooled depth in render.h)
     const bool colour = out->screen || out->obs_rgb;                      // else: render_kernel<.,.,1,0>, which has no pass 3
     const bool one_kernel = grid || sc->n_agents == 1 || !colour;        // (nothing to light without colour)
     if (ag->headings && one_kernel) {
