@@ -237,7 +237,8 @@ typedef struct MsMovement {
  *            moves and collides (Deathmatch's order, demo/envs/deathmatch.py:96-99); respawn_after = 1: after the
  *            step's integration (Explorer's order, demo/envs/explorer.py:83-90)
  *   imu      of the state the call leaves behind: [angvelocity/imu_ang_scale, (c vx + s vy)/imu_speed_scale,
- *            (-s vx + c vy)/imu_speed_scale] with (c, s) = cos, sin of the heading in radians, binary32 as torch does */
+ *            (-s vx + c vy)/imu_speed_scale] with (c, s) = cos, sin of the heading in radians, binary32 as torch does - the
+ *            quotients included: a tensor over a scalar is `a * (1.f/b)` in ATen */
 typedef struct MsStepExtras {
     unsigned char*   respawn_mask;      /* (N, A) bytes, non-zero = respawn; written back when lifespans tick  */
     const long long* respawn_choice;    /* (N, A) */

@@ -376,9 +376,11 @@ __global__ __launch_bounds__(WAVE) void physics_kernel(
             if (ex.imu) {                                    // modules.py:263-270, to_local_frame :24-31
                 const float a_ = 0.017453292519943295f*turned;
                 const float s_ = sinf(a_), c_ = cosf(a_);
-                ex.imu[3*i] = w_/ex.imu_ang_scale;
-                ex.imu[3*i + 1] = (c_*v.x + s_*v.y)/ex.imu_speed_scale;
-                ex.imu[3*i + 2] = (-s_*v.x + c_*v.y)/ex.imu_speed_scale;
+                // (times the reciprocals ms_step_physics left in the two fields: the modules divide a tensor by a Python scalar, which
+                // ATen evaluates as `a * (1.f/b)` - torch's own bits)
+                ex.imu[3*i] = w_*ex.imu_ang_scale;
+                ex.imu[3*i + 1] = (c_*v.x + s_*v.y)*ex.imu_speed_scale;
+                ex.imu[3*i + 2] = (-s_*v.x + c_*v.y)*ex.imu_speed_scale;
             }
         }
     }

@@ -631,9 +631,9 @@ __global__ __launch_bounds__(RW*WAVE) __attribute__((amdgpu_waves_per_eu(NG > 1 
             const float a_ = 0.017453292519943295f*turned;
             const float s_ = sinf(a_), c_ = cosf(a_);
             if (lane == 0) {
-                ex.imu[3*n] = w_/ex.imu_ang_scale;
-                ex.imu[3*n + 1] = (c_*v_.x + s_*v_.y)/ex.imu_speed_scale;
-                ex.imu[3*n + 2] = (-s_*v_.x + c_*v_.y)/ex.imu_speed_scale;
+                ex.imu[3*n] = w_*ex.imu_ang_scale;                           // (the reciprocals: see physics_kernel)
+                ex.imu[3*n + 1] = (c_*v_.x + s_*v_.y)*ex.imu_speed_scale;
+                ex.imu[3*n + 2] = (-s_*v_.x + c_*v_.y)*ex.imu_speed_scale;
             }
         }
         ag_s = hsc.x; ag_c = hsc.y; ag_p = p_new;                            // the pose the rays are cast from

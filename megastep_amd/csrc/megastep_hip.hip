@@ -462,7 +462,8 @@ int ms_step_physics(const MsScenery* sc, const MsAgents* ag, const MsMovement* m
     const MsMovement no_move{nullptr, nullptr, 0, 0.f};
     const MsStepExtras no_extras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
     const MsMovement mvv = mv ? *mv : no_move;
-    const MsStepExtras exv = ex ? *ex : no_extras;
+    MsStepExtras exv = ex ? *ex : no_extras;
+    exv.imu_ang_scale = 1.f/exv.imu_ang_scale; exv.imu_speed_scale = 1.f/exv.imu_speed_scale;   // (the kernel multiplies: see its IMU reading)
     MsScenery scn = *sc;
     if (!sc->wg_cells) { scn.wg_geom = sc->lines_vals; scn.wg_starts = sc->lines_starts; }   // (rows the kernel may read: see there)
     const hipStream_t hs = (hipStream_t)stream;
@@ -626,6 +627,7 @@ static int render_launch(const MsScenery* sc, const MsAgents* ag, const MsRender
         rcs.progress = progress; rcs.fps = cfg->fps; rcs.wg_cells_physics = sc->wg_cells;
         rcs.mv = mv ? *mv : MsMovement{nullptr, nullptr, 0, 0.f};
         rcs.ex = ex ? *ex : MsStepExtras{nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
+        rcs.ex.imu_ang_scale = 1.f/rcs.ex.imu_ang_scale; rcs.ex.imu_speed_scale = 1.f/rcs.ex.imu_speed_scale;
 #define MS_LAUNCH_STEP(O, S) \
     hipLaunchKernelGGL((render_kernel<2, RW, O, S, 1, 1>), rgrid, rblock, 0, hs, scn, agn, outn, cfg->agent_radius, half_screen, R, (int)n_fans, rcs)
         if (!colour) MS_LAUNCH_STEP(1, 0); else if (obs) MS_LAUNCH_STEP(1, 1); else MS_LAUNCH_STEP(0, 1);
