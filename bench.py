@@ -439,7 +439,9 @@ def _torch_step_all_cores(core, threads, n, deadline_s=25.):
                 return {'value': n*steps/dt, 'unit': 'env-steps/s', 'cores': threads,
                         'sample': f'first {n} envs x {steps} steps, torch.set_num_threads({threads}), own process'}
             return {'value': None, 'cores': threads, 'note': 'the all-cores run failed: ' + got.stderr[-200:]}
-        except subprocess.TimeoutExpired:
+        except Exception as e:                                             # (a reported-only leg never takes the line down with it)
+            if not isinstance(e, subprocess.TimeoutExpired):
+                return {'value': None, 'cores': threads, 'note': f'the all-cores run could not be made: {type(e).__name__}: {e}'[:300]}
             log(f'pure-PyTorch CPU step on {threads} threads: not through its first steps of {n} envs after {deadline_s:.0f}s')
             return {'value': None, 'cores': threads, 'upper_bound': n*2/deadline_s,
                     'note': f'with torch.set_num_threads({threads}) the step of {n} envs did not get through two steps (one to warm up) in '
