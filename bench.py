@@ -201,35 +201,31 @@ def env_step_fps(device, n_core_envs=4096, steps=40, warmup=8):
 
     out = {}
     np.random.seed(0); torch.manual_seed(0)
-    env = Explorer(n_core_envs, device=device, geometries=geometries)
-    log('Explorer built')
-    eager, graphed = rate(env, n_core_envs)
-    log('Explorer timed')
-    del env
-    out['explorer'] = {'fps': eager, 'fps_hip_graph': graphed,
-                       'env': f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU', 'distinct_floorplans': plans}
-    torch.cuda.empty_cache()
-    # BASELINE config 2 says "depth-only": the same env without the RGB observation - the renderer's colourless instantiation
-    env = Explorer(n_core_envs, device=device, geometries=geometries, depth_only=True)
-    eager, graphed = rate(env, n_core_envs)
-    del env
-    out['explorer_depth_only'] = {'fps': eager, 'fps_hip_graph': graphed,
-                                  'env': f'Explorer({n_core_envs}, depth_only=True): 1 agent, 256 rays -> 64 px D+IMU', 'distinct_floorplans': plans}
-    torch.cuda.empty_cache()
     from megastep_amd.demo import Minimal
-    env = Minimal(n_core_envs, device=device)
-    eager, graphed = rate(env, n_core_envs)
-    del env
-    out['minimal'] = {'fps': eager, 'fps_hip_graph': graphed,
-                      'env': f"Minimal({n_core_envs}): the reference's tutorial env (one agent in a 5 m box, SimpleMovement, 64 rays RGB) - "
-                             f"one launch a step (ms_move_step_render)"}
-    torch.cuda.empty_cache()
-    env = Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries)
-    log('Deathmatch built')
-    eager, graphed = rate(env, 4*n_core_envs)
-    out['deathmatch'] = {'fps': eager, 'fps_hip_graph': graphed,
-                         'env': f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU',
-                         'distinct_floorplans': plans}
+
+    def leg(key, make, n, what, **more):
+        """One env's rates; a leg that fails leaves its reason in the line and the others go on."""
+        try:
+            env = make()
+            log(f'{key} built')
+            eager, graphed = rate(env, n)
+            del env
+            out[key] = {'fps': eager, 'fps_hip_graph': graphed, 'env': what, **more}
+        except Exception as e:                                             # noqa: BLE001
+            log(f'env.step leg {key} FAILED: {type(e).__name__}: {e}')
+            out[key] = {'fps': None, 'fps_hip_graph': None, 'env': what, 'error': f'{type(e).__name__}: {e}'[:400]}
+        torch.cuda.empty_cache()
+
+    leg('explorer', lambda: Explorer(n_core_envs, device=device, geometries=geometries), n_core_envs,
+        f'Explorer({n_core_envs}): 1 agent, 256 rays -> 64 px RGB+D+IMU', distinct_floorplans=plans)
+    # BASELINE config 2 says "depth-only": the same env without the RGB observation - the renderer's colourless instantiation
+    leg('explorer_depth_only', lambda: Explorer(n_core_envs, device=device, geometries=geometries, depth_only=True), n_core_envs,
+        f'Explorer({n_core_envs}, depth_only=True): 1 agent, 256 rays -> 64 px D+IMU', distinct_floorplans=plans)
+    leg('minimal', lambda: Minimal(n_core_envs, device=device), n_core_envs,
+        f"Minimal({n_core_envs}): the reference's tutorial env (one agent in a 5 m box, SimpleMovement, 64 rays RGB) - one launch a step "
+        f"(ms_move_step_render)")
+    leg('deathmatch', lambda: Deathmatch(4*n_core_envs, 4, device=device, geometries=geometries), 4*n_core_envs,
+        f'Deathmatch({4*n_core_envs}, 4): {n_core_envs} core envs x 4 agents, 512 rays -> 128 px RGB+D+IMU', distinct_floorplans=plans)
     return out
 
 
@@ -723,53 +719,69 @@ def other_shapes(dev, steps=20, warmup=5):
         log(f'{tag}: world built in {c.build_seconds:.1f}s')
         return c
 
-    c = world('C2', 4096, 1, 64, 130., n_unique=plan_count(4096, 1))
-    out['c2_rgbd'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 2 (Explorer shape, one floorplan per env) with all five planes')
-    out['c2_depth_only'] = shape_entry(dev, c, steps, warmup, fields=('distances',),
-                                       note="BASELINE config 2 as stated: depth-only - render_kernel<2,1,1,0,1>, no shading pass")
-    out['c2_rgbd_one_launch'] = shape_entry(dev, c, steps, warmup, one_launch=True,
-                                            note='BASELINE config 2 with all five planes, the step as ONE launch (ms_step_render)')
-    out['c2_depth_only_one_launch'] = shape_entry(dev, c, steps, warmup, fields=('distances',), one_launch=True,
-                                                  note='BASELINE config 2 as stated (depth-only), the step as ONE launch: render_kernel<2,1,1,0,1,1>')
-    del c
-    torch.cuda.empty_cache()
-    c = world('C3', 4096, 4, 128, 70., n_unique=plan_count(4096, 4))
-    out['c3'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 3 (Deathmatch shape at 128 rays)')
-    c512 = core_.Core(c.scenery, res=512, fov=70., fps=10)
-    c512.agents.positions[:], c512.agents.angles[:] = c.agents.positions, c.agents.angles
-    del c
-    out['r512'] = shape_entry(dev, c512, steps, warmup, note="the reference Deathmatch's own resolution (512 rays -> 128 px)")
-    del c512
-    torch.cuda.empty_cache()
-    c = world('C5 share', 32768, 1, 256, 130., n_unique=C5_PLANS, large=True, fast=True)
-    out['c5_per_gpu_share'] = shape_entry(dev, c, steps, warmup, note=f'BASELINE config 5 / 8 GPUs: 32768 envs of 800-1200 walls on {C5_PLANS} distinct '
-                                          'plans tiled - the diversity of the reference, whose cubicasa.sample tiles 4492 geometries '
-                                          '(megastep/cubicasa.py:177-224); wall grid un-coarsened (see wall_grid)')
-    del c
-    torch.cuda.empty_cache()
-    c = world('C5 share, 64 plans', 32768, 1, 256, 130., n_unique=64, large=True, fast=True)
-    out['c5_per_gpu_share_64_plans'] = shape_entry(dev, c, steps, warmup, note="the same on rounds 3-4's 64 distinct plans (a 0.5 GB wall grid that "
-                                                   "lives in the caches): for continuity, not the figure of record")
-    del c
-    torch.cuda.empty_cache()
-    c = world('headline, 4096 plans', 4096, 4, 64, 130., n_unique=4096)
-    out['headline_4096_plans'] = shape_entry(dev, c, steps, warmup, note="the headline shape on ONE DISTINCT FLOORPLAN PER CORE ENV - what the reference's "
-                                             "Deathmatch(16384, 4) builds (deathmatch.py:24: cubicasa.sample(n_envs // 4) for its n_envs // 4 core envs; "
-                                             "SURVEY 8(d)'s 'N // 4 tiled', which the headline follows, reads that line as a quarter of that)")
-    del c
-    torch.cuda.empty_cache()
-    c = world('headline, oblique plans', 4096, 4, 64, 130., n_unique=plan_count(4096, 4), oblique=True)
-    c.oblique = True
-    out['headline_oblique'] = shape_entry(dev, c, steps, warmup, note="the headline shape on floorplans turned by seeded angles, with diagonal partitions "
-                                          "(cubicasa.sample(oblique=True)): the reference's walls are exteriors of arbitrary SVG polygons "
-                                          "(geometry.py:43-57), the synthetic generator's are axis-aligned - same plan count as the headline")
-    del c
-    torch.cuda.empty_cache()
-    c = world('headline, 460 plans', 4096, 4, 64, 130., legacy=True)
-    out['headline_460_plans'] = shape_entry(dev, c, steps, warmup, note="the headline shape on rounds 1-3's floorplan pool (the training "
-                                            "split of a 512-plan sample), for continuity with BENCH_r01..r03")
-    del c
-    torch.cuda.empty_cache()
+    def guard(tag, fn):
+        """One world's shapes: if it fails (a GPU too small or too busy for C5's grid, say) the line says so under
+        `<tag>_error` and carries on with the next world."""
+        try:
+            fn()
+        except Exception as e:                                             # noqa: BLE001
+            log(f'shapes: {tag} FAILED: {type(e).__name__}: {e}')
+            out[tag + '_error'] = f'{type(e).__name__}: {e}'[:400]
+        torch.cuda.empty_cache()
+
+    def _c2():
+        c = world('C2', 4096, 1, 64, 130., n_unique=plan_count(4096, 1))
+        out['c2_rgbd'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 2 (Explorer shape, one floorplan per env) with all five planes')
+        out['c2_depth_only'] = shape_entry(dev, c, steps, warmup, fields=('distances',),
+                                           note="BASELINE config 2 as stated: depth-only - render_kernel<2,1,1,0,1>, no shading pass")
+        out['c2_rgbd_one_launch'] = shape_entry(dev, c, steps, warmup, one_launch=True,
+                                                note='BASELINE config 2 with all five planes, the step as ONE launch (ms_step_render)')
+        out['c2_depth_only_one_launch'] = shape_entry(dev, c, steps, warmup, fields=('distances',), one_launch=True,
+                                                      note='BASELINE config 2 as stated (depth-only), the step as ONE launch: render_kernel<2,1,1,0,1,1>')
+    guard('c2', _c2)
+
+    def _c3_r512():
+        c = world('C3', 4096, 4, 128, 70., n_unique=plan_count(4096, 4))
+        out['c3'] = shape_entry(dev, c, steps, warmup, note='BASELINE config 3 (Deathmatch shape at 128 rays)')
+        c512 = core_.Core(c.scenery, res=512, fov=70., fps=10)
+        c512.agents.positions[:], c512.agents.angles[:] = c.agents.positions, c.agents.angles
+        out['r512'] = shape_entry(dev, c512, steps, warmup, note="the reference Deathmatch's own resolution (512 rays -> 128 px)")
+    guard('c3_r512', _c3_r512)
+
+    def _c5():
+        c = world('C5 share', 32768, 1, 256, 130., n_unique=C5_PLANS, large=True, fast=True)
+        out['c5_per_gpu_share'] = shape_entry(dev, c, steps, warmup, note=f'BASELINE config 5 / 8 GPUs: 32768 envs of 800-1200 walls on {C5_PLANS} distinct '
+                                              'plans tiled - the diversity of the reference, whose cubicasa.sample tiles 4492 geometries '
+                                              '(megastep/cubicasa.py:177-224); wall grid un-coarsened (see wall_grid)')
+    guard('c5', _c5)
+
+    def _c5_64():
+        c = world('C5 share, 64 plans', 32768, 1, 256, 130., n_unique=64, large=True, fast=True)
+        out['c5_per_gpu_share_64_plans'] = shape_entry(dev, c, steps, warmup, note="the same on rounds 3-4's 64 distinct plans (a 0.5 GB wall grid that "
+                                                       "lives in the caches): for continuity, not the figure of record")
+    guard('c5_64', _c5_64)
+
+    def _headline_4096():
+        c = world('headline, 4096 plans', 4096, 4, 64, 130., n_unique=4096)
+        out['headline_4096_plans'] = shape_entry(dev, c, steps, warmup, note="the headline shape on ONE DISTINCT FLOORPLAN PER CORE ENV - what the reference's "
+                                                 "Deathmatch(16384, 4) builds (deathmatch.py:24: cubicasa.sample(n_envs // 4) for its n_envs // 4 core envs; "
+                                                 "SURVEY 8(d)'s 'N // 4 tiled', which the headline follows, reads that line as a quarter of that)")
+    guard('headline_4096', _headline_4096)
+
+    def _headline_oblique():
+        c = world('headline, oblique plans', 4096, 4, 64, 130., n_unique=plan_count(4096, 4), oblique=True)
+        c.oblique = True
+        out['headline_oblique'] = shape_entry(dev, c, steps, warmup, note="the headline shape on floorplans turned by seeded angles, with diagonal partitions "
+                                              "(cubicasa.sample(oblique=True)): the reference's walls are exteriors of arbitrary SVG polygons "
+                                              "(geometry.py:43-57), the synthetic generator's are axis-aligned - same plan count as the headline")
+    guard('headline_oblique', _headline_oblique)
+
+    def _headline_460():
+        c = world('headline, 460 plans', 4096, 4, 64, 130., legacy=True)
+        out['headline_460_plans'] = shape_entry(dev, c, steps, warmup, note="the headline shape on rounds 1-3's floorplan pool (the training "
+                                                "split of a 512-plan sample), for continuity with BENCH_r01..r03")
+    guard('headline_460', _headline_460)
+
     return out
 
 
@@ -983,19 +995,31 @@ def main(argv=None):
         out['scaling_efficiency'] = {'vs': os.path.basename(args.baseline_line), 'n1_value': base['value'], 'n1_gpus': base.get('n_gpus', 1),
                                      'efficiency': value/(world*base['value']/max(base.get('n_gpus', 1), 1))}
     if extras:
+        def leg(name, fn):
+            """An auxiliary leg of the line: what it returns - or, if it fails, the reason in its place. The headline (`value`,
+            `roofline`) has been measured by now and is printed whatever happens to the legs after it."""
+            try:
+                return fn()
+            except Exception as e:                                         # noqa: BLE001 (reported, not swallowed: the line says what failed)
+                import traceback
+                log(f'{name} FAILED: {type(e).__name__}: {e}')
+                torch.cuda.empty_cache()
+                return {'error': f'{type(e).__name__}: {e}'[:400], 'where': traceback.format_exc(limit=3)[-600:]}
         if not args.no_cpu_baseline:
-            out.update(cpu_baselines(core))
+            got = leg('cpu baselines', lambda: cpu_baselines(core))
+            out.update(got if 'error' not in got else {'cpu_baseline': {'value': None, 'unit': 'env-steps/s', 'cores': 0, 'kind': 'port',
+                                                                        'sample': 'failed', **got}})
             log('cpu baselines done')
         if not args.no_env_fps:
-            out['env_step_headline_shape'] = headline_env_step(dev, core)
+            out['env_step_headline_shape'] = leg('env.step at the headline shape', lambda: headline_env_step(dev, core))
             log('env.step at the headline shape done')
         del core, scenery
         torch.cuda.empty_cache()
         if not args.no_shapes:
-            out['shapes'] = other_shapes(dev)
+            out['shapes'] = leg('other shapes', lambda: other_shapes(dev))
             log('other shapes done')
         if not args.no_env_fps:
-            out['env_step'] = env_step_fps(device)
+            out['env_step'] = leg('env-step rates', lambda: env_step_fps(device))
             log('env-step rates done')
     if rank == 0:
         print(json.dumps(out), flush=True)
