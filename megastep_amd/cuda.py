@@ -965,7 +965,10 @@ def render(scenery, agents, fields=None, pooled=None, telemetry=False, out=None,
     # (what an `out` must have been made for: put together only when one is handed over, or asked of a result later)
     spec = (n, a, cfg.res, fields, pooled, dev, seen_ptrs)
     if out is not None:
-        if _render_key(getattr(out, '_spec', None)) != _render_key(spec):
+        made_for = getattr(out, '_key', None)
+        if made_for is None:
+            made_for = out._key = _render_key(getattr(out, '_spec', None))   # (once per result)
+        if made_for != _render_key(spec):
             raise RuntimeError('`out` must come from a render call with the same shapes, fields and pooling')
         result = out
     else:
